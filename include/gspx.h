@@ -1,0 +1,144 @@
+/*
+ * gspx.h — C-ABI of libgspx: MI355X (gfx950) Chebyshev graph-filtering engine.
+ *
+ * Drop-in boundary for ONE hot path of epfl-lts2/pygsp (a pure-Python library, so the
+ * "FFI" a maintainer binds is ctypes):
+ *
+ *   pygsp/filters/approximations.py:58-114   cheby_op(G, c, signal)      -> gspx_cheby_filter*
+ *   pygsp/filters/filter.py:303-322          Filter.filter analysis/synthesis dispatch
+ *   pygsp/graphs/graph.py:510-630            Graph.compute_laplacian     -> gspx_graph_create_from_w
+ *   pygsp/graphs/graph.py:830-838            Graph.dw                    -> gspx_graph_download_dw
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; gspx_last_error() returns a
+ *     thread-local message for the last failing call on this thread.  Nothing throws across
+ *     the boundary, nothing calls exit().
+ *   - host pointers are borrowed for the duration of the call only.
+ *   - device memory is owned by handles (ctx / graph / buf) and freed by *_destroy / *_free.
+ *   - one ctx = one device + one HIP stream.  Calls on one ctx must be serialised by the
+ *     caller; different ctx may be driven from different threads (ctypes drops the GIL).
+ *   - no torch / numpy types appear here: plain pointers and sizes.
+ */
+#ifndef GSPX_H
+#define GSPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gspx_ctx gspx_ctx;
+typedef struct gspx_graph gspx_graph;
+typedef struct gspx_buf gspx_buf;
+
+/* element types */
+#define GSPX_F32 0
+#define GSPX_F64 1
+
+/* Laplacian types (graph.py:618-628) */
+#define GSPX_LAP_COMBINATORIAL 0
+#define GSPX_LAP_NORMALIZED 1
+
+/* filter modes (filter.py:307-322) */
+#define GSPX_ANALYSIS 0  /* x: [N][Nsig]       -> y: [Nf][N][Nsig] */
+#define GSPX_SYNTHESIS 1 /* x: [Nf][N][Nsig]   -> y: [N][Nsig]     */
+
+/* status codes */
+#define GSPX_OK 0
+#define GSPX_ERR_INVALID 1 /* bad argument (shape / dtype / null)   -> ValueError  */
+#define GSPX_ERR_COEFF 2   /* M < 2 (approximations.py:83-84)       -> TypeError   */
+#define GSPX_ERR_HIP 3     /* HIP runtime failure                   -> RuntimeError*/
+#define GSPX_ERR_NODEVICE 4
+
+const char* gspx_last_error(void);
+const char* gspx_version(void);
+
+/* ---- devices / contexts --------------------------------------------------------------- */
+int gspx_device_count(int* n);
+int gspx_ctx_create(int device, gspx_ctx** out);
+int gspx_ctx_destroy(gspx_ctx* ctx);
+int gspx_ctx_sync(gspx_ctx* ctx);
+/* tuning knobs (integers).  Unknown key -> GSPX_ERR_INVALID.  Keys:
+ *   "kernel"      0 auto, 1 panel (wave-per-row, scalar CSR metadata), 2 narrow (sub-wave rows)
+ *   "vec"         0 auto, else elements per lane (1,2,4)
+ *   "rows_per_wave"  panel kernel: consecutive rows per wave (default 8)
+ *   "narrow_g_log2"  narrow kernel: log2 of lanes splitting one row's entries
+ *   "xcd_remap"   1 (default) contiguous row ranges per XCD, 0 plain order
+ *   "combine"     0 auto, 1 fused flush every 3rd step, 2 deferred combine (keep all T_k)
+ *   "graph_launch" 1 capture the K-step loop in a hipGraph (default 0)
+ */
+int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value);
+int gspx_ctx_get_option(gspx_ctx* ctx, const char* key, int64_t* value);
+
+/* ---- device buffers (for device-resident chaining and honest kernel-only timing) ------- */
+int gspx_buf_alloc(gspx_ctx* ctx, int64_t bytes, gspx_buf** out);
+int gspx_buf_free(gspx_buf* buf);
+int gspx_buf_upload(gspx_buf* buf, const void* host, int64_t bytes);
+int gspx_buf_download(gspx_buf* buf, void* host, int64_t bytes);
+int gspx_buf_ptr(gspx_buf* buf, void** device_ptr); /* raw device pointer (interop) */
+int gspx_buf_bytes(gspx_buf* buf, int64_t* bytes);
+
+/* ---- graphs ---------------------------------------------------------------------------- */
+/* Upload the (symmetric, canonical CSR: sorted indices, no duplicates, no explicit zeros)
+ * weight matrix W and build the Laplacian ON DEVICE.  Replaces graph.py:618-628 (+ dw,
+ * graph.py:830-838).  Directed graphs must be symmetrised by the caller first
+ * (graph.py:613-616).  data_dtype: dtype of `data`; compute_dtype: dtype of L and of all
+ * filtering arithmetic.  `perm` (nullable, length N): vertex ordering used INTERNALLY only
+ * (perm[new] = old); inputs and outputs of every call stay in the caller's vertex order. */
+int gspx_graph_create_from_w(gspx_ctx* ctx, int64_t N, int64_t nnz, const int32_t* indptr,
+                             const int32_t* indices, const void* data, int data_dtype,
+                             int lap_type, int compute_dtype, const int32_t* perm,
+                             gspx_graph** out);
+/* Upload a host-built Laplacian (bit-parity mode; also for directed graphs whose L the
+ * reference builds through utils.symmetrize).  Same CSR requirements. */
+int gspx_graph_create_from_l(gspx_ctx* ctx, int64_t N, int64_t nnz, const int32_t* indptr,
+                             const int32_t* indices, const void* data, int data_dtype,
+                             int compute_dtype, const int32_t* perm, gspx_graph** out);
+int gspx_graph_destroy(gspx_graph* g);
+int gspx_graph_n(gspx_graph* g, int64_t* N);
+/* nnz of the canonical Laplacian (explicit zeros dropped, as scipy does) */
+int gspx_graph_nnz_l(gspx_graph* g, int64_t* nnz);
+/* number of stored entries of the internal padded layout (diagnostics / roofline maths) */
+int gspx_graph_nnz_internal(gspx_graph* g, int64_t* nnz);
+/* canonical L in the caller's vertex order; data in the graph's compute dtype */
+int gspx_graph_download_l(gspx_graph* g, int32_t* indptr, int32_t* indices, void* data);
+/* weighted degree (only for graphs created from W); compute dtype */
+int gspx_graph_download_dw(gspx_graph* g, void* dw);
+/* wall-clock milliseconds of the device-side build (H2D excluded) */
+int gspx_graph_build_ms(gspx_graph* g, double* ms);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* Order-(M-1) Chebyshev filtering, whole K-loop inside one call.
+ *   coeffs : host, Nf x M row-major float64 (as compute_cheby_coeff returns them; c[.,0] is
+ *            halved inside, approximations.py:103)
+ *   x, y   : DEVICE pointers, compute dtype, row-major, contiguous (layouts above)
+ *   lmax   : the value the reference would read from G.lmax (approximations.py:93)
+ *   kernel_ms (nullable): device time of the whole call (HIP events on the ctx stream)
+ * Errors: M < 2 -> GSPX_ERR_COEFF; Nf < 1, Nsig < 0, lmax <= 0, null pointers -> GSPX_ERR_INVALID.
+ * Nsig == 0 is a no-op. */
+int gspx_cheby_filter_dev(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
+                          int64_t Nsig, const void* x_dev, void* y_dev, int mode,
+                          double* kernel_ms);
+/* Same with HOST pointers (one H2D + one D2H around the device call). */
+int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
+                      int64_t Nsig, const void* x_host, void* y_host, int mode,
+                      double* kernel_ms);
+
+/* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
+ *   out[0] total device time, out[1] time inside the recurrence-step launches only,
+ *   out[2] number of step launches, out[3] permute-in/copy time, out[4] combine time */
+int gspx_last_timing(gspx_ctx* ctx, double out[5]);
+
+/* Host-only: the step schedule the engine would run for (Nf, M) under the ctx's current
+ * options, for CPU-side verification of the schedule logic (no device work).  Each of the
+ * K = M-1 rows of `plan` is 4 + 3*Nf doubles:
+ *   [scale, gamma, flush (0 none / 1 write / 2 accumulate), final (0/1),
+ *    then for each filter f: w_new, w_cur, w_old]
+ * `plan` must hold (M-1)*(4+3*Nf) doubles.  a1 = a2 = lmax/2 as approximations.py:93-96. */
+int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, double* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPX_H */

@@ -1,0 +1,1106 @@
+// gspx.hip — host side of libgspx (C-ABI in include/gspx.h) for MI355X / gfx950.
+//
+// Replaces, for ONE hot path of epfl-lts2/pygsp:
+//   pygsp/filters/approximations.py:58-114  cheby_op           -> gspx_cheby_filter[_dev]
+//   pygsp/filters/filter.py:313-322         synthesis loop     -> mode GSPX_SYNTHESIS
+//   pygsp/graphs/graph.py:510-630, 830-838  compute_laplacian  -> gspx_graph_create_from_w
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gspx.hip -o libgspx.so
+#include "gspx_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gspx.h"
+
+using namespace gspx;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int set_err(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return set_err(GSPX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                     __FILE__, __LINE__);                                                   \
+  } while (0)
+
+#define CHK(expr)               \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != GSPX_OK) return rc_; \
+  } while (0)
+
+extern "C" const char* gspx_last_error(void) { return g_err.c_str(); }
+extern "C" const char* gspx_version(void) { return "gspx 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// small RAII device allocation
+// ------------------------------------------------------------------------------------------------
+struct DevMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  ~DevMem() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  int alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return set_err(GSPX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    return GSPX_OK;
+  }
+  int ensure(size_t n) {  // grow-only
+    if (n <= bytes && p) return GSPX_OK;
+    return alloc(n);
+  }
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct Options {
+  int64_t kernel = 0;         // 0 auto, 1 panel, 2 narrow
+  int64_t vec = 0;            // 0 auto
+  int64_t rows_per_wave = 8;
+  int64_t narrow_g_log2 = 2;
+  int64_t xcd_remap = 1;
+  int64_t combine = 0;        // 0 auto, 1 fused flush, 2 deferred
+  int64_t graph_launch = 0;
+  int64_t ws_limit_mb = 65536;  // workspace budget per filter call
+  int64_t max_batch = 0;        // 0 = no extra cap on signals per batch
+};
+
+struct gspx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Options opt;
+  // workspace (grow-only, reused across calls)
+  DevMem ws_t;      // T_k panels
+  DevMem ws_r;      // accumulators
+  DevMem ws_w;      // per-step flush weights / combine coefficients
+  DevMem io_x, io_y;  // staging for the host-pointer entry point
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_pool;
+  double timing[5] = {0, 0, 0, 0, 0};
+};
+
+struct gspx_buf {
+  gspx_ctx* ctx = nullptr;
+  DevMem mem;
+  int64_t bytes = 0;
+};
+
+struct gspx_graph {
+  gspx_ctx* ctx = nullptr;
+  int64_t N = 0;
+  int dtype = GSPX_F64;
+  bool from_w = false;
+  // canonical Laplacian, caller's vertex order
+  int64_t nnz_l = 0;
+  DevMem lptr, lcol, lval, dw;
+  // internal padded CSR, engine vertex order
+  int64_t nnz_int = 0;
+  DevMem rptr, rcol, rval, fval;
+  DevMem perm, iperm;
+  bool has_perm = false;
+  double fval_lmax = -1.0;
+  double build_ms = 0.0;
+};
+
+static size_t elt_size(int dtype) { return dtype == GSPX_F32 ? 4 : 8; }
+
+// ------------------------------------------------------------------------------------------------
+// devices / contexts
+// ------------------------------------------------------------------------------------------------
+extern "C" int gspx_device_count(int* n) {
+  if (!n) return set_err(GSPX_ERR_INVALID, "gspx_device_count: null output");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    (void)hipGetLastError();
+    return set_err(GSPX_ERR_NODEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *n = c;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
+  if (!out) return set_err(GSPX_ERR_INVALID, "gspx_ctx_create: null output");
+  *out = nullptr;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) {
+    (void)hipGetLastError();
+    return set_err(GSPX_ERR_NODEVICE, "no HIP device visible (libgspx has no CPU fallback)");
+  }
+  if (device < 0 || device >= c)
+    return set_err(GSPX_ERR_INVALID, "device %d out of range (%d visible)", device, c);
+  HIPCHK(hipSetDevice(device));
+  gspx_ctx* ctx = new gspx_ctx();
+  ctx->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return set_err(GSPX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  for (int i = 0; i < 4; ++i) {
+    e = hipEventCreate(&ctx->ev[i]);
+    if (e != hipSuccess) {
+      delete ctx;
+      return set_err(GSPX_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = ctx;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_ctx_destroy(gspx_ctx* ctx) {
+  if (!ctx) return GSPX_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 4; ++i)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  ctx->ws_t.release();
+  ctx->ws_r.release();
+  ctx->ws_w.release();
+  ctx->io_x.release();
+  ctx->io_y.release();
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_ctx_sync(gspx_ctx* ctx) {
+  if (!ctx) return set_err(GSPX_ERR_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GSPX_OK;
+}
+
+static int64_t* option_slot(Options& o, const char* key) {
+  if (!key) return nullptr;
+  if (!strcmp(key, "kernel")) return &o.kernel;
+  if (!strcmp(key, "vec")) return &o.vec;
+  if (!strcmp(key, "rows_per_wave")) return &o.rows_per_wave;
+  if (!strcmp(key, "narrow_g_log2")) return &o.narrow_g_log2;
+  if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
+  if (!strcmp(key, "combine")) return &o.combine;
+  if (!strcmp(key, "graph_launch")) return &o.graph_launch;
+  if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
+  if (!strcmp(key, "max_batch")) return &o.max_batch;
+  return nullptr;
+}
+
+extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx) return set_err(GSPX_ERR_INVALID, "null ctx");
+  int64_t* s = option_slot(ctx->opt, key);
+  if (!s) return set_err(GSPX_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
+  if (!strcmp(key, "rows_per_wave") && (value < 1 || value > 1024))
+    return set_err(GSPX_ERR_INVALID, "rows_per_wave must be in [1, 1024]");
+  if (!strcmp(key, "narrow_g_log2") && (value < 0 || value > 6))
+    return set_err(GSPX_ERR_INVALID, "narrow_g_log2 must be in [0, 6]");
+  if (!strcmp(key, "vec") && !(value == 0 || value == 1 || value == 2 || value == 4))
+    return set_err(GSPX_ERR_INVALID, "vec must be 0, 1, 2 or 4");
+  *s = value;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_ctx_get_option(gspx_ctx* ctx, const char* key, int64_t* value) {
+  if (!ctx || !value) return set_err(GSPX_ERR_INVALID, "null argument");
+  int64_t* s = option_slot(ctx->opt, key);
+  if (!s) return set_err(GSPX_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
+  *value = *s;
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// buffers
+// ------------------------------------------------------------------------------------------------
+extern "C" int gspx_buf_alloc(gspx_ctx* ctx, int64_t bytes, gspx_buf** out) {
+  if (!ctx || !out || bytes < 0) return set_err(GSPX_ERR_INVALID, "gspx_buf_alloc: bad argument");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(ctx->device));
+  gspx_buf* b = new gspx_buf();
+  b->ctx = ctx;
+  b->bytes = bytes;
+  int rc = b->mem.alloc((size_t)bytes);
+  if (rc != GSPX_OK) {
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_buf_free(gspx_buf* b) {
+  if (!b) return GSPX_OK;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  delete b;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_buf_upload(gspx_buf* b, const void* host, int64_t bytes) {
+  if (!b || (!host && bytes > 0) || bytes < 0 || bytes > b->bytes)
+    return set_err(GSPX_ERR_INVALID, "gspx_buf_upload: bad argument");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  if (bytes == 0) return GSPX_OK;
+  HIPCHK(hipMemcpyAsync(b->mem.p, host, (size_t)bytes, hipMemcpyHostToDevice, b->ctx->stream));
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  return GSPX_OK;
+}
+
+extern "C" int gspx_buf_download(gspx_buf* b, void* host, int64_t bytes) {
+  if (!b || (!host && bytes > 0) || bytes < 0 || bytes > b->bytes)
+    return set_err(GSPX_ERR_INVALID, "gspx_buf_download: bad argument");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  if (bytes == 0) return GSPX_OK;
+  HIPCHK(hipMemcpyAsync(host, b->mem.p, (size_t)bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  return GSPX_OK;
+}
+
+extern "C" int gspx_buf_ptr(gspx_buf* b, void** p) {
+  if (!b || !p) return set_err(GSPX_ERR_INVALID, "gspx_buf_ptr: null argument");
+  *p = b->mem.p;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_buf_bytes(gspx_buf* b, int64_t* bytes) {
+  if (!b || !bytes) return set_err(GSPX_ERR_INVALID, "gspx_buf_bytes: null argument");
+  *bytes = b->bytes;
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device exclusive scan of n int32 (in-place safe: out may equal in)
+// ------------------------------------------------------------------------------------------------
+static int scan_exclusive(gspx_ctx* ctx, const int* in, int* out, int n) {
+  if (n <= 0) return GSPX_OK;
+  const int ntiles = (n + GSPX_SCAN_TILE - 1) / GSPX_SCAN_TILE;
+  DevMem sums;
+  CHK(sums.alloc((size_t)ntiles * sizeof(int)));
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, in, n, out,
+                     sums.as<int>());
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, sums.as<int>(), ntiles);
+  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, out, n, sums.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph construction
+// ------------------------------------------------------------------------------------------------
+static int validate_csr(int64_t N, int64_t nnz, const int32_t* indptr, const int32_t* indices) {
+  if (N < 0 || nnz < 0) return set_err(GSPX_ERR_INVALID, "negative N or nnz");
+  if (N >= (int64_t)1 << 30) return set_err(GSPX_ERR_INVALID, "N too large (%lld)", (long long)N);
+  if (nnz >= ((int64_t)1 << 31) - 8 * N - 64)
+    return set_err(GSPX_ERR_INVALID, "nnz too large for int32 indexing (%lld)", (long long)nnz);
+  if (!indptr || (nnz > 0 && !indices)) return set_err(GSPX_ERR_INVALID, "null CSR arrays");
+  if (indptr[0] != 0 || indptr[N] != nnz)
+    return set_err(GSPX_ERR_INVALID, "indptr[0] must be 0 and indptr[N] must equal nnz");
+  for (int64_t i = 0; i < N; ++i) {
+    const int32_t s = indptr[i], e = indptr[i + 1];
+    if (e < s) return set_err(GSPX_ERR_INVALID, "indptr not monotone at row %lld", (long long)i);
+    for (int32_t j = s; j < e; ++j) {
+      const int32_t c = indices[j];
+      if (c < 0 || c >= N)
+        return set_err(GSPX_ERR_INVALID, "column index %d out of range in row %lld", c,
+                       (long long)i);
+      if (j > s && indices[j - 1] >= c)
+        return set_err(GSPX_ERR_INVALID,
+                       "row %lld is not canonical (indices must be strictly ascending)",
+                       (long long)i);
+    }
+  }
+  return GSPX_OK;
+}
+
+template <typename T>
+static void convert_values(const void* data, int data_dtype, int64_t n, std::vector<T>& out) {
+  out.resize((size_t)n);
+  if (data_dtype == GSPX_F32) {
+    const float* p = (const float*)data;
+    for (int64_t i = 0; i < n; ++i) out[(size_t)i] = (T)p[i];
+  } else {
+    const double* p = (const double*)data;
+    for (int64_t i = 0; i < n; ++i) out[(size_t)i] = (T)p[i];
+  }
+}
+
+static int upload_perm(gspx_graph* g, const int32_t* perm) {
+  const int64_t N = g->N;
+  g->has_perm = false;
+  if (!perm || N == 0) return GSPX_OK;
+  std::vector<char> seen((size_t)N, 0);
+  bool identity = true;
+  for (int64_t i = 0; i < N; ++i) {
+    const int32_t p = perm[i];
+    if (p < 0 || p >= N || seen[(size_t)p])
+      return set_err(GSPX_ERR_INVALID, "perm is not a permutation of 0..N-1");
+    seen[(size_t)p] = 1;
+    if (p != i) identity = false;
+  }
+  if (identity) return GSPX_OK;
+  gspx_ctx* ctx = g->ctx;
+  CHK(g->perm.alloc((size_t)N * sizeof(int)));
+  CHK(g->iperm.alloc((size_t)N * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(g->perm.p, perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice,
+                        ctx->stream));
+  const int nb = (int)((N + 255) / 256);
+  hipLaunchKernelGGL(k_inverse_perm, dim3(nb), dim3(256), 0, ctx->stream, g->perm.as<int>(),
+                     (int)N, g->iperm.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  g->has_perm = true;
+  return GSPX_OK;
+}
+
+// canonical L (device) -> internal padded CSR
+template <typename T> static int build_internal(gspx_graph* g) {
+  gspx_ctx* ctx = g->ctx;
+  const int N = (int)g->N;
+  const int nb = std::max(1, (N + 255) / 256);
+  const int* perm = g->has_perm ? g->perm.as<int>() : nullptr;
+  const int* iperm = g->has_perm ? g->iperm.as<int>() : nullptr;
+  DevMem cnt;
+  CHK(cnt.alloc((size_t)(N + 1) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(N + 1) * sizeof(int), ctx->stream));
+  CHK(g->rptr.alloc((size_t)(N + 1 + 16) * sizeof(int)));
+  if (N > 0) {
+    hipLaunchKernelGGL((k_internal_build<T, false>), dim3(nb), dim3(256), 0, ctx->stream,
+                       g->lptr.as<int>(), g->lcol.as<int>(), g->lval.as<T>(), N, perm, iperm,
+                       cnt.as<int>(), (const int*)nullptr, (int*)nullptr, (T*)nullptr);
+    HIPCHK(hipGetLastError());
+  }
+  CHK(scan_exclusive(ctx, cnt.as<int>(), g->rptr.as<int>(), N + 1));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, g->rptr.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost));
+  g->nnz_int = total;
+  // rows past N read as empty: rowptr[N+1 .. N+16] = total
+  hipLaunchKernelGGL((k_fill<int>), dim3(1), dim3(64), 0, ctx->stream, g->rptr.as<int>() + N + 1,
+                     (size_t)16, total);
+  const size_t cap = (size_t)total + 64;
+  CHK(g->rcol.alloc(cap * sizeof(int)));
+  CHK(g->rval.alloc(cap * sizeof(T)));
+  CHK(g->fval.alloc(cap * sizeof(T)));
+  // tail padding (never used by the kernels; keeps any over-read inside the allocation)
+  hipLaunchKernelGGL((k_fill<int>), dim3(1), dim3(64), 0, ctx->stream, g->rcol.as<int>() + total,
+                     (size_t)64, N);
+  hipLaunchKernelGGL((k_fill<T>), dim3(1), dim3(64), 0, ctx->stream, g->rval.as<T>() + total,
+                     (size_t)64, T(0));
+  hipLaunchKernelGGL((k_fill<T>), dim3(1), dim3(64), 0, ctx->stream, g->fval.as<T>() + total,
+                     (size_t)64, T(0));
+  if (N > 0) {
+    hipLaunchKernelGGL((k_internal_build<T, true>), dim3(nb), dim3(256), 0, ctx->stream,
+                       g->lptr.as<int>(), g->lcol.as<int>(), g->lval.as<T>(), N, perm, iperm,
+                       (int*)nullptr, g->rptr.as<int>(), g->rcol.as<int>(), g->rval.as<T>());
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  g->fval_lmax = -1.0;
+  return GSPX_OK;
+}
+
+template <typename T>
+static int create_from_w_t(gspx_graph* g, int64_t nnz, const int32_t* indptr,
+                           const int32_t* indices, const void* data, int data_dtype,
+                           int lap_type) {
+  gspx_ctx* ctx = g->ctx;
+  const int N = (int)g->N;
+  std::vector<T> vals;
+  convert_values<T>(data, data_dtype, nnz, vals);
+  DevMem wptr, wcol, wval, cnt;
+  CHK(wptr.alloc((size_t)(N + 1) * sizeof(int)));
+  CHK(wcol.alloc((size_t)nnz * sizeof(int)));
+  CHK(wval.alloc((size_t)nnz * sizeof(T)));
+  CHK(g->dw.alloc((size_t)std::max(N, 1) * sizeof(T)));
+  HIPCHK(hipMemcpy(wptr.p, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIPCHK(hipMemcpy(wcol.p, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(wval.p, vals.data(), (size_t)nnz * sizeof(T), hipMemcpyHostToDevice));
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const int nb = std::max(1, (N + 255) / 256);
+  CHK(cnt.alloc((size_t)(N + 1) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(N + 1) * sizeof(int), ctx->stream));
+  CHK(g->lptr.alloc((size_t)(N + 1) * sizeof(int)));
+  if (N > 0) {
+    hipLaunchKernelGGL((k_degree<T>), dim3(nb), dim3(256), 0, ctx->stream, wptr.as<int>(),
+                       wval.as<T>(), N, g->dw.as<T>());
+    hipLaunchKernelGGL((k_lap_build<T, false>), dim3(nb), dim3(256), 0, ctx->stream,
+                       wptr.as<int>(), wcol.as<int>(), wval.as<T>(), g->dw.as<T>(), N, lap_type,
+                       cnt.as<int>(), (const int*)nullptr, (int*)nullptr, (T*)nullptr);
+    HIPCHK(hipGetLastError());
+  }
+  CHK(scan_exclusive(ctx, cnt.as<int>(), g->lptr.as<int>(), N + 1));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, g->lptr.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost));
+  g->nnz_l = total;
+  CHK(g->lcol.alloc((size_t)total * sizeof(int)));
+  CHK(g->lval.alloc((size_t)total * sizeof(T)));
+  if (N > 0) {
+    hipLaunchKernelGGL((k_lap_build<T, true>), dim3(nb), dim3(256), 0, ctx->stream,
+                       wptr.as<int>(), wcol.as<int>(), wval.as<T>(), g->dw.as<T>(), N, lap_type,
+                       (int*)nullptr, g->lptr.as<int>(), g->lcol.as<int>(), g->lval.as<T>());
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  CHK(build_internal<T>(g));
+  g->build_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return GSPX_OK;
+}
+
+template <typename T>
+static int create_from_l_t(gspx_graph* g, int64_t nnz, const int32_t* indptr,
+                           const int32_t* indices, const void* data, int data_dtype) {
+  const int N = (int)g->N;
+  std::vector<T> vals;
+  convert_values<T>(data, data_dtype, nnz, vals);
+  CHK(g->lptr.alloc((size_t)(N + 1) * sizeof(int)));
+  CHK(g->lcol.alloc((size_t)nnz * sizeof(int)));
+  CHK(g->lval.alloc((size_t)nnz * sizeof(T)));
+  HIPCHK(hipMemcpy(g->lptr.p, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIPCHK(hipMemcpy(g->lcol.p, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->lval.p, vals.data(), (size_t)nnz * sizeof(T), hipMemcpyHostToDevice));
+  }
+  g->nnz_l = nnz;
+  const auto t0 = std::chrono::steady_clock::now();
+  CHK(build_internal<T>(g));
+  g->build_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return GSPX_OK;
+}
+
+static int graph_create_common(gspx_ctx* ctx, int64_t N, int64_t nnz, const int32_t* indptr,
+                               const int32_t* indices, const void* data, int data_dtype,
+                               int lap_type, int compute_dtype, const int32_t* perm, bool from_w,
+                               gspx_graph** out) {
+  if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null ctx or output");
+  *out = nullptr;
+  if (data_dtype != GSPX_F32 && data_dtype != GSPX_F64)
+    return set_err(GSPX_ERR_INVALID, "data_dtype must be GSPX_F32 or GSPX_F64");
+  if (compute_dtype != GSPX_F32 && compute_dtype != GSPX_F64)
+    return set_err(GSPX_ERR_INVALID, "compute_dtype must be GSPX_F32 or GSPX_F64");
+  if (from_w && lap_type != GSPX_LAP_COMBINATORIAL && lap_type != GSPX_LAP_NORMALIZED)
+    return set_err(GSPX_ERR_INVALID, "Unknown Laplacian type %d", lap_type);
+  if (nnz > 0 && !data) return set_err(GSPX_ERR_INVALID, "null data");
+  CHK(validate_csr(N, nnz, indptr, indices));
+  HIPCHK(hipSetDevice(ctx->device));
+  gspx_graph* g = new gspx_graph();
+  g->ctx = ctx;
+  g->N = N;
+  g->dtype = compute_dtype;
+  g->from_w = from_w;
+  int rc = upload_perm(g, perm);
+  if (rc == GSPX_OK) {
+    if (from_w) {
+      rc = compute_dtype == GSPX_F32
+               ? create_from_w_t<float>(g, nnz, indptr, indices, data, data_dtype, lap_type)
+               : create_from_w_t<double>(g, nnz, indptr, indices, data, data_dtype, lap_type);
+    } else {
+      rc = compute_dtype == GSPX_F32
+               ? create_from_l_t<float>(g, nnz, indptr, indices, data, data_dtype)
+               : create_from_l_t<double>(g, nnz, indptr, indices, data, data_dtype);
+    }
+  }
+  if (rc != GSPX_OK) {
+    delete g;
+    return rc;
+  }
+  *out = g;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_create_from_w(gspx_ctx* ctx, int64_t N, int64_t nnz,
+                                        const int32_t* indptr, const int32_t* indices,
+                                        const void* data, int data_dtype, int lap_type,
+                                        int compute_dtype, const int32_t* perm,
+                                        gspx_graph** out) {
+  return graph_create_common(ctx, N, nnz, indptr, indices, data, data_dtype, lap_type,
+                             compute_dtype, perm, true, out);
+}
+
+extern "C" int gspx_graph_create_from_l(gspx_ctx* ctx, int64_t N, int64_t nnz,
+                                        const int32_t* indptr, const int32_t* indices,
+                                        const void* data, int data_dtype, int compute_dtype,
+                                        const int32_t* perm, gspx_graph** out) {
+  return graph_create_common(ctx, N, nnz, indptr, indices, data, data_dtype, 0, compute_dtype,
+                             perm, false, out);
+}
+
+extern "C" int gspx_graph_destroy(gspx_graph* g) {
+  if (!g) return GSPX_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  delete g;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_n(gspx_graph* g, int64_t* N) {
+  if (!g || !N) return set_err(GSPX_ERR_INVALID, "null argument");
+  *N = g->N;
+  return GSPX_OK;
+}
+extern "C" int gspx_graph_nnz_l(gspx_graph* g, int64_t* nnz) {
+  if (!g || !nnz) return set_err(GSPX_ERR_INVALID, "null argument");
+  *nnz = g->nnz_l;
+  return GSPX_OK;
+}
+extern "C" int gspx_graph_nnz_internal(gspx_graph* g, int64_t* nnz) {
+  if (!g || !nnz) return set_err(GSPX_ERR_INVALID, "null argument");
+  *nnz = g->nnz_int;
+  return GSPX_OK;
+}
+extern "C" int gspx_graph_build_ms(gspx_graph* g, double* ms) {
+  if (!g || !ms) return set_err(GSPX_ERR_INVALID, "null argument");
+  *ms = g->build_ms;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_download_l(gspx_graph* g, int32_t* indptr, int32_t* indices,
+                                     void* data) {
+  if (!g || !indptr) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (g->nnz_l > 0 && (!indices || !data)) return set_err(GSPX_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpy(indptr, g->lptr.p, (size_t)(g->N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (g->nnz_l > 0) {
+    HIPCHK(hipMemcpy(indices, g->lcol.p, (size_t)g->nnz_l * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(data, g->lval.p, (size_t)g->nnz_l * elt_size(g->dtype),
+                     hipMemcpyDeviceToHost));
+  }
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_download_dw(gspx_graph* g, void* dw) {
+  if (!g || (!dw && g->N > 0)) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (!g->from_w) return set_err(GSPX_ERR_INVALID, "graph was created from L: no degree vector");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  if (g->N > 0)
+    HIPCHK(hipMemcpy(dw, g->dw.p, (size_t)g->N * elt_size(g->dtype), hipMemcpyDeviceToHost));
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// step schedule ("plan")
+// ------------------------------------------------------------------------------------------------
+struct PlanStep {
+  double scale = 1.0, gamma = -1.0;
+  int flush = 0;   // 0 none, 1 write, 2 accumulate
+  int final = 0;
+  std::vector<double> w;  // nf*3: w_new, w_cur, w_old
+};
+
+// Fused-flush schedule.  T_k overwrites T_{k-2} in place, so a term must be folded into the
+// accumulators no later than the step that overwrites it; folding happens every third step
+// (when T_k, T_{k-1}, T_{k-2} are all in registers), i.e. 2/3 of an accumulator pass per step
+// instead of the reference's one read-modify-write per step per filter
+// (approximations.py:108-109).
+//   cp: nf x M coefficients with c[.,0] already halved (approximations.py:103)
+static void make_plan_fused(int nf, int M, const std::vector<double>& cp, bool acc_existing,
+                            bool final_to_y, std::vector<PlanStep>& plan) {
+  const int K = M - 1;
+  plan.assign((size_t)K, PlanStep());
+  int covered = -1;  // T_0..T_covered are already folded
+  bool first = !acc_existing;
+  for (int k = 1; k <= K; ++k) {
+    PlanStep& st = plan[(size_t)k - 1];
+    st.scale = (k == 1) ? 0.5 : 1.0;
+    st.gamma = (k == 1) ? 0.0 : -1.0;
+    st.w.assign((size_t)nf * 3, 0.0);
+    const bool must = (k == K) || (k >= 2 && (k - 2) > covered);
+    if (!must) continue;
+    st.flush = first ? 1 : 2;
+    first = false;
+    st.final = (k == K && final_to_y) ? 1 : 0;
+    for (int f = 0; f < nf; ++f) {
+      const double* c = &cp[(size_t)f * M];
+      if (k > covered) st.w[(size_t)f * 3 + 0] = c[k];
+      if (k - 1 > covered) st.w[(size_t)f * 3 + 1] = c[k - 1];
+      if (k >= 2 && k - 2 > covered) st.w[(size_t)f * 3 + 2] = c[k - 2];
+    }
+    covered = k;
+  }
+}
+
+// Deferred schedule: every T_k is kept, no flush inside the steps.
+static void make_plan_deferred(int nf, int M, std::vector<PlanStep>& plan) {
+  const int K = M - 1;
+  plan.assign((size_t)K, PlanStep());
+  for (int k = 1; k <= K; ++k) {
+    PlanStep& st = plan[(size_t)k - 1];
+    st.scale = (k == 1) ? 0.5 : 1.0;
+    st.gamma = (k == 1) ? 0.0 : -1.0;
+    st.w.assign((size_t)nf * 3, 0.0);
+  }
+}
+
+static void halve_c0(int nf, int M, const double* coeffs, std::vector<double>& cp) {
+  cp.assign(coeffs, coeffs + (size_t)nf * M);
+  for (int f = 0; f < nf; ++f) cp[(size_t)f * M] *= 0.5;
+}
+
+extern "C" int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs,
+                                  double* plan_out) {
+  if (M < 2) return set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape");
+  if (Nf < 1 || !coeffs || !plan_out) return set_err(GSPX_ERR_INVALID, "bad argument");
+  Options opt;
+  if (ctx) opt = ctx->opt;
+  std::vector<double> cp;
+  halve_c0(Nf, M, coeffs, cp);
+  std::vector<PlanStep> plan;
+  const bool deferred = opt.combine == 2 || (opt.combine == 0 && Nf >= 2);
+  if (deferred)
+    make_plan_deferred(Nf, M, plan);
+  else
+    make_plan_fused(Nf, M, cp, false, true, plan);
+  const size_t stride = 4 + 3 * (size_t)Nf;
+  for (size_t k = 0; k < plan.size(); ++k) {
+    double* o = plan_out + k * stride;
+    o[0] = plan[k].scale;
+    o[1] = plan[k].gamma;
+    o[2] = plan[k].flush;
+    o[3] = plan[k].final;
+    for (size_t j = 0; j < 3 * (size_t)Nf; ++j) o[4 + j] = plan[k].w[j];
+  }
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel dispatch
+// ------------------------------------------------------------------------------------------------
+struct Shape {
+  int kernel;  // 1 panel, 2 narrow
+  int vec;
+  int wlog2;
+  int glog2;   // narrow only
+  int gridy;   // panel only
+};
+
+static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap) {
+  Shape s{};
+  const int maxvec = std::min((int)(16 / elt), veccap);
+  int vec = 1;
+  for (int v = maxvec; v >= 1; v /= 2)
+    if (ld % v == 0) { vec = v; break; }
+  while (vec > 1 && ld / vec < 16) vec /= 2;
+  if (opt.vec != 0 && opt.vec <= maxvec && ld % opt.vec == 0) vec = (int)opt.vec;
+  int kernel = (ld <= 4) ? 2 : 1;
+  if (opt.kernel == 2 && ld <= 64) kernel = 2;
+  if (opt.kernel == 1 && ld > 4) kernel = 1;
+  s.kernel = kernel;
+  if (kernel == 1) {
+    s.vec = vec;
+    const int64_t lanes = ld / vec;
+    s.wlog2 = lanes <= 16 ? 4 : (lanes <= 32 ? 5 : 6);
+    s.gridy = (int)((lanes + 63) / 64);
+    s.glog2 = 0;
+  } else {
+    s.vec = 1;
+    int wl = 0;
+    while ((1 << wl) < ld) ++wl;
+    s.wlog2 = wl;
+    s.glog2 = (int)std::min<int64_t>(opt.narrow_g_log2, 6 - wl);
+    s.gridy = 1;
+  }
+  return s;
+}
+
+template <typename T, int VEC, bool FLUSH>
+static void launch_panel_w(const StepArgs<T>& a, int wlog2, dim3 grid, hipStream_t st) {
+#define GSPX_LP(WL)                                                                              \
+  hipLaunchKernelGGL((k_step_panel<T, VEC, WL, FLUSH>), grid, dim3(256), 0, st, a.rowptr, a.col, \
+                     a.val, a.cur, a.wts, a.perm, a)
+  switch (wlog2) {
+    case 4: GSPX_LP(4); break;
+    case 5: GSPX_LP(5); break;
+    default: GSPX_LP(6); break;
+  }
+#undef GSPX_LP
+}
+
+template <typename T, bool FLUSH>
+static void launch_panel(const StepArgs<T>& a, const Shape& s, dim3 grid, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    if (s.vec == 4) return launch_panel_w<T, 4, FLUSH>(a, s.wlog2, grid, st);
+  }
+  if (s.vec == 2) return launch_panel_w<T, 2, FLUSH>(a, s.wlog2, grid, st);
+  return launch_panel_w<T, 1, FLUSH>(a, s.wlog2, grid, st);
+}
+
+template <typename T>
+static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st) {
+  int rpw = (int)opt.rows_per_wave;
+  if (s.kernel == 1) rpw = (rpw + 3) & ~3;  // whole row sets (up to 4 rows per wave pass)
+  a.rows_per_wave = rpw;
+  int rows_per_chunk;
+  if (s.kernel == 1)
+    rows_per_chunk = 4 * rpw;
+  else
+    rows_per_chunk = rpw * (4 << (6 - s.wlog2 - s.glog2));
+  a.nchunks = (a.N + rows_per_chunk - 1) / rows_per_chunk;
+  int gx = a.nchunks;
+  a.cpx = 0;
+  if (opt.xcd_remap) {
+    a.cpx = (a.nchunks + 7) / 8;
+    gx = a.cpx * 8;
+  }
+  dim3 grid((unsigned)gx, (unsigned)s.gridy, 1);
+  if (s.kernel == 1) {
+    if (a.flush) launch_panel<T, true>(a, s, grid, st);
+    else launch_panel<T, false>(a, s, grid, st);
+  } else {
+    if (a.flush)
+      hipLaunchKernelGGL((k_step_narrow<T, true>), grid, dim3(256), 0, st, a, s.wlog2, s.glog2);
+    else
+      hipLaunchKernelGGL((k_step_narrow<T, false>), grid, dim3(256), 0, st, a, s.wlog2, s.glog2);
+  }
+}
+
+template <typename T>
+static void launch_permute_in(const T* x, unsigned ldx, T* out, unsigned ld, int N,
+                              const int* perm, int vec, hipStream_t st) {
+  const size_t total = (size_t)N * (ld / vec);
+  const unsigned nb = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+  if (nb == 0) return;
+  if constexpr (sizeof(T) == 4) {
+    if (vec == 4) {
+      hipLaunchKernelGGL((k_permute_in<T, 4>), dim3(nb), dim3(256), 0, st, x, ldx, out, ld, N, perm);
+      return;
+    }
+  }
+  if (vec == 2)
+    hipLaunchKernelGGL((k_permute_in<T, 2>), dim3(nb), dim3(256), 0, st, x, ldx, out, ld, N, perm);
+  else
+    hipLaunchKernelGGL((k_permute_in<T, 1>), dim3(nb), dim3(256), 0, st, x, ldx, out, ld, N, perm);
+}
+
+template <typename T, int VEC>
+static void launch_combine_v(const T* slots, int nslots, size_t slot_stride, const T* cf, int M,
+                             int nf, int N, unsigned ld, T* y, unsigned ldy, size_t plane_y,
+                             const int* perm, hipStream_t st) {
+  const size_t total = (size_t)N * (ld / VEC);
+  const unsigned nb = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
+  if (nb == 0) return;
+  constexpr int NFB = 8;
+  for (int f0 = 0; f0 < nf; f0 += NFB) {
+    const int here = std::min(NFB, nf - f0);
+    hipLaunchKernelGGL((k_combine<T, VEC, NFB>), dim3(nb), dim3(256), 0, st, slots, nslots,
+                       slot_stride, cf, M, f0, here, N, ld, y, ldy, plane_y, perm, 0);
+  }
+}
+
+template <typename T>
+static void launch_combine(const T* slots, int nslots, size_t slot_stride, const T* cf, int M,
+                           int nf, int N, unsigned ld, T* y, unsigned ldy, size_t plane_y,
+                           const int* perm, int vec, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    if (vec == 4)
+      return launch_combine_v<T, 4>(slots, nslots, slot_stride, cf, M, nf, N, ld, y, ldy, plane_y,
+                                    perm, st);
+  }
+  if (vec == 2)
+    return launch_combine_v<T, 2>(slots, nslots, slot_stride, cf, M, nf, N, ld, y, ldy, plane_y,
+                                  perm, st);
+  return launch_combine_v<T, 1>(slots, nslots, slot_stride, cf, M, nf, N, ld, y, ldy, plane_y,
+                                perm, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the filter
+// ------------------------------------------------------------------------------------------------
+template <typename T> static int ensure_factor(gspx_graph* g, double lmax) {
+  if (g->fval_lmax == lmax) return GSPX_OK;
+  gspx_ctx* ctx = g->ctx;
+  const int N = (int)g->N;
+  // a1 = a2 = lmax/2 (approximations.py:93-96); the reference's arithmetic dtype follows L
+  const T a1 = (T)(lmax / 2.0), a2 = (T)(lmax / 2.0);
+  const T two_over_a1 = T(2) / a1;
+  const int nb = std::max(1, (N + 255) / 256);
+  if (N > 0)
+    hipLaunchKernelGGL((k_factor<T>), dim3(nb), dim3(256), 0, ctx->stream, g->rptr.as<int>(),
+                       g->rcol.as<int>(), g->rval.as<T>(), N, two_over_a1, a2, g->fval.as<T>());
+  HIPCHK(hipGetLastError());
+  g->fval_lmax = lmax;
+  return GSPX_OK;
+}
+
+static hipEvent_t pool_event(gspx_ctx* ctx, size_t i) {
+  while (ctx->ev_pool.size() <= i) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    ctx->ev_pool.push_back(e);
+  }
+  return ctx->ev_pool[i];
+}
+
+// One (sub)problem: nf filters applied to one batch of `ld` signals whose first column is
+// x/y column c0.  x: [N][ldx] (+c0), y: [nf][N][ldy] (+c0).
+template <typename T>
+static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp, const T* x,
+                     unsigned ldx, T* y, unsigned ldy, unsigned ld, bool deferred,
+                     bool acc_existing, bool final_to_y, size_t& ev_idx) {
+  gspx_ctx* ctx = g->ctx;
+  const Options& opt = ctx->opt;
+  hipStream_t st = ctx->stream;
+  const int N = (int)g->N;
+  const int K = M - 1;
+  const size_t U = (size_t)N * ld;  // elements per panel
+  // vector stores into y need aligned rows: cap the lane vector width accordingly
+  int veccap = 4;
+  while (veccap > 1 && ((ldy % veccap) != 0 || (((uintptr_t)y / sizeof(T)) % veccap) != 0))
+    veccap /= 2;
+  const Shape shape = choose_shape(opt, sizeof(T), ld, veccap);
+  const int* perm = g->has_perm ? g->perm.as<int>() : nullptr;
+
+  std::vector<PlanStep> plan;
+  if (deferred)
+    make_plan_deferred(nf, M, plan);
+  else
+    make_plan_fused(nf, M, cp, acc_existing, final_to_y, plan);
+
+  // device-side weights / coefficients
+  std::vector<T> hw;
+  if (deferred) {
+    hw.resize((size_t)nf * M);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (T)cp[i];
+  } else {
+    hw.resize((size_t)K * nf * 3);
+    for (int k = 0; k < K; ++k)
+      for (int j = 0; j < nf * 3; ++j) hw[(size_t)k * nf * 3 + j] = (T)plan[(size_t)k].w[(size_t)j];
+  }
+  CHK(ctx->ws_w.ensure(hw.size() * sizeof(T) + 64));
+  HIPCHK(hipMemcpyAsync(ctx->ws_w.p, hw.data(), hw.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // hw is a stack-owned staging buffer
+
+  const size_t nslots = deferred ? (size_t)M : 2;
+  CHK(ctx->ws_t.ensure(nslots * U * sizeof(T) + 256));
+  if (!deferred) CHK(ctx->ws_r.ensure((size_t)nf * U * sizeof(T) + 256));
+  T* slots = ctx->ws_t.as<T>();
+  T* racc = ctx->ws_r.as<T>();
+
+  hipEvent_t e0 = pool_event(ctx, ev_idx++), e1 = pool_event(ctx, ev_idx++),
+             e2 = pool_event(ctx, ev_idx++), e3 = pool_event(ctx, ev_idx++);
+  if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
+
+  HIPCHK(hipEventRecord(e0, st));
+  // permute-in vector width: x rows must be aligned too
+  int pvec = shape.vec;
+  while (pvec > 1 && ((ldx % pvec) != 0 || (((uintptr_t)x / sizeof(T)) % pvec) != 0)) pvec /= 2;
+  launch_permute_in<T>(x, ldx, slots, ld, N, perm, pvec, st);
+  HIPCHK(hipEventRecord(e1, st));
+
+  StepArgs<T> a{};
+  a.rowptr = g->rptr.as<int>();
+  a.col = g->rcol.as<int>();
+  a.val = g->fval.as<T>();
+  a.N = N;
+  a.ld = ld;
+  a.curbytes = (u32)(U * sizeof(T));
+  a.nf = nf;
+  a.racc = racc;
+  a.y = y;
+  a.ldy = ldy;
+  a.perm = perm;
+  for (int k = 1; k <= K; ++k) {
+    const PlanStep& ps = plan[(size_t)k - 1];
+    if (deferred) {
+      a.cur = slots + (size_t)(k - 1) * U;
+      a.old = k >= 2 ? slots + (size_t)(k - 2) * U : slots;
+      a.out = slots + (size_t)k * U;
+    } else {
+      a.cur = slots + (size_t)((k - 1) & 1) * U;
+      a.old = slots + (size_t)(k & 1) * U;
+      a.out = slots + (size_t)(k & 1) * U;
+    }
+    if (ps.gamma == 0.0) a.old = a.cur;  // never read for its value; keeps the kernel branch-free
+    a.scale = (T)ps.scale;
+    a.gamma = (T)ps.gamma;
+    a.flush = ps.flush;
+    a.final = ps.final;
+    a.wts = ctx->ws_w.as<T>() + (size_t)(k - 1) * nf * 3;
+    launch_step<T>(a, shape, opt, st);
+  }
+  HIPCHK(hipEventRecord(e2, st));
+  if (deferred) {
+    int cvec = shape.vec;
+    while (cvec > 1 && ((ldy % cvec) != 0 || (((uintptr_t)y / sizeof(T)) % cvec) != 0)) cvec /= 2;
+    launch_combine<T>(slots, M, U, ctx->ws_w.as<T>(), M, nf, N, ld, y, ldy, (size_t)N * ldy, perm,
+                      cvec, st);
+  }
+  HIPCHK(hipEventRecord(e3, st));
+  HIPCHK(hipGetLastError());
+  return GSPX_OK;
+}
+
+template <typename T>
+static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
+                        int64_t Nsig, const T* x, T* y, int mode) {
+  gspx_ctx* ctx = g->ctx;
+  const Options& opt = ctx->opt;
+  const int64_t N = g->N;
+  for (int i = 0; i < 5; ++i) ctx->timing[i] = 0;
+  if (N == 0 || Nsig == 0) return GSPX_OK;
+  CHK(ensure_factor<T>(g, lmax));
+
+  std::vector<double> cp;
+  halve_c0(Nf, M, coeffs, cp);
+
+  // final-flush / combine stores use the panel's vector width on y rows of Nsig elements
+  const int K = M - 1;
+  const bool analysis = mode == GSPX_ANALYSIS;
+  bool deferred = analysis && (opt.combine == 2 || (opt.combine == 0 && Nf >= 2));
+
+  // signals per batch: bounded by the 2 GiB buffer-descriptor window and the workspace budget
+  const size_t rowb = (size_t)N * sizeof(T);
+  int64_t max_ld = (int64_t)((((size_t)1 << 31) - 65536) / rowb);
+  if (max_ld < 1)
+    return set_err(GSPX_ERR_INVALID, "graph too large: one signal column exceeds 2 GiB");
+  const size_t budget = (size_t)std::max<int64_t>(opt.ws_limit_mb, 1) << 20;
+  auto ws_per_col = [&](bool def) {
+    return rowb * (def ? (size_t)M : (size_t)(2 + (analysis ? Nf : 1)));
+  };
+  if (deferred && ws_per_col(true) * (size_t)std::min<int64_t>(Nsig, 4) > budget) deferred = false;
+  max_ld = std::min<int64_t>(max_ld, std::max<int64_t>(1, (int64_t)(budget / ws_per_col(deferred))));
+  if (opt.max_batch > 0) max_ld = std::min<int64_t>(max_ld, opt.max_batch);
+  if (max_ld < Nsig && max_ld >= 4) max_ld &= ~(int64_t)3;  // keep batch starts 16-byte friendly
+
+  size_t ev_idx = 0;
+  HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+  const size_t plane_x = (size_t)N * Nsig;  // synthesis: x is [Nf][N][Nsig]
+  for (int64_t c0 = 0; c0 < Nsig; c0 += max_ld) {
+    const unsigned ld = (unsigned)std::min<int64_t>(max_ld, Nsig - c0);
+    if (analysis) {
+      CHK(run_batch<T>(g, Nf, M, cp, x + c0, (unsigned)Nsig, y + c0, (unsigned)Nsig, ld, deferred,
+                       false, true, ev_idx));
+    } else {
+      // out = sum_f p_f(L) s_f  (filter.py:317-321): one single-filter recurrence per feature,
+      // accumulated on device; only the last one writes y.
+      for (int f = 0; f < Nf; ++f) {
+        std::vector<double> cf(cp.begin() + (size_t)f * M, cp.begin() + (size_t)(f + 1) * M);
+        CHK(run_batch<T>(g, 1, M, cf, x + (size_t)f * plane_x + c0, (unsigned)Nsig, y + c0,
+                         (unsigned)Nsig, ld, false, f > 0, f == Nf - 1, ev_idx));
+      }
+    }
+  }
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+  ctx->timing[0] = ms;
+  double t_perm = 0, t_steps = 0, t_comb = 0;
+  for (size_t i = 0; i + 3 < ev_idx; i += 4) {
+    float a = 0, b = 0, c = 0;
+    HIPCHK(hipEventElapsedTime(&a, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+    HIPCHK(hipEventElapsedTime(&b, ctx->ev_pool[i + 1], ctx->ev_pool[i + 2]));
+    HIPCHK(hipEventElapsedTime(&c, ctx->ev_pool[i + 2], ctx->ev_pool[i + 3]));
+    t_perm += a;
+    t_steps += b;
+    t_comb += c;
+  }
+  ctx->timing[1] = t_steps;
+  ctx->timing[2] = (double)(ev_idx / 4) * K;
+  ctx->timing[3] = t_perm;
+  ctx->timing[4] = t_comb;
+  return GSPX_OK;
+}
+
+static int check_filter_args(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
+                             int64_t Nsig, const void* x, void* y, int mode) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (M < 2) return set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape");
+  if (Nf < 1) return set_err(GSPX_ERR_INVALID, "Nf must be >= 1");
+  if (!coeffs) return set_err(GSPX_ERR_INVALID, "null coefficients");
+  if (Nsig < 0) return set_err(GSPX_ERR_INVALID, "negative number of signals");
+  if (mode != GSPX_ANALYSIS && mode != GSPX_SYNTHESIS)
+    return set_err(GSPX_ERR_INVALID, "unknown mode %d", mode);
+  if (!(lmax > 0.0) || !std::isfinite(lmax))
+    return set_err(GSPX_ERR_INVALID, "lmax must be positive and finite (got %g)", lmax);
+  if (Nsig > 0 && g->N > 0 && (!x || !y)) return set_err(GSPX_ERR_INVALID, "null signal pointer");
+  for (int64_t i = 0; i < (int64_t)Nf * M; ++i)
+    if (!std::isfinite(coeffs[i])) return set_err(GSPX_ERR_INVALID, "non-finite coefficient");
+  if (Nsig >= ((int64_t)1 << 31) / 16) return set_err(GSPX_ERR_INVALID, "too many signals");
+  return GSPX_OK;
+}
+
+extern "C" int gspx_cheby_filter_dev(gspx_graph* g, double lmax, int Nf, int M,
+                                     const double* coeffs, int64_t Nsig, const void* x_dev,
+                                     void* y_dev, int mode, double* kernel_ms) {
+  CHK(check_filter_args(g, lmax, Nf, M, coeffs, Nsig, x_dev, y_dev, mode));
+  HIPCHK(hipSetDevice(g->ctx->device));
+  int rc = g->dtype == GSPX_F32
+               ? filter_dev_t<float>(g, lmax, Nf, M, coeffs, Nsig, (const float*)x_dev,
+                                     (float*)y_dev, mode)
+               : filter_dev_t<double>(g, lmax, Nf, M, coeffs, Nsig, (const double*)x_dev,
+                                      (double*)y_dev, mode);
+  if (rc == GSPX_OK && kernel_ms) *kernel_ms = g->ctx->timing[0];
+  return rc;
+}
+
+extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
+                                 int64_t Nsig, const void* x_host, void* y_host, int mode,
+                                 double* kernel_ms) {
+  CHK(check_filter_args(g, lmax, Nf, M, coeffs, Nsig, x_host, y_host, mode));
+  gspx_ctx* ctx = g->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t e = elt_size(g->dtype);
+  const size_t n_in = (size_t)g->N * (size_t)Nsig * (mode == GSPX_ANALYSIS ? 1 : (size_t)Nf);
+  const size_t n_out = (size_t)g->N * (size_t)Nsig * (mode == GSPX_ANALYSIS ? (size_t)Nf : 1);
+  if (n_in == 0 || n_out == 0) {
+    if (kernel_ms) *kernel_ms = 0;
+    return GSPX_OK;
+  }
+  CHK(ctx->io_x.ensure(n_in * e));
+  CHK(ctx->io_y.ensure(n_out * e));
+  HIPCHK(hipMemcpyAsync(ctx->io_x.p, x_host, n_in * e, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  CHK(gspx_cheby_filter_dev(g, lmax, Nf, M, coeffs, Nsig, ctx->io_x.p, ctx->io_y.p, mode,
+                            kernel_ms));
+  HIPCHK(hipMemcpyAsync(y_host, ctx->io_y.p, n_out * e, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GSPX_OK;
+}
+
+extern "C" int gspx_last_timing(gspx_ctx* ctx, double out[5]) {
+  if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null argument");
+  for (int i = 0; i < 5; ++i) out[i] = ctx->timing[i];
+  return GSPX_OK;
+}

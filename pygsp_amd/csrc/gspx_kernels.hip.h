@@ -1,0 +1,763 @@
+// gspx_kernels.hip.h — gfx950 (MI355X / CDNA4) device code of libgspx.
+//
+// Written for wave64 CDNA4 only: no CUDA shims, no multi-backend paths.
+//
+// What is computed (reference: pygsp/filters/approximations.py:93-112):
+//     a1 = a2 = lmax/2
+//     F      = (2/a1) * (L - a2*I)                     ("factor", approximations.py:105)
+//     T_0    = x ;  T_1 = 0.5 * F T_0                  (== (L x - a2 x)/a1, approximations.py:99)
+//     T_k    = F T_{k-1} - T_{k-2}                     (approximations.py:107)
+//     r_f    = 0.5 c_f0 T_0 + sum_{k>=1} c_fk T_k      (approximations.py:103,109)
+//
+// Data layout in HBM:
+//   * signals: row-major [N][ld] panels (ld = number of signals in the batch), so one vertex's
+//     signals are contiguous: a neighbour gather is one coalesced ld*elt-byte read.
+//   * matrix: "padded CSR" in the engine's internal vertex order: every row owns a diagonal
+//     slot, row length is a multiple of 4, pad entries are (col = N, val = 0).  col = N makes
+//     the gather address land exactly at num_records of the buffer descriptor, so the hardware
+//     bounds check returns 0 without touching memory: no predicates, no branches in the gather.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gspx {
+
+typedef unsigned int u32;
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+#define GSPX_POISON 0x80000000u  // voffset >= num_records for every panel we accept (< 2 GiB)
+
+// ---------------------------------------------------------------------------------------------
+// vector-of-T helpers: VEC elements per lane, at most 16 bytes
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC> struct VT;
+
+template <> struct VT<float, 1> {
+  typedef float t;
+  static __device__ __forceinline__ t bload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0));
+  }
+  static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, v), r, o, 0, 0);
+  }
+};
+template <> struct VT<float, 2> {
+  typedef float t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ t bload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(t, __builtin_amdgcn_raw_buffer_load_b64(r, o, 0, 0));
+  }
+  static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, o, 0, 0);
+  }
+};
+template <> struct VT<float, 4> {
+  typedef float t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ t bload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(t, __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 0));
+  }
+  static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, 0);
+  }
+};
+template <> struct VT<double, 1> {
+  typedef double t;
+  static __device__ __forceinline__ t bload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o, 0, 0));
+  }
+  static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, o, 0, 0);
+  }
+};
+template <> struct VT<double, 2> {
+  typedef double t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ t bload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(t, __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 0));
+  }
+  static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int off) { return __shfl_xor(v, off); }
+
+template <typename T, int VEC>
+__device__ __forceinline__ typename VT<T, VEC>::t vec_shfl_xor(typename VT<T, VEC>::t v, int off) {
+  if constexpr (VEC == 1) {
+    return __shfl_xor(v, off);
+  } else {
+    typename VT<T, VEC>::t o;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = __shfl_xor(v[k], off);
+    return o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// arguments of one recurrence step:  out = scale * (F cur) + gamma * old   (+ optional flush)
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct StepArgs {
+  const int* rowptr;  // [N+1] padded-CSR row starts (internal vertex order)
+  const int* col;     // [nnz_int + 64]
+  const T* val;       // [nnz_int + 64] factor values F
+  const T* cur;       // T_{k-1}   [N][ld]
+  const T* old;       // T_{k-2}   [N][ld]   (may alias out; unused when gamma == 0)
+  T* out;             // T_k       [N][ld]
+  int N;
+  u32 ld;        // signals in this batch (elements per row)
+  u32 curbytes;  // N*ld*sizeof(T)  (< 2 GiB)
+  T scale, gamma;
+  // flush: r_f (=|+=) w_new*T_k + w_cur*T_{k-1} + w_old*T_{k-2}
+  int flush;     // 0 none, 1 write, 2 accumulate
+  int final;     // 1: write to y (caller's vertex order, row stride ldy) instead of racc
+  int nf;
+  const T* wts;  // device, [nf][3]
+  T* racc;       // [nf][N][ld] internal accumulators
+  T* y;          // [nf][N][ldy] (already offset to the batch's first column)
+  u32 ldy;
+  const int* perm;  // internal row -> caller's row (nullable = identity)
+  // row -> workgroup mapping
+  int rows_per_wave;
+  int nchunks;      // number of (4*rows_per_wave)-row chunks
+  int cpx;          // chunks per XCD (xcd_remap) or 0 for plain order
+};
+
+// ---------------------------------------------------------------------------------------------
+// PANEL kernel.  W = 2^WLOG2 lanes span the signals of one vertex (VEC each); a wave works on
+// R = 64/W consecutive rows at a time ("row set"), lane group r owning row r of the set.
+//
+//  * Row metadata (rowptr / col / val) is wave-uniform per row, so it travels through the
+//    scalar cache (s_load_dwordx4/x8) and never touches the vector memory pipeline; lane groups
+//    pick their row's entry with v_cndmask.  The vector pipeline carries only the neighbour
+//    gathers (one coalesced buffer_load per stored entry per row), T_{k-2} and T_k.
+//  * Gathers are issued 8 deep per lane (two 4-entry chunks) before the first FMA.  Lanes whose
+//    row has run out of chunks get an out-of-range offset: the descriptor bounds check returns 0
+//    and generates no memory traffic, so there is no divergent control flow in the loop.
+//  * vmcnt retires in order, so the streaming T_{k-2} read of the NEXT row set is issued right
+//    after the current set's first gathers: it is younger than them (does not delay their
+//    wait) and has a whole row-set's latency to arrive.
+// ---------------------------------------------------------------------------------------------
+// Lane group r of a wave picks its row's value out of R wave-uniform (SGPR) values.  The pick
+// is a bitwise blend  a ^ ((a ^ b) & m)  with per-lane masks m in {0, ~0} that are made opaque
+// to the optimiser once per kernel (LaneSel): spelled as selects, LLVM rewrites "select among
+// the R members" into a dynamically indexed private array and the AMDGPU backend parks that in
+// LDS/scratch.  (a ^ b) of two SGPRs is scalar work; the blend costs 2 VALU ops per dword.
+struct LaneSel {
+  u32 m0, m1;  // ~0 where bit 0 / bit 1 of the lane's row index is set
+};
+__device__ __forceinline__ LaneSel make_lane_sel(int r) {
+  LaneSel s;
+  s.m0 = (u32) - (r & 1);
+  s.m1 = (u32) - ((r >> 1) & 1);
+  asm volatile("" : "+v"(s.m0), "+v"(s.m1));
+  return s;
+}
+__device__ __forceinline__ u32 blend(u32 a, u32 b, u32 m) { return a ^ ((a ^ b) & m); }
+__device__ __forceinline__ int blend(int a, int b, u32 m) { return (int)blend((u32)a, (u32)b, m); }
+__device__ __forceinline__ float blend(float a, float b, u32 m) {
+  return __builtin_bit_cast(float, blend(__builtin_bit_cast(u32, a), __builtin_bit_cast(u32, b), m));
+}
+__device__ __forceinline__ double blend(double a, double b, u32 m) {
+  const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+  u32x2 o;
+  o.x = blend(ua.x, ub.x, m);
+  o.y = blend(ua.y, ub.y, m);
+  return __builtin_bit_cast(double, o);
+}
+
+template <typename T, int R> struct RowVals;
+template <typename T> struct RowVals<T, 1> {
+  T a;
+  template <class F> static __device__ __forceinline__ RowVals make(F f) { return RowVals{f(0)}; }
+  __device__ __forceinline__ T at(int) const { return a; }
+  __device__ __forceinline__ T pick(const LaneSel&) const { return a; }
+};
+template <typename T> struct RowVals<T, 2> {
+  T a, b;
+  template <class F> static __device__ __forceinline__ RowVals make(F f) {
+    return RowVals{f(0), f(1)};
+  }
+  __device__ __forceinline__ T at(int q) const { return q == 0 ? a : b; }
+  __device__ __forceinline__ T pick(const LaneSel& s) const { return blend(a, b, s.m0); }
+};
+template <typename T> struct RowVals<T, 4> {
+  T a, b, c, d;
+  template <class F> static __device__ __forceinline__ RowVals make(F f) {
+    return RowVals{f(0), f(1), f(2), f(3)};
+  }
+  __device__ __forceinline__ T at(int q) const { return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d)); }
+  __device__ __forceinline__ T pick(const LaneSel& s) const {
+    return blend(blend(a, b, s.m0), blend(c, d, s.m0), s.m1);
+  }
+};
+
+// per-wave constants of the panel kernel
+template <typename T, int VEC> struct PanelCtx {
+  const int* __restrict__ rowptr;
+  const int* __restrict__ col;
+  const T* __restrict__ val;
+  const T* __restrict__ wts;
+  const int* __restrict__ perm;
+  rsrc_t rc;    // T_{k-1} panel (gathers)
+  rsrc_t rold;  // T_{k-2} panel
+  rsrc_t rout;  // T_k panel (may be the same memory as rold)
+  rsrc_t rra;   // accumulator plane 0 (flush kernels)
+  u32 ldb, lane_off, colel;
+  int r;          // this lane's row within the set
+  LaneSel sel;
+  int row0;       // first row of this wave
+  int nsets;
+  bool lane_on;
+};
+
+// One row set.  `ov_use`/`ra_use` were prefetched by the previous set; `ov_pf`/`ra_pf` receive the
+// prefetch for the next one (distinct registers: the caller alternates two pairs, so no copy -
+// and therefore no wait on the in-flight prefetch - is needed at the top of the loop).
+template <typename T, int VEC, int R, bool FLUSH>
+__device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const StepArgs<T>& a,
+                                              const int it,
+                                              const typename VT<T, VEC>::t& ov_use,
+                                              const typename VT<T, VEC>::t& ra_use,
+                                              typename VT<T, VEC>::t& ov_pf,
+                                              typename VT<T, VEC>::t& ra_pf) {
+  typedef VT<T, VEC> X;
+  typedef typename X::t V;
+  const int srow = __builtin_amdgcn_readfirstlane(c.row0 + it * R);
+  if (srow >= a.N) return false;
+  // rowptr is padded past N with the total entry count, so rows >= N read as empty
+  const RowVals<int, R> rs = RowVals<int, R>::make([&](int q) { return c.rowptr[srow + q]; });
+  const RowVals<int, R> nch = RowVals<int, R>::make(
+      [&](int q) { return (c.rowptr[srow + q + 1] - c.rowptr[srow + q]) >> 2; });  // len % 4 == 0
+  const RowVals<int, R> last =
+      RowVals<int, R>::make([&](int q) { return nch.at(q) > 0 ? nch.at(q) - 1 : 0; });
+  int nmax = nch.at(0);
+  if constexpr (R >= 2) nmax = nch.at(1) > nmax ? nch.at(1) : nmax;
+  if constexpr (R >= 4) {
+    nmax = nch.at(2) > nmax ? nch.at(2) : nmax;
+    nmax = nch.at(3) > nmax ? nch.at(3) : nmax;
+  }
+  const int nch_l = nch.pick(c.sel);
+  const int myrow = srow + c.r;
+  const bool row_on = myrow < a.N && c.lane_on;
+
+  V x0, x1, x2, x3, x4, x5, x6, x7;
+  T v0, v1, v2, v3, v4, v5, v6, v7;
+  V acc = 0;
+  V curv = 0;
+
+  // one gather: entry u of chunk kk of every row of the set
+  // `pm` is 0 for lanes whose row still has chunk kk and GSPX_POISON otherwise; it is opaque to the
+  // optimiser so that the (scalar) col/val loads stay unconditional and batched.
+  auto gather = [&](const RowVals<int, R>& base, const u32 pm, const int u, V& xo, T& vo) {
+    const RowVals<int, R> cs = RowVals<int, R>::make([&](int q) { return c.col[base.at(q) + u]; });
+    const RowVals<T, R> vs = RowVals<T, R>::make([&](int q) { return c.val[base.at(q) + u]; });
+    const int cc = cs.pick(c.sel);
+    vo = vs.pick(c.sel);
+    xo = X::bload(c.rc, ((u32)cc * c.ldb + c.lane_off) | pm);
+  };
+  // issue the 8 gathers of chunks k, k+1 (no FMA yet)
+  auto issue_pair = [&](const int k) {
+    {
+      const RowVals<int, R> base = RowVals<int, R>::make(
+          [&](int q) { return rs.at(q) + 4 * (k < last.at(q) ? k : last.at(q)); });
+      u32 pm = k < nch_l ? 0u : GSPX_POISON;
+      asm volatile("" : "+v"(pm));
+      gather(base, pm, 0, x0, v0);
+      gather(base, pm, 1, x1, v1);
+      gather(base, pm, 2, x2, v2);
+      gather(base, pm, 3, x3, v3);
+    }
+    {
+      const int k1 = k + 1;
+      const RowVals<int, R> base = RowVals<int, R>::make(
+          [&](int q) { return rs.at(q) + 4 * (k1 < last.at(q) ? k1 : last.at(q)); });
+      u32 pm = k1 < nch_l ? 0u : GSPX_POISON;
+      asm volatile("" : "+v"(pm));
+      gather(base, pm, 0, x4, v4);
+      gather(base, pm, 1, x5, v5);
+      gather(base, pm, 2, x6, v6);
+      gather(base, pm, 3, x7, v7);
+    }
+  };
+  auto fma_pair = [&]() {
+    acc += v0 * x0;
+    acc += v1 * x1;
+    acc += v2 * x2;
+    acc += v3 * x3;
+    acc += v4 * x4;
+    acc += v5 * x5;
+    acc += v6 * x6;
+    acc += v7 * x7;
+  };
+
+  // all chunk pairs but the last
+  int k = 0;
+  for (; k + 2 < nmax; k += 2) {
+    issue_pair(k);
+    fma_pair();
+  }
+  // last pair (every row owns a diagonal slot, so nmax >= 1), then the streaming prefetch for the
+  // next row set.  The prefetch is issued AFTER this set's last gathers: vmcnt retires in order,
+  // so being younger it never delays their wait, and it is unconditional (clamped address) so
+  // that the compiler's vmcnt bookkeeping is exact and the final FMA does not wait for it.
+  issue_pair(k);
+  if constexpr (FLUSH) curv = X::bload(c.rc, (u32)myrow * c.ldb + c.lane_off);
+  {
+    const int nrow = myrow + R;
+    const bool pf_on = (it + 1 < c.nsets) && nrow < a.N;
+    const u32 po = pf_on ? (u32)nrow * c.ldb + c.lane_off : GSPX_POISON;
+    ov_pf = X::bload(c.rold, po);
+    if constexpr (FLUSH) ra_pf = X::bload(c.rra, po);
+  }
+  fma_pair();
+
+  // T_k = scale * (F T_{k-1}) + gamma * T_{k-2}; lanes without a row store out of range (dropped)
+  V nv = a.scale * acc;
+  nv += a.gamma * ov_use;  // gamma == 0: the host points `old` at `cur`, the product vanishes
+  X::bstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
+
+  if constexpr (FLUSH) {
+    if (row_on) {
+      const size_t o = (size_t)myrow * a.ld + c.colel;
+      size_t orow = (size_t)myrow;
+      if (a.final && c.perm) orow = (size_t)c.perm[myrow];
+      const size_t plane_r = (size_t)a.N * a.ld;
+      const size_t plane_y = (size_t)a.N * a.ldy;
+      for (int f = 0; f < a.nf; ++f) {
+        const T wn = c.wts[3 * f + 0], wc = c.wts[3 * f + 1], wo = c.wts[3 * f + 2];
+        V res = wn * nv + wc * curv + wo * ov_use;
+        if (a.flush == 2) res += (f == 0) ? ra_use : *(const V*)(a.racc + f * plane_r + o);
+        if (a.final)
+          *(V*)(a.y + f * plane_y + orow * a.ldy + c.colel) = res;
+        else
+          *(V*)(a.racc + f * plane_r + o) = res;
+      }
+    }
+  }
+  return true;
+}
+
+template <typename T, int VEC, int WLOG2, bool FLUSH>
+__global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowptr,
+                                                    const int* __restrict__ col,
+                                                    const T* __restrict__ val,
+                                                    const T* __restrict__ cur,
+                                                    const T* __restrict__ wts,
+                                                    const int* __restrict__ perm,
+                                                    const StepArgs<T> a) {
+  typedef typename VT<T, VEC>::t V;
+  constexpr int W = 1 << WLOG2;
+  constexpr int R = 64 / W;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = lane & (W - 1);
+
+  int chunk = blockIdx.x;
+  if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);  // contiguous row range per XCD
+  if (chunk >= a.nchunks) return;
+
+  PanelCtx<T, VEC> c;
+  c.rowptr = rowptr;
+  c.col = col;
+  c.val = val;
+  c.wts = wts;
+  c.perm = perm;
+  c.r = lane >> WLOG2;
+  c.sel = make_lane_sel(c.r);
+  c.colel = (blockIdx.y * W + w) * VEC;  // first signal handled by this lane
+  c.lane_on = c.colel < a.ld;
+  c.ldb = a.ld * (u32)sizeof(T);
+  c.lane_off = c.lane_on ? c.colel * (u32)sizeof(T) : GSPX_POISON;
+  c.rc = __builtin_amdgcn_make_buffer_rsrc((void*)cur, 0, a.curbytes, 0x00020000);
+  c.rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
+  c.rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
+  c.rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
+  c.row0 = (chunk * 4 + wave) * a.rows_per_wave;
+  c.nsets = a.rows_per_wave / R;
+
+  if (c.row0 >= a.N) return;
+  V ovA = 0, raA = 0, ovB = 0, raB = 0;
+  {
+    typedef VT<T, VEC> X;
+    const int myrow = c.row0 + c.r;
+    const u32 po = myrow < a.N ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON;
+    ovA = X::bload(c.rold, po);
+    if constexpr (FLUSH) raA = X::bload(c.rra, po);
+  }
+#pragma unroll 1
+  for (int it = 0; it < c.nsets; it += 2) {
+    if (!panel_row_set<T, VEC, R, FLUSH>(c, a, it, ovA, raA, ovB, raB)) break;
+    if (it + 1 >= c.nsets) break;
+    if (!panel_row_set<T, VEC, R, FLUSH>(c, a, it + 1, ovB, raB, ovA, raA)) break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NARROW kernel (1..4 signals): several rows per wave; W lanes span the signals, G lanes split a
+// row's entries (per-lane vector loads of col/val, coalesced because a wave's rows are
+// consecutive in the padded CSR), xor-shuffle reduction across the G lanes.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool FLUSH>
+__global__ __launch_bounds__(256) void k_step_narrow(const StepArgs<T> a, const int wlog2,
+                                                     const int glog2) {
+  typedef VT<T, 1> X;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int W = 1 << wlog2, G = 1 << glog2;
+  const int w = lane & (W - 1);
+  const int g = (lane >> wlog2) & (G - 1);
+  const int rlog2 = 6 - wlog2 - glog2;  // rows per wave = 2^rlog2
+  const int r_in_wave = lane >> (wlog2 + glog2);
+
+  int chunk = blockIdx.x;
+  if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);
+  if (chunk >= a.nchunks) return;
+
+  const bool lane_on = (u32)w < a.ld;
+  const u32 ldb = a.ld * (u32)sizeof(T);
+  const u32 lane_off = lane_on ? (u32)w * (u32)sizeof(T) : GSPX_POISON;
+  const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)a.cur, 0, a.curbytes, 0x00020000);
+
+  const int rows_per_pass = 4 << rlog2;  // rows a workgroup covers per pass
+  const int row_begin = chunk * a.rows_per_wave * rows_per_pass;
+#pragma unroll 1
+  for (int i = 0; i < a.rows_per_wave; ++i) {
+    const int row = row_begin + i * rows_per_pass + (wave << rlog2) + r_in_wave;
+    const bool row_on = row < a.N;
+    int s = 0, e = 0;
+    if (row_on) {
+      s = a.rowptr[row];
+      e = a.rowptr[row + 1];
+    }
+    T acc = 0;
+    for (int j = s + g; j < e; j += 2 * G) {
+      const int c0 = a.col[j];
+      const T v0 = a.val[j];
+      const int j1 = j + G;
+      const bool on1 = j1 < e;
+      const int c1 = on1 ? a.col[j1] : a.N;
+      const T v1 = on1 ? a.val[j1] : T(0);
+      const T x0 = X::bload(rc, (u32)c0 * ldb + lane_off);
+      const T x1 = X::bload(rc, (u32)c1 * ldb + lane_off);
+      acc += v0 * x0;
+      acc += v1 * x1;
+    }
+    for (int off = W; off < (W << glog2); off <<= 1) acc += __shfl_xor(acc, off);
+
+    if (row_on && g == 0 && lane_on) {
+      const size_t o = (size_t)row * a.ld + w;
+      T nv = a.scale * acc;
+      T ov = 0;
+      if (a.gamma != T(0)) {
+        ov = a.old[o];
+        nv += a.gamma * ov;
+      }
+      a.out[o] = nv;
+      if constexpr (FLUSH) {
+        const T curv = a.cur[o];
+        size_t orow = (size_t)row;
+        if (a.final && a.perm) orow = (size_t)a.perm[row];
+        const size_t plane_r = (size_t)a.N * a.ld;
+        const size_t plane_y = (size_t)a.N * a.ldy;
+        for (int f = 0; f < a.nf; ++f) {
+          const T wn = a.wts[3 * f + 0], wc = a.wts[3 * f + 1], wo = a.wts[3 * f + 2];
+          T r = wn * nv + wc * curv + wo * ov;
+          if (a.flush == 2) r += a.racc[f * plane_r + o];
+          if (a.final)
+            a.y[f * plane_y + orow * a.ldy + w] = r;
+          else
+            a.racc[f * plane_r + o] = r;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deferred combine (filterbanks): all T_k of the batch are kept ([K+1][N][ld] slots) and the
+// Nf outputs are formed in ONE streaming pass:  y_f = sum_k c'_fk T_k.   This is the
+// tall-skinny contraction [N*ld x (K+1)] . [(K+1) x Nf]; at ~3 flop/byte it is HBM-bound, so
+// plain VALU FMAs (not MFMA) are the right tool.  NFB filters are accumulated per pass.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, int NFB>
+__global__ __launch_bounds__(256) void k_combine(const T* __restrict__ slots, int nslots,
+                                                 size_t slot_stride, const T* __restrict__ cf,
+                                                 int M, int f0, int nf_here, int N, u32 ld, T* y,
+                                                 u32 ldy, size_t plane_y, const int* __restrict__ perm,
+                                                 int accumulate) {
+  typedef typename VT<T, VEC>::t V;
+  const u32 cpr = ld / VEC;  // vector chunks per row
+  const size_t total = (size_t)N * cpr;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * 256) {
+    const u32 row = (u32)(idx / cpr);
+    const u32 ch = (u32)(idx - (size_t)row * cpr);
+    const size_t o = (size_t)row * ld + (size_t)ch * VEC;
+    V acc[NFB];
+#pragma unroll
+    for (int f = 0; f < NFB; ++f) acc[f] = 0;
+    for (int k = 0; k < nslots; ++k) {
+      const V t = *(const V*)(slots + (size_t)k * slot_stride + o);
+#pragma unroll
+      for (int f = 0; f < NFB; ++f)
+        if (f < nf_here) acc[f] += cf[(size_t)(f0 + f) * M + k] * t;
+    }
+    const size_t orow = perm ? (size_t)perm[row] : (size_t)row;
+#pragma unroll
+    for (int f = 0; f < NFB; ++f)
+      if (f < nf_here) {
+        V* dst = (V*)(y + (size_t)(f0 + f) * plane_y + orow * ldy + (size_t)ch * VEC);
+        if (accumulate)
+          *dst = *dst + acc[f];
+        else
+          *dst = acc[f];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// permute-in: T_0[i][c] = x[perm[i]][c0 + c]   (also the plain copy when perm == null)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_permute_in(const T* __restrict__ x, u32 ldx,
+                                                    T* __restrict__ out, u32 ld, int N,
+                                                    const int* __restrict__ perm) {
+  typedef typename VT<T, VEC>::t V;
+  const u32 cpr = ld / VEC;
+  const size_t total = (size_t)N * cpr;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * 256) {
+    const u32 row = (u32)(idx / cpr);
+    const u32 ch = (u32)(idx - (size_t)row * cpr);
+    const size_t src = perm ? (size_t)perm[row] : (size_t)row;
+    *(V*)(out + (size_t)row * ld + (size_t)ch * VEC) =
+        *(const V*)(x + src * ldx + (size_t)ch * VEC);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// graph build kernels (replace graph.py:618-628, 830-838)
+// ---------------------------------------------------------------------------------------------
+// dw[i] = sum_j W_ij, sequential in ascending column order: for an exactly symmetric W this is
+// the same addition order as scipy's column sums W.sum(axis=0) (graph.py:833).
+template <typename T>
+__global__ void k_degree(const int* __restrict__ ptr, const T* __restrict__ val, int N,
+                         T* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  T s = 0;
+  for (int j = ptr[i]; j < ptr[i + 1]; ++j) s += val[j];
+  dw[i] = s;
+}
+
+// d^{-1/2} with the reference's isolated-vertex rule (graph.py:622-624)
+template <typename T> __device__ __forceinline__ T inv_sqrt_deg(T dw) {
+  return dw == T(0) ? T(0) : T(1) / sqrt(dw);
+}
+
+// value of L_ij for an off-diagonal stored W_ij
+template <typename T>
+__device__ __forceinline__ T lap_offdiag(int lap_type, T w, T di, T dj) {
+  if (lap_type == 0) return -w;
+  return -((di * w) * dj);  // (D*W)*D, graph.py:626
+}
+// value of L_ii given dw_i and the (possibly absent) self-loop weight
+template <typename T> __device__ __forceinline__ T lap_diag(int lap_type, T dw, T wii, T di) {
+  if (lap_type == 0) return dw - wii;
+  if (dw == T(0)) return T(0);   // L[disconnected, disconnected] = 0, graph.py:627
+  return T(1) - (di * wii) * di;
+}
+
+// pass 1 (count) / pass 2 (fill) of canonical L = D - W  or  I - D^-1/2 W D^-1/2, zeros dropped
+template <typename T, bool FILL>
+__global__ void k_lap_build(const int* __restrict__ wptr, const int* __restrict__ wcol,
+                            const T* __restrict__ wval, const T* __restrict__ dw, int N,
+                            int lap_type, int* __restrict__ cnt, const int* __restrict__ lptr,
+                            int* __restrict__ lcol, T* __restrict__ lval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const T dwi = dw[i];
+  const T di = lap_type == 1 ? inv_sqrt_deg(dwi) : T(0);
+  // self loop weight
+  T wii = 0;
+  for (int j = wptr[i]; j < wptr[i + 1]; ++j)
+    if (wcol[j] == i) wii = wval[j];
+  const T dval = lap_diag(lap_type, dwi, wii, di);
+  int n = 0;
+  int o = FILL ? lptr[i] : 0;
+  bool diag_done = false;
+  for (int j = wptr[i]; j < wptr[i + 1]; ++j) {
+    const int c = wcol[j];
+    if (c == i) continue;
+    if (!diag_done && c > i) {
+      diag_done = true;
+      if (dval != T(0)) {
+        if (FILL) { lcol[o] = i; lval[o] = dval; ++o; }
+        ++n;
+      }
+    }
+    const T dj = lap_type == 1 ? inv_sqrt_deg(dw[c]) : T(0);
+    const T v = lap_offdiag(lap_type, wval[j], di, dj);
+    if (v != T(0)) {
+      if (FILL) { lcol[o] = c; lval[o] = v; ++o; }
+      ++n;
+    }
+  }
+  if (!diag_done && dval != T(0)) {
+    if (FILL) { lcol[o] = i; lval[o] = dval; ++o; }
+    ++n;
+  }
+  if (!FILL) cnt[i] = n;
+}
+
+__global__ void k_inverse_perm(const int* __restrict__ perm, int N, int* __restrict__ iperm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) iperm[perm[i]] = i;
+}
+
+// canonical L -> internal padded CSR.  pass 1: padded row lengths; pass 2: fill.
+template <typename T, bool FILL>
+__global__ void k_internal_build(const int* __restrict__ lptr, const int* __restrict__ lcol,
+                                 const T* __restrict__ lval, int N,
+                                 const int* __restrict__ perm, const int* __restrict__ iperm,
+                                 int* __restrict__ cnt, const int* __restrict__ rptr,
+                                 int* __restrict__ rcol, T* __restrict__ rval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // internal row
+  if (i >= N) return;
+  const int old = perm ? perm[i] : i;
+  const int s = lptr[old], e = lptr[old + 1];
+  bool has_diag = false;
+  for (int j = s; j < e; ++j)
+    if (lcol[j] == old) { has_diag = true; break; }
+  const int n = (e - s) + (has_diag ? 0 : 1);
+  const int npad = (n + 3) & ~3;
+  if (!FILL) {
+    cnt[i] = npad;
+    return;
+  }
+  const int o = rptr[i];
+  int m = 0;
+  for (int j = s; j < e; ++j) {
+    rcol[o + m] = iperm ? iperm[lcol[j]] : lcol[j];
+    rval[o + m] = lval[j];
+    ++m;
+  }
+  if (!has_diag) {
+    rcol[o + m] = i;
+    rval[o + m] = T(0);
+    ++m;
+  }
+  // keep short rows sorted by (internal) column: neighbouring gathers stay adjacent
+  if ((perm || !has_diag) && m <= 128) {
+    for (int p = 1; p < m; ++p) {
+      const int c = rcol[o + p];
+      const T v = rval[o + p];
+      int q = p - 1;
+      while (q >= 0 && rcol[o + q] > c) {
+        rcol[o + q + 1] = rcol[o + q];
+        rval[o + q + 1] = rval[o + q];
+        --q;
+      }
+      rcol[o + q + 1] = c;
+      rval[o + q + 1] = v;
+    }
+  }
+  for (; m < npad; ++m) {
+    rcol[o + m] = N;  // out-of-range sentinel: the gather's bounds check returns 0
+    rval[o + m] = T(0);
+  }
+}
+
+// F = (2/a1) * (L - a2 I) on the internal layout (approximations.py:105)
+template <typename T>
+__global__ void k_factor(const int* __restrict__ rptr, const int* __restrict__ rcol,
+                         const T* __restrict__ rval, int N, T two_over_a1, T a2,
+                         T* __restrict__ fval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int j = rptr[i]; j < rptr[i + 1]; ++j) {
+    const int c = rcol[j];
+    T v = rval[j];
+    if (c == i) v -= a2;
+    fval[j] = (c == N) ? T(0) : two_over_a1 * v;
+  }
+}
+
+template <typename T> __global__ void k_fill(T* p, size_t n, T v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of int32 (three small kernels; tile = 1024 elements)
+// ---------------------------------------------------------------------------------------------
+#define GSPX_SCAN_TILE 1024
+__global__ __launch_bounds__(256) void k_scan_tiles(const int* __restrict__ in, int n,
+                                                    int* __restrict__ out,
+                                                    int* __restrict__ tile_sums) {
+  __shared__ int wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int base = blockIdx.x * GSPX_SCAN_TILE + t * 4;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (base + k < n) ? in[base + k] : 0;
+  const int mine = v[0] + v[1] + v[2] + v[3];
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int k = 0; k < wv; ++k) wbase += wsum[k];
+  int run = wbase + incl - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (t == 255) tile_sums[blockIdx.x] = wbase + incl;
+}
+
+__global__ __launch_bounds__(256) void k_scan_sums(int* tile_sums, int ntiles) {
+  // single workgroup: serial over 256-element strips with a carry
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 256) {
+    const int i = base + t;
+    const int mine = i < ntiles ? tile_sums[i] : 0;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int wbase = carry_s;
+    for (int k = 0; k < wv; ++k) wbase += wsum[k];
+    if (i < ntiles) tile_sums[i] = wbase + incl - mine;
+    __syncthreads();
+    if (t == 255) carry_s = wbase + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(int* __restrict__ out, int n,
+                                                  const int* __restrict__ tile_sums) {
+  const int add = tile_sums[blockIdx.x];
+  const int base = blockIdx.x * GSPX_SCAN_TILE + threadIdx.x * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < n) out[base + k] += add;
+}
+
+}  // namespace gspx

@@ -1,0 +1,291 @@
+"""Thin object layer over the libgspx C-ABI: Context, DeviceBuffer, DeviceGraph.
+
+Nothing here computes: every numeric result comes out of the HIP kernels in
+pygsp_amd/csrc.  Vertex reordering (a graph-setup step, like building the Laplacian) is the
+only host-side preparation, see ``locality_order``.
+"""
+import ctypes
+import threading
+
+import numpy as np
+from scipy import sparse
+
+from . import _capi
+
+
+class Context:
+    """One device + one HIP stream (gspx_ctx).  Calls on one Context must be serialised."""
+
+    def __init__(self, device=0):
+        lib = _capi.load()
+        h = ctypes.c_void_p()
+        _capi.check(lib.gspx_ctx_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.load().gspx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _capi.check(_capi.load().gspx_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_int64(0)
+        _capi.check(_capi.load().gspx_ctx_get_option(self._h, key.encode(), ctypes.byref(v)))
+        return v.value
+
+    def sync(self):
+        _capi.check(_capi.load().gspx_ctx_sync(self._h))
+
+    def last_timing(self):
+        """dict of HIP-event timings (ms) of the last filter call on this context."""
+        out = (ctypes.c_double * 5)()
+        _capi.check(_capi.load().gspx_last_timing(self._h, out))
+        return {"total_ms": out[0], "steps_ms": out[1], "step_launches": int(out[2]),
+                "permute_ms": out[3], "combine_ms": out[4]}
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, arr.nbytes)
+        buf.upload(arr)
+        return buf
+
+
+_default_ctx = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device=0):
+    with _default_lock:
+        ctx = _default_ctx.get(device)
+        if ctx is None:
+            ctx = Context(device)
+            _default_ctx[device] = ctx
+        return ctx
+
+
+class DeviceBuffer:
+    """Device memory owned by libgspx (gspx_buf)."""
+
+    def __init__(self, ctx, nbytes):
+        h = ctypes.c_void_p()
+        _capi.check(_capi.load().gspx_buf_alloc(ctx._h, int(nbytes), ctypes.byref(h)))
+        self._h = h
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+
+    def free(self):
+        if getattr(self, "_h", None):
+            _capi.load().gspx_buf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def ptr(self):
+        p = ctypes.c_void_p()
+        _capi.check(_capi.load().gspx_buf_ptr(self._h, ctypes.byref(p)))
+        return p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        _capi.check(_capi.load().gspx_buf_upload(self._h, _capi.ptr(arr), arr.nbytes))
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        _capi.check(_capi.load().gspx_buf_download(self._h, _capi.ptr(out), out.nbytes))
+        return out
+
+
+def _canonical_csr(M):
+    M = sparse.csr_matrix(M)
+    if not M.has_canonical_format:
+        M = M.copy()
+        M.sum_duplicates()
+    if M.indices.dtype != np.int32 or M.indptr.dtype != np.int32:
+        if M.shape[0] >= 2 ** 31 - 1 or M.nnz >= 2 ** 31 - 1:
+            raise ValueError("graph too large for int32 CSR indices")
+        M = sparse.csr_matrix((M.data, M.indices.astype(np.int32), M.indptr.astype(np.int32)),
+                              shape=M.shape)
+    return M
+
+
+def locality_order(W, coords=None):
+    """Vertex order used INSIDE the engine (perm[new] = old) so that neighbour gathers hit cache.
+
+    * with coordinates (NN graphs such as Sensor): Morton (Z-order) code of the first two/three
+      coordinates - median |i-j| over stored entries drops from ~N/4 to a handful;
+    * otherwise reverse Cuthill-McKee on the pattern of W.
+    The order is invisible to callers: inputs/outputs stay in the graph's own vertex order.
+    """
+    N = W.shape[0]
+    if N < 2:
+        return None
+    if coords is not None and np.ndim(coords) == 2 and coords.shape[0] == N and coords.shape[1] >= 2:
+        c = np.asarray(coords, dtype=np.float64)[:, :3]
+        lo = c.min(axis=0)
+        span = c.max(axis=0) - lo
+        span[span == 0] = 1.0
+        d = c.shape[1]
+        bits = 21 if d == 3 else 31
+        q = np.minimum(((c - lo) / span * (2 ** bits - 1)).astype(np.uint64), 2 ** bits - 1)
+        code = np.zeros(N, dtype=np.uint64)
+        for b in range(bits):
+            for k in range(d):
+                code |= ((q[:, k] >> np.uint64(b)) & np.uint64(1)) << np.uint64(b * d + k)
+        return np.argsort(code, kind="stable").astype(np.int32)
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    pattern = sparse.csr_matrix((np.ones(W.nnz, dtype=np.int8), W.indices, W.indptr), shape=W.shape)
+    return np.asarray(reverse_cuthill_mckee(pattern, symmetric_mode=True), dtype=np.int32)
+
+
+class DeviceGraph:
+    """Device-resident Laplacian (gspx_graph): built on the GPU from W, or uploaded as L."""
+
+    def __init__(self, handle, ctx, N, dtype):
+        self._h = handle
+        self.ctx = ctx
+        self.N = int(N)
+        self.dtype = np.dtype(dtype)
+
+    @classmethod
+    def from_w(cls, W, lap_type="combinatorial", dtype=np.float64, perm=None, ctx=None):
+        """graph.py:510-630 on device.  W must be symmetric (undirected)."""
+        ctx = ctx or default_context()
+        if lap_type not in ("combinatorial", "normalized"):
+            raise ValueError("Unknown Laplacian type {}".format(lap_type))
+        W = _canonical_csr(W)
+        data = W.data
+        if data.dtype not in (np.float32, np.float64):
+            data = data.astype(np.float64)  # int64 adjacency (ER/SBM) -> float64, as scipy does
+        data = np.ascontiguousarray(data)
+        lap = _capi.LAP_COMBINATORIAL if lap_type == "combinatorial" else _capi.LAP_NORMALIZED
+        p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.load().gspx_graph_create_from_w(
+            ctx._h, W.shape[0], W.nnz, _capi.ptr(W.indptr), _capi.ptr(W.indices), _capi.ptr(data),
+            _capi.dtype_code(data.dtype), lap, _capi.dtype_code(dtype), _capi.ptr(p),
+            ctypes.byref(h)))
+        return cls(h, ctx, W.shape[0], dtype)
+
+    @classmethod
+    def from_l(cls, L, dtype=np.float64, perm=None, ctx=None):
+        ctx = ctx or default_context()
+        L = _canonical_csr(L)
+        data = L.data
+        if data.dtype not in (np.float32, np.float64):
+            data = data.astype(np.float64)
+        data = np.ascontiguousarray(data)
+        p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.load().gspx_graph_create_from_l(
+            ctx._h, L.shape[0], L.nnz, _capi.ptr(L.indptr), _capi.ptr(L.indices), _capi.ptr(data),
+            _capi.dtype_code(data.dtype), _capi.dtype_code(dtype), _capi.ptr(p), ctypes.byref(h)))
+        return cls(h, ctx, L.shape[0], dtype)
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            _capi.load().gspx_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def _i64(self, fn):
+        v = ctypes.c_int64(0)
+        _capi.check(fn(self._h, ctypes.byref(v)))
+        return v.value
+
+    @property
+    def nnz_l(self):
+        return self._i64(_capi.load().gspx_graph_nnz_l)
+
+    @property
+    def nnz_internal(self):
+        return self._i64(_capi.load().gspx_graph_nnz_internal)
+
+    @property
+    def build_ms(self):
+        v = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_graph_build_ms(self._h, ctypes.byref(v)))
+        return v.value
+
+    def download_l(self):
+        """Canonical Laplacian as scipy CSR in the graph's own vertex order."""
+        nnz = self.nnz_l
+        indptr = np.empty(self.N + 1, dtype=np.int32)
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz, dtype=self.dtype)
+        _capi.check(_capi.load().gspx_graph_download_l(self._h, _capi.ptr(indptr),
+                                                       _capi.ptr(indices), _capi.ptr(data)))
+        return sparse.csr_matrix((data, indices, indptr), shape=(self.N, self.N))
+
+    def download_dw(self):
+        dw = np.empty(self.N, dtype=self.dtype)
+        _capi.check(_capi.load().gspx_graph_download_dw(self._h, _capi.ptr(dw)))
+        return dw
+
+    # ---- the hot path -------------------------------------------------------------------------
+    def cheby_filter(self, coeffs, x, lmax, mode=_capi.ANALYSIS):
+        """Host arrays in / out.  coeffs: (Nf, M) float64.
+        analysis:  x (N, Nsig)      -> (Nf, N, Nsig)
+        synthesis: x (Nf, N, Nsig)  -> (N, Nsig)
+        Returns (y, kernel_ms)."""
+        c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))
+        Nf, M = c.shape
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        if mode == _capi.ANALYSIS:
+            if x.ndim != 2 or x.shape[0] != self.N:
+                raise ValueError("analysis input must be (N, Nsig), got {}".format(x.shape))
+            nsig = x.shape[1]
+            y = np.empty((Nf, self.N, nsig), dtype=self.dtype)
+        else:
+            if x.ndim != 3 or x.shape[0] != Nf or x.shape[1] != self.N:
+                raise ValueError("synthesis input must be (Nf, N, Nsig), got {}".format(x.shape))
+            nsig = x.shape[2]
+            y = np.empty((self.N, nsig), dtype=self.dtype)
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_cheby_filter(
+            self._h, float(lmax), Nf, M, _capi.ptr(c), nsig, _capi.ptr(x), _capi.ptr(y), mode,
+            ctypes.byref(ms)))
+        return y, ms.value
+
+    def cheby_filter_dev(self, coeffs, x_ptr, y_ptr, nsig, lmax, mode=_capi.ANALYSIS):
+        """Device pointers in / out (ints).  Returns device milliseconds of the whole call."""
+        c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))
+        Nf, M = c.shape
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_cheby_filter_dev(
+            self._h, float(lmax), Nf, M, _capi.ptr(c), int(nsig), ctypes.c_void_p(x_ptr),
+            ctypes.c_void_p(y_ptr), mode, ctypes.byref(ms)))
+        return ms.value
+
+
+def plan_describe(coeffs, ctx=None):
+    """The engine's step schedule for these coefficients (host-only; for schedule tests)."""
+    c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))
+    Nf, M = c.shape
+    if M < 2:
+        _capi.check(_capi.load().gspx_plan_describe(None, Nf, M, _capi.ptr(c), None))
+    plan = np.zeros((M - 1, 4 + 3 * Nf), dtype=np.float64)
+    _capi.check(_capi.load().gspx_plan_describe(ctx._h if ctx else None, Nf, M, _capi.ptr(c),
+                                                _capi.ptr(plan)))
+    return plan

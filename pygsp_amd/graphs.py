@@ -1,0 +1,338 @@
+"""pygsp.graphs.Graph surface for the Chebyshev-filtering hot path, backed by libgspx.
+
+Mirrors (same names, argument meaning and exceptions) the parts of
+``pygsp/graphs/graph.py`` the path touches:
+
+* ``Graph.__init__``              graph.py:98-176   (validation, n_vertices/N, n_edges/Ne)
+* ``Graph.compute_laplacian``     graph.py:510-630  -> built ON DEVICE (gspx_graph_create_from_w)
+* ``Graph.dw``                    graph.py:783-838  -> device column sums
+* ``Graph.lmax / estimate_lmax``  graph.py:840-960  (host, scipy: a read-only input of the path)
+* ``Graph._check_signal``         graph.py:632-640
+* ``Graph.is_directed``           graph.py:357-405
+
+Everything else of the reference's Graph (plotting, I/O, subgraphs, ...) is out of scope; use
+the real pygsp together with ``pygsp_amd.plugin.install()`` for those.
+
+The synthetic generators at the bottom (Sensor, ErdosRenyi, StochasticBlockModel) are vectorised
+samplers of the same distributions as the reference's constructors (the reference's ER/SBM
+constructors are O(N^2) Python loops, stochasticblockmodel.py:125-139, unusable at N >= 1e5).
+"""
+import logging
+
+import numpy as np
+from scipy import sparse, spatial
+from scipy.sparse import linalg as splinalg
+
+from . import engine
+
+_logger = logging.getLogger(__name__)
+
+
+class Graph:
+    def __init__(self, adjacency, lap_type="combinatorial", coords=None, plotting={}, *,
+                 compute_dtype=np.float64, device=0, reorder="auto"):
+        self.logger = _logger
+        if not sparse.issparse(adjacency):
+            adjacency = np.asanyarray(adjacency)
+        if adjacency.ndim != 2 or adjacency.shape[0] != adjacency.shape[1]:
+            raise ValueError("Adjacency: must be a square matrix.")
+        self._adjacency = sparse.csr_matrix(adjacency, copy=False)
+        total = self._adjacency.sum()
+        if np.isnan(total):
+            raise ValueError("Adjacency: there is a Not a Number (NaN).")
+        if np.isinf(total):
+            raise ValueError("Adjacency: there is an infinite value.")
+        if self._adjacency.diagonal().any():
+            self.logger.warning("Adjacency: there are self-loops (non-zeros on the diagonal). "
+                                "The Laplacian will not see them.")
+        if (self._adjacency < 0).nnz != 0:
+            self.logger.warning("Adjacency: there are negative edge weights.")
+        self.n_vertices = self._adjacency.shape[0]
+        self._adjacency.eliminate_zeros()
+
+        self._directed = None
+        if self.is_directed():
+            self.n_edges = self._adjacency.nnz
+        else:
+            diagonal = int(np.count_nonzero(self._adjacency.diagonal()))
+            self.n_edges = (self._adjacency.nnz - diagonal) // 2 + diagonal
+        if coords is not None:
+            self.coords = np.asanyarray(coords)
+        self.plotting = dict(plotting)
+        self.signals = dict()
+
+        self.compute_dtype = np.dtype(compute_dtype)
+        self.device = int(device)
+        self.reorder = reorder
+        self._perm = None
+        self._perm_done = False
+
+        self._dw = None
+        self._lmax = None
+        self._lmax_method = None
+        self._U = None
+        self._e = None
+        self._L = None
+        self._dev = {}
+
+        self.lap_type = lap_type
+        self.compute_laplacian(lap_type)
+        self.Ne = self.n_edges
+        self.N = self.n_vertices
+
+    # ---- adjacency -----------------------------------------------------------------------------
+    @property
+    def W(self):
+        return self._adjacency
+
+    def is_directed(self):
+        if self._directed is None:
+            self._directed = (self.W != self.W.T).nnz != 0
+        return self._directed
+
+    def _symmetric_w(self):
+        """W itself if undirected, else (W + W.T)/2 (utils.symmetrize 'average', graph.py:613-616)."""
+        if not self.is_directed():
+            return self.W
+        return sparse.csr_matrix((self.W + self.W.T) / 2)
+
+    # ---- Laplacian (device) --------------------------------------------------------------------
+    def _internal_order(self):
+        if not self._perm_done:
+            self._perm_done = True
+            mode = self.reorder
+            if mode in (None, False, "none"):
+                self._perm = None
+            elif mode == "auto":
+                big = self.n_vertices >= 4096
+                self._perm = engine.locality_order(self.W, getattr(self, "coords", None)) \
+                    if big and getattr(self, "coords", None) is not None else None
+            elif mode == "morton":
+                self._perm = engine.locality_order(self.W, getattr(self, "coords", None))
+            elif mode == "rcm":
+                self._perm = engine.locality_order(self.W, None)
+            else:
+                self._perm = np.asarray(mode, dtype=np.int32)
+        return self._perm
+
+    def device_graph(self, dtype=None):
+        """The device-resident Laplacian in `dtype` (built on first use, cached)."""
+        dt = np.dtype(dtype or self.compute_dtype)
+        g = self._dev.get(dt)
+        if g is None:
+            ctx = engine.default_context(self.device)
+            g = engine.DeviceGraph.from_w(self._symmetric_w(), self.lap_type, dtype=dt,
+                                          perm=self._internal_order(), ctx=ctx)
+            self._dev[dt] = g
+        return g
+
+    def compute_laplacian(self, lap_type="combinatorial"):
+        """graph.py:510-630.  The Laplacian is assembled by HIP kernels from W; ``G.L`` is the
+        scipy CSR copy downloaded from the device on first access."""
+        if lap_type not in ("combinatorial", "normalized"):
+            raise ValueError("Unknown Laplacian type {}".format(lap_type))
+        if lap_type != self.lap_type:
+            # caches invalidated when the Laplacian changes (graph.py:602-609)
+            self._lmax = None
+            self._lmax_method = None
+            self._U = None
+            self._e = None
+        self.lap_type = lap_type
+        self._L = None
+        for g in self._dev.values():
+            g.destroy()
+        self._dev = {}
+        self.device_graph()  # build now: errors surface here, like in the reference
+
+    @property
+    def L(self):
+        if self._L is None:
+            # the reference's L is float64 for normalized and for integer W, and follows W's
+            # dtype for combinatorial; the device copy is in the compute dtype
+            self._L = self.device_graph().download_l()
+        return self._L
+
+    @property
+    def dw(self):
+        if self._dw is None:
+            self._dw = self.device_graph().download_dw()
+        return self._dw
+
+    def _check_signal(self, s):
+        s = np.asanyarray(s)
+        if s.shape[0] != self.n_vertices:
+            raise ValueError("First dimension must be the number of vertices "
+                             "G.N = {}, got {}.".format(self.N, s.shape))
+        return s
+
+    # ---- spectrum bounds (host; read-only input of the hot path) -------------------------------
+    @property
+    def lmax(self):
+        if self._lmax is None:
+            self.logger.warning("The largest eigenvalue G.lmax is not available, we need to "
+                                "estimate it. Explicitly call G.estimate_lmax() or "
+                                "G.compute_fourier_basis() once beforehand to suppress the warning.")
+            self.estimate_lmax()
+        return self._lmax
+
+    def estimate_lmax(self, method="lanczos"):
+        if method == self._lmax_method:
+            return
+        self._lmax_method = method
+        if method == "lanczos":
+            try:
+                lmax = splinalg.eigsh(self.L.astype(np.float64), k=1, tol=5e-3,
+                                      ncv=min(self.N, 10), return_eigenvectors=False)[0]
+            except splinalg.ArpackNoConvergence:
+                raise ValueError("The Lanczos method did not converge. Try to use bounds.")
+            assert lmax <= self._get_upper_bound() + 1e-12
+            self._lmax = lmax * 1.01  # 1 % safety margin, as the reference
+        elif method == "bounds":
+            self._lmax = self._get_upper_bound()
+        else:
+            raise ValueError("Unknown method {}".format(method))
+
+    def _get_upper_bound(self):
+        if self.lap_type == "normalized":
+            return 2
+        W = self._symmetric_w()
+        dw = np.asarray(self.dw, dtype=np.float64)
+        bounds = [self.n_vertices * W.max(), 2 * dw.max()]
+        if self.n_edges > 0:
+            coo = self.W.tocoo()  # max over edges: both triangles give the same maximum
+            bounds.append(np.max(dw[coo.row] + dw[coo.col]))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            m = W.dot(dw) / dw
+        bounds.append(np.max(dw + m))
+        return min(bounds)
+
+    def compute_fourier_basis(self):
+        """Dense eigendecomposition (fourier.py:97-195) - host LAPACK, for small graphs / tests."""
+        if self._U is not None:
+            return
+        e, U = np.linalg.eigh(self.L.toarray().astype(np.float64))
+        e[0] = 0 if abs(e[0]) < 1e-9 else e[0]
+        self._e, self._U = e, U
+        self._lmax = e[-1]
+        self._lmax_method = "fourier"
+
+    @property
+    def e(self):
+        if self._e is None:
+            self.compute_fourier_basis()
+        return self._e
+
+    @property
+    def U(self):
+        if self._U is None:
+            self.compute_fourier_basis()
+        return self._U
+
+    def __repr__(self):
+        return "{}(n_vertices={}, n_edges={}, lap_type={})".format(
+            self.__class__.__name__, self.n_vertices, self.n_edges, self.lap_type)
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic graph generators (vectorised restatements of the reference's models)
+# ------------------------------------------------------------------------------------------------
+def sensor_weights(N, k=6, seed=None, return_coords=True):
+    """W of ``graphs.Sensor(N, k, seed=seed)`` (nngraphs/sensor.py:50-75, nngraph.py:213-297):
+    uniform coordinates in the unit square, k nearest neighbours, weights exp(-d^2/sigma) with
+    sigma = mean neighbour distance, symmetrised by averaging."""
+    rng = np.random.default_rng(seed)
+    coords = rng.uniform(0, 1, (N, 2))
+    tree = spatial.cKDTree(coords)
+    D, NN = tree.query(coords, k=k + 1, workers=-1)
+    sigma = np.mean(D[:, 1:])
+    rows = np.repeat(np.arange(N), k)
+    cols = NN[:, 1:].ravel()
+    vals = np.exp(-np.power(D[:, 1:].ravel(), 2) / float(sigma))
+    W = sparse.csc_matrix((vals, (rows, cols)), shape=(N, N))
+    W = sparse.csr_matrix((W + W.T) / 2)
+    return (W, coords) if return_coords else W
+
+
+class Sensor(Graph):
+    def __init__(self, N=64, k=6, seed=None, **kwargs):
+        self.k = k
+        self.seed = seed
+        W, coords = sensor_weights(N, k, seed)
+        super().__init__(W, coords=coords, **kwargs)
+
+
+def _sample_pairs_within(rng, n, p):
+    """m ~ Binomial(n(n-1)/2, p) distinct unordered pairs (r > c) among n vertices."""
+    total = n * (n - 1) // 2
+    m = rng.binomial(total, p) if total > 0 else 0
+    if m == 0:
+        return np.empty(0, np.int64), np.empty(0, np.int64)
+    got = np.empty(0, dtype=np.int64)
+    while got.size < m:
+        cand = rng.integers(0, total, size=int((m - got.size) * 1.1) + 16)
+        got = np.unique(np.concatenate([got, cand]))
+    got = rng.permutation(got)[:m]
+    # linear index -> (r, c) with r > c :  idx = r(r-1)/2 + c
+    r = np.floor((1 + np.sqrt(1 + 8 * got.astype(np.float64))) / 2).astype(np.int64)
+    r = np.where(r * (r - 1) // 2 > got, r - 1, r)
+    r = np.where((r + 1) * r // 2 <= got, r + 1, r)
+    c = got - r * (r - 1) // 2
+    return r, c
+
+
+def _sample_pairs_between(rng, na, nb, p):
+    total = na * nb
+    m = rng.binomial(total, p) if total > 0 else 0
+    if m == 0:
+        return np.empty(0, np.int64), np.empty(0, np.int64)
+    got = np.empty(0, dtype=np.int64)
+    while got.size < m:
+        cand = rng.integers(0, total, size=int((m - got.size) * 1.1) + 16)
+        got = np.unique(np.concatenate([got, cand]))
+    got = rng.permutation(got)[:m]
+    return got // nb, got % nb
+
+
+def sbm_weights(N, k=5, z=None, p=0.7, q=None, seed=None):
+    """W with the distribution of ``graphs.StochasticBlockModel(N, k, z, p=p, q=q,
+    directed=False, self_loops=False)`` (stochasticblockmodel.py:61-144): every unordered pair
+    is an edge independently with probability p (same block) or q (different blocks); unit
+    weights (int64, as the reference).  O(nnz) instead of the reference's O(N^2) loop."""
+    rng = np.random.default_rng(seed)
+    if z is None:
+        z = np.sort(rng.integers(0, k, N))
+    z = np.asarray(z)
+    if q is None:
+        q = 0.3 / k
+    order = np.argsort(z, kind="stable")
+    bounds = np.searchsorted(z[order], np.arange(k + 1))
+    rows, cols = [], []
+    for a in range(k):
+        ia = order[bounds[a]:bounds[a + 1]]
+        r, c = _sample_pairs_within(rng, ia.size, p)
+        rows.append(ia[r]); cols.append(ia[c])
+        for b in range(a):
+            ib = order[bounds[b]:bounds[b + 1]]
+            r, c = _sample_pairs_between(rng, ia.size, ib.size, q)
+            rows.append(ia[r]); cols.append(ib[c])
+    rows = np.concatenate(rows) if rows else np.empty(0, np.int64)
+    cols = np.concatenate(cols) if cols else np.empty(0, np.int64)
+    data = np.ones(rows.size * 2, dtype=np.int64)
+    W = sparse.csr_matrix((data, (np.concatenate([rows, cols]), np.concatenate([cols, rows]))),
+                          shape=(N, N))
+    return W, z
+
+
+class StochasticBlockModel(Graph):
+    def __init__(self, N=1024, k=5, z=None, p=0.7, q=None, seed=None, **kwargs):
+        W, z = sbm_weights(N, k, z, p, q, seed)
+        self.z = z
+        super().__init__(W, **kwargs)
+
+
+class ErdosRenyi(Graph):
+    """erdosrenyi.py:49-61: the one-block stochastic block model."""
+
+    def __init__(self, N=100, p=0.1, seed=None, **kwargs):
+        W, _ = sbm_weights(N, 1, np.zeros(N, dtype=np.int64), p, 0, seed)
+        super().__init__(W, **kwargs)

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (pygsp v0.6.1 from /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/gen_golden.py
+The fixtures are committed; tests read them, never /root/reference.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, "/root/reference")
+os.environ.setdefault("MPLBACKEND", "agg")
+import pygsp  # noqa: E402
+from pygsp import filters, graphs  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def csr_parts(M, prefix):
+    M = M.tocsr()
+    M.sort_indices()
+    return {prefix + "_indptr": M.indptr.astype(np.int32), prefix + "_indices": M.indices.astype(np.int32),
+            prefix + "_data": M.data, prefix + "_shape": np.array(M.shape)}
+
+
+def logo():
+    """BASELINE.json configs[0]: graphs.Logo() + Heat(scale=50), 3 deltas, order 30."""
+    G = graphs.Logo()
+    out = csr_parts(G.W, "W")
+    out.update(csr_parts(G.L, "L"))
+    s = np.zeros(G.N)
+    s[[20, 30, 1090]] = 1
+    out["signal"] = s
+    out["dw"] = G.dw
+    for tag, setter in (("bounds", lambda: G.estimate_lmax("bounds")),
+                        ("fourier", lambda: G.compute_fourier_basis())):
+        setter()
+        g = filters.Heat(G, scale=50)
+        out["lmax_" + tag] = np.float64(G.lmax)
+        out["coeff_" + tag] = filters.compute_cheby_coeff(g, m=30)
+        out["y_" + tag] = g.filter(s, method="chebyshev", order=30)
+    np.savez_compressed(os.path.join(OUT, "logo_heat50.npz"), **out)
+
+
+def sensor123():
+    """The fixture of pygsp/tests/test_filters.py:12-29: Sensor(123, seed=42), exact lmax,
+    uniform signal from default_rng(42)."""
+    G = graphs.Sensor(123, seed=42)
+    G.compute_fourier_basis()
+    rng = np.random.default_rng(42)
+    sig = rng.uniform(size=G.N)
+    out = csr_parts(G.W, "W")
+    out.update(csr_parts(G.L, "Lcomb"))
+    out["coords"] = G.coords
+    out["lmax"] = np.float64(G.lmax)
+    out["dw"] = G.dw
+    out["signal"] = sig
+    sigs = rng.standard_normal((G.N, 5))
+    out["signals5"] = sigs
+    # single filter
+    g = filters.Heat(G, scale=10)
+    out["heat10_c"] = filters.compute_cheby_coeff(g, m=30)
+    out["heat10_y"] = g.filter(sig, method="chebyshev", order=30)
+    out["heat10_y5"] = g.filter(sigs, method="chebyshev", order=30)
+    out["heat10_exact"] = g.filter(sig, method="exact")
+    # two scales (test_frame, test_filters.py:157-168)
+    g2 = filters.Heat(G, scale=[8, 9])
+    out["heat89_frame"] = g2.compute_frame(method="chebyshev", order=30)
+    # filterbank: analysis + synthesis
+    mh = filters.MexicanHat(G, Nf=6)
+    out["mh6_c"] = np.array(filters.compute_cheby_coeff(mh, m=40))
+    a = mh.filter(sigs, method="chebyshev", order=40)          # (N, 5, 6)
+    out["mh6_analysis"] = a
+    out["mh6_synthesis"] = mh.filter(a, method="chebyshev", order=40)  # (N, 5)
+    out["mh6_analysis1"] = mh.filter(sig, method="chebyshev", order=40)  # (N, 6)
+    out["mh6_synthesis1"] = mh.filter(out["mh6_analysis1"], method="chebyshev", order=40)
+    # low orders (order=1, 2 work; order=0 raises TypeError)
+    out["heat10_order1"] = g.filter(sig, method="chebyshev", order=1)
+    out["heat10_order2"] = g.filter(sig, method="chebyshev", order=2)
+    # normalized Laplacian
+    G.compute_laplacian("normalized")
+    out.update(csr_parts(G.L, "Lnorm"))
+    G.estimate_lmax("bounds")
+    out["lmax_norm"] = np.float64(G.lmax)
+    gn = filters.Heat(G, scale=10)
+    out["heat10_norm_y"] = gn.filter(sig, method="chebyshev", order=30)
+    np.savez_compressed(os.path.join(OUT, "sensor123.npz"), **out)
+
+
+def doctest_sensor30():
+    """filter.py:232-256: Sensor(30, seed=42), MexicanHat Nf=4, ||s1 - s2|| = 0.27649."""
+    G = graphs.Sensor(30, seed=42)
+    G.compute_fourier_basis()
+    out = csr_parts(G.W, "W")
+    out["coords"] = G.coords
+    out["lmax"] = np.float64(G.lmax)
+    s1 = np.zeros(G.N)
+    s1[13] = 1
+    s1 = filters.Heat(G, 3).filter(s1)
+    g = filters.MexicanHat(G, Nf=4)
+    s2 = g.analyze(s1)
+    s3 = g.synthesize(s2)
+    out["s1"], out["s2"], out["s3"] = s1, s2, s3
+    out["norm"] = np.float64(np.linalg.norm(s1 - s3))
+    np.savez_compressed(os.path.join(OUT, "doctest_sensor30.npz"), **out)
+
+
+def laplacians4():
+    """pygsp/tests/test_graphs.py:195-254: hand-written 4x4 adjacency, directed and undirected,
+    combinatorial and normalized; plus a graph with an isolated vertex and one with self-loops."""
+    out = {}
+    W_und = np.array([[0, 2, 0, 0], [2, 0, 4, 0], [0, 4, 0, 5], [0, 0, 5, 0]], dtype=float)
+    W_dir = np.array([[0, 2, 0, 0], [0, 0, 4, 0], [0, 4, 0, 5], [0, 0, 0, 0]], dtype=float)
+    W_iso = np.array([[0, 1, 0, 0], [1, 0, 3, 0], [0, 3, 0, 0], [0, 0, 0, 0]], dtype=float)
+    W_loop = np.array([[1, 2, 0, 0], [2, 0, 4, 0], [0, 4, 3, 5], [0, 0, 5, 0]], dtype=float)
+    for name, W in (("und", W_und), ("dir", W_dir), ("iso", W_iso), ("loop", W_loop)):
+        out["W_" + name] = W
+        for lt in ("combinatorial", "normalized"):
+            G = graphs.Graph(W, lap_type=lt)
+            out["L_{}_{}".format(name, lt)] = G.L.toarray()
+            out["dw_" + name] = G.dw
+    np.savez_compressed(os.path.join(OUT, "laplacians4.npz"), **out)
+
+
+if __name__ == "__main__":
+    print("pygsp", pygsp.__version__)
+    logo()
+    sensor123()
+    doctest_sensor30()
+    laplacians4()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
