@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py - Chebyshev graph filtering throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+            --master-port P bench.py --gpus N --steps K --warmup W)
+
+A "step" is one pass of the hot path over one batch of synthetic input: an order-30 Heat filter
+of 64 signals on a 1M-vertex k=8 sensor graph (~10M stored entries of W) - the north-star
+headline configuration (SURVEY.md 8d "NS").  Graph, coefficients, input and output stay resident
+in HBM; the timed region is bracketed by barrier + device sync on both sides and the MAX over
+ranks is reported.  Each rank owns an independent graph of the same size (weak scaling, no
+data-path collective); the RCCL gather of the outputs to rank 0 is timed separately after the
+timed region ("gather_ms").
+
+value = n_gpus * N * Nsig * order * steps / time    [vertex.signal.order / s]
+
+roofline: ALGORITHMIC bytes per recurrence-step launch (SURVEY.md 8d:
+B_alg = K*(CSR + 3U) + Nf*U, per launch B_alg/K) divided by the average launch duration measured
+with HIP events on the engine's own stream over the timed steps.
+
+cpu_baseline: the oracle (numpy/scipy restatement = the reference's algorithm, scipy's
+csr_matvecs kernel, single-threaded) on a bounded column sample of the same workload, rank 0 at
+N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0       # measured float4-copy ceiling on this chip (same guide)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                   help="arithmetic type (the reference computes in f64)")
+    p.add_argument("--n", type=int, default=1000000)
+    p.add_argument("--knn", type=int, default=8)
+    p.add_argument("--nsig", type=int, default=64)
+    p.add_argument("--order", type=int, default=30)
+    p.add_argument("--scale", type=float, default=50.0)
+    p.add_argument("--cpu-cols", type=int, default=8, help="columns of the CPU-baseline sample")
+    p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-gather", action="store_true")
+    p.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    p.add_argument("--reorder", default="auto")
+    return p.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(a.gpus, world))
+
+    from pygsp_amd import _capi, engine, graphs
+    from pygsp_amd import dist as gdist
+
+    torch = None
+    tdev = None
+    if world > 1:
+        import torch  # plumbing only: rendezvous, barrier, MAX-reduce, RCCL gather
+        gdist.init_process_group("nccl")
+        tdev = torch.device("cuda", local)
+
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    elt = np.dtype(dtype).itemsize
+    N, nsig, K = a.n, a.nsig, a.order
+
+    # ---- synthetic workload: one independent sensor graph per rank -----------------------------
+    t0 = time.perf_counter()
+    W, coords = graphs.sensor_weights(N, k=a.knn, seed=42 + rank)
+    t_gen = time.perf_counter() - t0
+    ctx = engine.default_context(local)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    t0 = time.perf_counter()
+    G = graphs.Graph(W, coords=coords, compute_dtype=dtype, device=local, reorder=a.reorder)
+    t_graph = time.perf_counter() - t0
+    dev = G.device_graph()
+    G.estimate_lmax("bounds")
+    lmax = float(G.lmax)
+    # Heat(scale) coefficients, compute_cheby_coeff (approximations.py:9-55)
+    from pygsp_amd import filters
+    c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, a.scale), m=K))
+    rng = np.random.default_rng(1234 + rank)
+    x = rng.standard_normal((N, nsig)).astype(dtype)  # random data: zeros would clock higher
+    bx = ctx.upload(x)
+    if torch is not None:
+        ty = torch.empty((1, N, nsig), dtype=torch.float64 if a.dtype == "f64" else torch.float32,
+                         device=tdev)
+        y_ptr = ty.data_ptr()
+        by = None
+    else:
+        by = ctx.alloc(x.nbytes)
+        y_ptr = by.ptr
+
+    def step():
+        return dev.cheby_filter_dev(c, bx.ptr, y_ptr, nsig, lmax)
+
+    def fence():
+        ctx.sync()
+        if torch is not None:
+            torch.cuda.synchronize(tdev)
+            gdist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    dev_ms, steps_ms, launches = 0.0, 0.0, 0
+    for _ in range(a.steps):
+        dev_ms += step()
+        t = ctx.last_timing()
+        steps_ms += t["steps_ms"]
+        launches += t["step_launches"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if torch is not None:
+        elapsed = gdist.max_over_ranks(elapsed, tdev)
+        steps_ms_max = gdist.max_over_ranks(steps_ms, tdev)
+    else:
+        steps_ms_max = steps_ms
+
+    # ---- the path's one collective, outside the timed region: outputs -> rank 0 ----------------
+    gather_ms = None
+    if torch is not None and not a.no_gather:
+        fence()
+        tg = time.perf_counter()
+        blocks = gdist.gather_to_root(ty, dst=0)
+        torch.cuda.synchronize(tdev)
+        gather_ms = gdist.max_over_ranks((time.perf_counter() - tg) * 1e3, tdev)
+        if rank == 0:
+            assert len(blocks) == world
+        del blocks
+
+    # ---- roofline of the dominant kernel (the recurrence step) ---------------------------------
+    nnz_l = dev.nnz_l
+    U = N * nsig * elt
+    csr = nnz_l * (elt + 4) + 4 * (N + 1)
+    b_alg_call = K * (csr + 3 * U) + 1 * U
+    b_alg_launch = b_alg_call / K
+    avg_launch_ms = steps_ms / max(launches, 1)
+    achieved = b_alg_launch / (avg_launch_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_{}.json".format(a.dtype))
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        units = world * N * nsig * K * a.steps
+        out = {
+            "metric": "filtered-vertices/sec (N*Nsig*K/s)",
+            "value": units / elapsed,
+            "unit": "vertex*signal*order/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": a.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "Sensor(N={}, k={}) combinatorial Laplacian, Heat(scale={:g}) order {}, "
+                            "{} signals, device-resident (north-star headline)".format(
+                                N, a.knn, a.scale, K, nsig),
+                "N": N, "Nsig": nsig, "order": K, "Nf": 1, "nnz_W": int(W.nnz), "nnz_L": int(nnz_l),
+                "n_edges": int(G.n_edges), "lmax": lmax, "lmax_method": "bounds",
+                "parallelism": "graph-parallel x{} (independent graphs, no data-path collective)".format(world),
+                "internal_order": "morton" if G._perm is not None else "none",
+                "engine_options": a.opt,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
+                "traffic": traffic,
+                "kernel": "k_step_panel (one recurrence order per launch)",
+                "algorithmic_bytes_per_launch": b_alg_launch,
+                "avg_launch_ms": avg_launch_ms, "launches_timed": launches,
+            },
+            "device_ms_per_step": dev_ms / a.steps,
+            "device_ms_recurrence_per_step": steps_ms_max / a.steps,
+            "gather_ms": gather_ms,
+            "setup_s": {"graph_generation_host": t_gen, "graph_object_incl_device_laplacian": t_graph,
+                        "device_laplacian_build_ms": dev.build_ms},
+        }
+
+    # ---- CPU baseline beside it (rank 0, N=1 only): the oracle on a bounded column sample --------
+    if rank == 0 and world == 1 and not a.no_cpu:
+        from oracle import cheby_oracle as orc
+        cols = min(a.cpu_cols, nsig)
+        L = G.L.astype(np.float64)
+        xs = x[:, :cols].astype(np.float64)
+        orc.cheby_op(L, lmax, c[0], xs[:, :1])  # warm-up
+        tc = time.perf_counter()
+        ref = orc.cheby_op(L, lmax, c[0], xs)
+        t_cpu = time.perf_counter() - tc
+        y = (by.download((1, N, nsig), dtype))[0]
+        err = float(np.max(np.abs(y[:, :cols] - ref)) / np.max(np.abs(ref)))
+        out["cpu_baseline"] = {
+            "value": N * cols * K / t_cpu, "unit": "vertex*signal*order/s", "cores": 1,
+            "kind": "port",
+            "sample": "same graph/coefficients, first {} of {} signal columns, order {}, float64, "
+                      "scipy csr_matvecs single-threaded ({} host cores present), {:.1f} s".format(
+                          cols, nsig, K, os.cpu_count(), t_cpu),
+        }
+        out["parity_vs_oracle"] = {"max_rel_err": err, "columns": cols,
+                                   "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
+    if rank == 0:
+        print(json.dumps(out))
+    if torch is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

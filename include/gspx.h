@@ -138,6 +138,10 @@ int gspx_last_timing(gspx_ctx* ctx, double out[5]);
  * `plan` must hold (M-1)*(4+3*Nf) doubles.  a1 = a2 = lmax/2 as approximations.py:93-96. */
 int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, double* plan);
 
+/* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two
+ * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */
+int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1104,3 +1104,31 @@ extern "C" int gspx_last_timing(gspx_ctx* ctx, double out[5]) {
   for (int i = 0; i < 5; ++i) out[i] = ctx->timing[i];
   return GSPX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// calibration: streaming copy with the engine's own 16-byte-per-lane copy kernel (k_permute_in
+// without a permutation) - the measured HBM ceiling quoted beside every roofline fraction.
+// ------------------------------------------------------------------------------------------------
+extern "C" int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps) {
+  if (!ctx || !gbps || bytes < 4096 || iters < 1)
+    return set_err(GSPX_ERR_INVALID, "gspx_bench_copy: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevMem a, b;
+  CHK(a.alloc((size_t)bytes));
+  CHK(b.alloc((size_t)bytes));
+  const unsigned ld = 1024;  // floats per row
+  const int rows = (int)(bytes / (ld * sizeof(float)));
+  hipLaunchKernelGGL((k_fill<float>), dim3(4096), dim3(256), 0, ctx->stream, a.as<float>(),
+                     (size_t)rows * ld, 1.0f);
+  launch_permute_in<float>(a.as<float>(), ld, b.as<float>(), ld, rows, nullptr, 4, ctx->stream);
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+  for (int i = 0; i < iters; ++i)
+    launch_permute_in<float>(a.as<float>(), ld, b.as<float>(), ld, rows, nullptr, 4, ctx->stream);
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+  *gbps = 2.0 * (double)rows * ld * sizeof(float) * iters / (ms * 1e-3) / 1e9;
+  return GSPX_OK;
+}

@@ -1,0 +1,93 @@
+"""Multi-GPU batch driver: one process per GPU, independent graphs / signal panels per rank.
+
+The Chebyshev recurrence needs no exchange between graphs (or between signal columns of one
+graph), so the units of a batch are sharded across ranks with NO data-path collective; the only
+collective is the final gather of the outputs to the root (RCCL over xGMI when the backend is
+"nccl", gloo on CPU for the tests).  torch.distributed is plumbing here (rendezvous, barrier,
+gather); all filtering goes through libgspx.
+"""
+import os
+
+
+def env_world():
+    """(rank, world_size, local_rank) from the torchrun environment (defaults: single process)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the environment.  Returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_units(n_units, rank, world):
+    """Contiguous slice of `n_units` independent units (graphs or signal columns) for `rank`:
+    sizes differ by at most one, every unit is owned by exactly one rank."""
+    base, extra = divmod(n_units, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """MAX-reduce a python float over all ranks (identity for a single process)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_to_root(tensor, dst=0):
+    """The path's one collective: every rank's output block to `dst`.  Returns the list of blocks
+    on the root (rank order), None elsewhere.  All blocks must have the same shape/dtype."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [tensor]
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if dist.get_backend() == "nccl":
+        # RCCL gather as grouped send/recv: each peer's block lands on its own xGMI link
+        if rank == dst:
+            out = [torch.empty_like(tensor) for _ in range(world)]
+            out[dst].copy_(tensor)
+            ops = [dist.P2POp(dist.irecv, out[r], r) for r in range(world) if r != dst]
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            return out
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, tensor, dst)]):
+            req.wait()
+        return None
+    out = [torch.empty_like(tensor) for _ in range(world)] if rank == dst else None
+    dist.gather(tensor, out, dst=dst)
+    return out

@@ -55,6 +55,12 @@ class Context:
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
+    def bench_copy(self, nbytes=1 << 30, iters=10):
+        """Measured read+write GB/s of the engine's streaming copy kernel (HBM ceiling)."""
+        v = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_bench_copy(self._h, int(nbytes), int(iters), ctypes.byref(v)))
+        return v.value
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         buf = DeviceBuffer(self, arr.nbytes)

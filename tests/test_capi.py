@@ -1,0 +1,94 @@
+"""C-ABI checks that need no GPU: the library loads, exports exactly what include/gspx.h
+declares, fails loudly without a device, and its step schedule is correct (executed on the CPU
+by the oracle's plan runner)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, csr_from, rel_err
+from oracle import cheby_oracle as orc
+from pygsp_amd import _capi, engine
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gspx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gspx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libgspx.so does not export " + n
+    # the ctypes table and the header agree
+    assert sorted(_capi.SIGNATURES) == names
+
+
+def test_version_and_error_string():
+    lib = _capi.load()
+    assert b"gfx950" in lib.gspx_version()
+    assert isinstance(_capi.last_error(), str)
+
+
+@pytest.mark.skipif(_capi.device_count() > 0, reason="checks the no-device behaviour")
+def test_fails_loudly_without_device():
+    """No CPU fallback: without a HIP device the product path raises."""
+    with pytest.raises(_capi.GspxError):
+        engine.Context(0)
+
+
+def test_argument_errors_need_no_device():
+    lib = _capi.load()
+    c = np.array([[1.0]])
+    # M < 2 -> TypeError, as approximations.py:83-84
+    with pytest.raises(TypeError):
+        _capi.check(lib.gspx_plan_describe(None, 1, 1, _capi.ptr(c), None))
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_plan_describe(None, 0, 3, _capi.ptr(c), None))
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_cheby_filter_dev(None, 1.0, 1, 3, None, 1, None, None, 0, None))
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_ctx_set_option(None, b"kernel", 1))
+    n = ctypes.c_int64()
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_graph_n(None, ctypes.byref(n)))
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7, 30, 31, 32, 50])
+def test_fused_schedule_reproduces_cheby_op(golden_sensor123, order):
+    """The every-third-step flush schedule == the reference's per-step accumulation."""
+    g = golden_sensor123
+    L = csr_from(g, "Lcomb")
+    lmax = float(g["lmax"])
+    c = orc.compute_cheby_coeff(orc.heat_kernel(10, lmax), lmax, order)
+    plan = engine.plan_describe(c)
+    assert plan.shape == (order, 7)
+    # step 1 is T1 = 0.5 F T0, later steps T_k = F T_{k-1} - T_{k-2}
+    assert plan[0, 0] == 0.5 and plan[0, 1] == 0.0
+    assert np.all(plan[1:, 0] == 1.0) and np.all(plan[1:, 1] == -1.0)
+    # exactly one final flush, on the last step; first flush writes, later ones accumulate
+    assert plan[-1, 3] == 1 and plan[:-1, 3].sum() == 0
+    fl = plan[:, 2][plan[:, 2] > 0]
+    assert fl[0] == 1 and np.all(fl[1:] == 2)
+    # at most ceil((K+1)/3) + 1 flushes: ~2/3 of an accumulator pass per step
+    assert len(fl) <= (order + 1 + 2) // 3 + 1
+    # every coefficient is used exactly once (c0 halved)
+    used = plan[:, 4:].sum()
+    assert abs(used - (c.sum() - 0.5 * c[0])) < 1e-12
+    x = g["signals5"]
+    y = orc.run_plan(L, lmax, plan, 1, x)[0]
+    ref = orc.cheby_op(L, lmax, c, x)
+    assert rel_err(y, ref) < 1e-13
+
+
+def test_filterbank_schedule_is_deferred(golden_sensor123):
+    lmax = float(golden_sensor123["lmax"])
+    c = np.array([orc.compute_cheby_coeff(k, lmax, 20) for k in orc.mexican_hat_kernels(lmax, 4)])
+    plan = engine.plan_describe(c)
+    assert plan.shape == (20, 4 + 12)
+    assert np.all(plan[:, 2] == 0)  # no in-step flush: all T_k kept, one combine pass at the end

@@ -1,0 +1,534 @@
+"""Parity of the HIP path (through the C-ABI) against the reference's golden vectors and the
+oracle.  All tests need a real MI355X: run with `-m gpu`.
+
+Tolerances (BASELINE.json north_star): 1e-5 relative in float64, 1e-3 in float32, measured as
+max|y - ref| / max|ref|.  The engine is expected to sit orders of magnitude inside both; the
+tighter bounds asserted below flag indexing / scaling bugs early.
+"""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import csr_from, rel_err
+from oracle import cheby_oracle as orc
+from pygsp_amd import _capi, engine, filters, graphs
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.dtype(np.float64): 1e-11, np.dtype(np.float32): 2e-5}
+BAR = {np.dtype(np.float64): 1e-5, np.dtype(np.float32): 1e-3}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.default_context(0)
+    yield c
+    for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 8), ("xcd_remap", 1),
+                     ("combine", 0), ("max_batch", 0), ("narrow_g_log2", 2)):
+        c.set_option(key, val)
+
+
+def random_graph(n, avg_deg, seed, hub=False, isolated=0):
+    """Random symmetric weighted graph with ragged rows; optional hub row and isolated vertices."""
+    rng = np.random.default_rng(seed)
+    m = int(n * avg_deg / 2)
+    r = rng.integers(0, n, m)
+    c = rng.integers(0, n, m)
+    keep = r != c
+    r, c = r[keep], c[keep]
+    w = rng.uniform(0.1, 1.0, r.size)
+    if hub:
+        hc = rng.choice(n - 1, size=min(n - 1, 300), replace=False) + 1
+        r = np.concatenate([r, np.zeros(hc.size, dtype=r.dtype)])
+        c = np.concatenate([c, hc])
+        w = np.concatenate([w, rng.uniform(0.1, 1.0, hc.size)])
+    A = sparse.coo_matrix((w, (r, c)), shape=(n, n)).tocsr()
+    W = sparse.csr_matrix(A + A.T)
+    if isolated:
+        iso = rng.choice(n, size=isolated, replace=False)
+        mask = np.ones(n)
+        mask[iso] = 0
+        D = sparse.diags(mask)
+        W = sparse.csr_matrix(D @ W @ D)
+        W.eliminate_zeros()
+    W.sum_duplicates()
+    W.sort_indices()
+    return W
+
+
+def upper_lmax(W):
+    return 2.0 * float(np.ravel(W.sum(axis=0)).max()) + 1e-9
+
+
+# ---------------------------------------------------------------------------------------------
+# Laplacian built on device (graph.py:510-630)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_laplacian_4x4(golden_lap4, dtype):
+    g = golden_lap4
+    for name in ("und", "dir", "iso", "loop"):
+        for lt in ("combinatorial", "normalized"):
+            G = graphs.Graph(g["W_" + name], lap_type=lt, compute_dtype=dtype)
+            ref = g["L_{}_{}".format(name, lt)]
+            L = G.L
+            assert L.has_canonical_format
+            assert L.nnz == np.count_nonzero(ref), (name, lt)
+            np.testing.assert_allclose(L.toarray(), ref, rtol=0,
+                                       atol=1e-15 if dtype == np.float64 else 1e-6)
+            np.testing.assert_allclose(G.dw, g["dw_" + name], rtol=1e-6)
+            assert G.is_directed() == (name == "dir")
+    with pytest.raises(ValueError):
+        graphs.Graph(g["W_und"], lap_type="fancy")
+
+
+def test_laplacian_sensor_logo_bit_level(golden_sensor123, golden_logo):
+    W = csr_from(golden_sensor123, "W")
+    for lt, key in (("combinatorial", "Lcomb"), ("normalized", "Lnorm")):
+        dev = engine.DeviceGraph.from_w(W, lt)
+        L, ref = dev.download_l(), csr_from(golden_sensor123, key)
+        assert L.nnz == ref.nnz and dev.nnz_l == ref.nnz
+        np.testing.assert_array_equal(L.indptr, ref.indptr)
+        np.testing.assert_array_equal(L.indices, ref.indices)
+        assert abs(L - ref).max() < 1e-15
+        assert dev.nnz_internal % 4 == 0 and dev.nnz_internal >= ref.nnz
+    # sequential row sums == scipy's column sums for an exactly symmetric W: bit-identical dw
+    np.testing.assert_array_equal(engine.DeviceGraph.from_w(W).download_dw(), golden_sensor123["dw"])
+    Wl = csr_from(golden_logo, "W")
+    devl = engine.DeviceGraph.from_w(Wl)
+    assert abs(devl.download_l() - csr_from(golden_logo, "L")).max() == 0
+    np.testing.assert_array_equal(devl.download_dw(), golden_logo["dw"])
+
+
+def test_empty_and_selfloop_graphs():
+    """pygsp/tests/test_graphs.py:432-461: L.nnz == 0 for empty / self-loop-only graphs."""
+    for W in (np.zeros((6, 6)), np.identity(6)):
+        for lt in ("combinatorial", "normalized"):
+            G = graphs.Graph(W, lap_type=lt)
+            assert G.L.nnz == 0
+            assert G.L.shape == (6, 6)
+
+
+def test_adjacency_types():
+    """pygsp/tests/test_graphs.py:464-485: float32 / int / CSC / COO / dense inputs."""
+    W = random_graph(50, 6, 3)
+    ref = orc.laplacian(W).toarray()
+    for conv in (sparse.csc_matrix, sparse.coo_matrix, sparse.lil_matrix, lambda m: m.toarray()):
+        G = graphs.Graph(conv(W))
+        np.testing.assert_allclose(G.L.toarray(), ref, atol=1e-14)
+    Wi = sparse.csr_matrix((W > 0).astype(np.int64))
+    np.testing.assert_allclose(graphs.Graph(Wi).L.toarray(), orc.laplacian(Wi.astype(float)).toarray())
+    G32 = graphs.Graph(W.astype(np.float32), compute_dtype=np.float32)
+    np.testing.assert_allclose(G32.L.toarray(), ref, atol=1e-5)
+    with pytest.raises(ValueError):
+        graphs.Graph(np.ones((3, 4)))
+    bad = W.toarray()
+    bad[0, 1] = np.nan
+    with pytest.raises(ValueError):
+        graphs.Graph(bad)
+    bad[0, 1] = np.inf
+    with pytest.raises(ValueError):
+        graphs.Graph(bad)
+
+
+def test_capi_rejects_non_canonical_csr(ctx):
+    indptr = np.array([0, 2, 2], dtype=np.int32)
+    indices = np.array([1, 0], dtype=np.int32)  # not ascending
+    data = np.ones(2)
+    import ctypes
+    h = ctypes.c_void_p()
+    rc = _capi.load().gspx_graph_create_from_w(ctx._h, 2, 2, _capi.ptr(indptr), _capi.ptr(indices),
+                                               _capi.ptr(data), _capi.F64, 0, _capi.F64, None,
+                                               ctypes.byref(h))
+    assert rc == _capi.ERR_INVALID and "canonical" in _capi.last_error()
+    perm = np.array([0, 0], dtype=np.int32)  # not a permutation
+    indices2 = np.array([0, 1], dtype=np.int32)
+    rc = _capi.load().gspx_graph_create_from_w(ctx._h, 2, 2, _capi.ptr(indptr), _capi.ptr(indices2),
+                                               _capi.ptr(data), _capi.F64, 0, _capi.F64,
+                                               _capi.ptr(perm), ctypes.byref(h))
+    assert rc == _capi.ERR_INVALID and "permutation" in _capi.last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors of the reference
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_logo_heat50_config0(golden_logo, dtype):
+    """BASELINE.json configs[0]: Logo + Heat(50), 3 deltas, order 30."""
+    g = golden_logo
+    G = graphs.Graph(csr_from(g, "W"), compute_dtype=dtype)
+    for tag in ("bounds", "fourier"):
+        G._lmax = float(g["lmax_" + tag])
+        h = filters.Heat(G, scale=50)
+        np.testing.assert_allclose(filters.compute_cheby_coeff(h, m=30), g["coeff_" + tag],
+                                   rtol=1e-12, atol=1e-16)
+        y = h.filter(g["signal"], method="chebyshev", order=30)
+        assert y.shape == (G.N,) and y.dtype == np.float64
+        assert rel_err(y, g["y_" + tag]) < TOL[np.dtype(dtype)]
+    G.estimate_lmax("bounds")
+    assert abs(G.lmax / float(g["lmax_bounds"]) - 1) < (1e-12 if dtype == np.float64 else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sensor123_golden(golden_sensor123, dtype):
+    g = golden_sensor123
+    tol = TOL[np.dtype(dtype)]
+    G = graphs.Graph(csr_from(g, "W"), coords=g["coords"], compute_dtype=dtype)
+    G._lmax = float(g["lmax"])
+    h = filters.Heat(G, scale=10)
+    assert rel_err(h.filter(g["signal"], order=30), g["heat10_y"]) < tol
+    assert rel_err(h.filter(g["signals5"], order=30), g["heat10_y5"]) < tol
+    assert rel_err(h.filter(g["signal"], order=1), g["heat10_order1"]) < tol
+    assert rel_err(h.filter(g["signal"], order=2), g["heat10_order2"]) < tol
+    if dtype == np.float64:
+        # test_approximations (test_filters.py:403-414): Chebyshev-30 == exact, rtol 1e-7
+        np.testing.assert_allclose(h.filter(g["signal"], order=30), g["heat10_exact"], rtol=1e-7)
+    with pytest.raises(TypeError):
+        h.filter(g["signal"], order=0)
+    with pytest.raises(ValueError):
+        h.filter(g["signal"], method="lanczos")
+    mh = filters.MexicanHat(G, Nf=6)
+    np.testing.assert_allclose(np.array(filters.compute_cheby_coeff(mh, m=40)), g["mh6_c"],
+                               rtol=1e-12, atol=1e-15)
+    a = mh.filter(g["signals5"], order=40)
+    assert a.shape == (123, 5, 6)
+    assert rel_err(a, g["mh6_analysis"]) < tol
+    assert rel_err(mh.filter(g["mh6_analysis"], order=40), g["mh6_synthesis"]) < tol
+    a1 = mh.filter(g["signal"], order=40)
+    assert a1.shape == (123, 6)
+    assert rel_err(a1, g["mh6_analysis1"]) < tol
+    assert rel_err(mh.filter(g["mh6_analysis1"], order=40), g["mh6_synthesis1"]) < tol
+    # frame: the identity as signal, Nsig = N = 123 (test_filters.py:157-168, 82-84)
+    h2 = filters.Heat(G, scale=[8, 9])
+    F = h2.compute_frame(method="chebyshev", order=30)
+    assert F.shape == (246, 123)
+    assert rel_err(F, g["heat89_frame"]) < tol
+    np.testing.assert_allclose(F.dot(g["signal"]).reshape(2, 123).T, h2.filter(g["signal"], order=30),
+                               rtol=1e-7 if dtype == np.float64 else 1e-3, atol=1e-12)
+    # normalized Laplacian with the bound lmax = 2
+    G.compute_laplacian("normalized")
+    G.estimate_lmax("bounds")
+    assert G.lmax == 2
+    hn = filters.Heat(G, scale=10)
+    assert rel_err(hn.filter(g["signal"], order=30), g["heat10_norm_y"]) < tol
+
+
+def test_doctest_value(golden_doctest):
+    """filter.py:232-256 pinned number: ||s1 - s2|| = 0.27649."""
+    g = golden_doctest
+    G = graphs.Graph(csr_from(g, "W"))
+    G._lmax = float(g["lmax"])
+    s1 = np.zeros(G.N)
+    s1[13] = 1
+    s1 = filters.Heat(G, 3).filter(s1)
+    assert rel_err(s1, g["s1"]) < 1e-12
+    mh = filters.MexicanHat(G, Nf=4)
+    s2 = mh.analyze(s1)
+    assert s2.shape == (G.N, 4)
+    s3 = mh.synthesize(s2)
+    assert "{:.5f}".format(np.linalg.norm(s1 - s3)) == "0.27649"
+
+
+def test_shape_contract():
+    """Truth table of Filter.filter (pygsp/tests/test_filters.py:87-122)."""
+    N = 40
+    W = random_graph(N, 5, 11)
+    G = graphs.Graph(W)
+    G.estimate_lmax("bounds")
+    rng = np.random.default_rng(0)
+    heat, mh = filters.Heat(G), filters.MexicanHat(G, Nf=6)
+    for shape, out1, out6 in [((N,), (N,), (N, 6)), ((N, 1), (N,), (N, 6)), ((N, 1, 1), (N,), (N, 6)),
+                              ((N, 4), (N, 4), (N, 4, 6)), ((N, 4, 1), (N, 4), (N, 4, 6)),
+                              ((N, 6), (N, 6), (N,)), ((N, 4, 6), None, (N, 4)),
+                              ((N, 6, 6), None, (N, 6)), ((N, 6, 1), (N, 6), (N, 6, 6)),
+                              ((N, 4, 3), None, None), ((N, 0), (N, 0), (N, 0, 6))]:
+        s = rng.standard_normal(shape)
+        for f, expect in ((heat, out1), (mh, out6)):
+            if expect is None:
+                with pytest.raises(ValueError):
+                    f.filter(s)
+            else:
+                assert f.filter(s).shape == expect, (shape, f.Nf)
+    with pytest.raises(ValueError):
+        heat.filter(rng.standard_normal((N, 2, 2, 1)))
+    with pytest.raises(ValueError):
+        heat.filter(rng.standard_normal(N + 1))
+    with pytest.raises(ValueError):
+        mh.analyze(rng.standard_normal((N, 4, 6)))
+    with pytest.raises(ValueError):
+        mh.synthesize(rng.standard_normal((N, 4)))
+    # integer / list / Fortran-ordered / float32 inputs give float64 C-ordered results
+    base = rng.integers(-3, 4, size=(N, 3))
+    ref = heat.filter(base.astype(float))
+    for s in (base, base.tolist(), np.asfortranarray(base.astype(float)), base.astype(np.float32)):
+        y = heat.filter(s)
+        assert y.dtype == np.float64
+        np.testing.assert_allclose(y, ref, rtol=1e-12, atol=1e-14)
+    # inputs are never mutated
+    s = rng.standard_normal((N, 3))
+    keep = s.copy()
+    mh.filter(s)
+    np.testing.assert_array_equal(s, keep)
+    # localize = sqrt(N) * filter(delta_i)
+    d = np.zeros(N)
+    d[7] = 1
+    np.testing.assert_allclose(heat.localize(7), np.sqrt(N) * heat.filter(d))
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded random graphs vs the oracle: every panel width, both kernels, both dtypes
+# ---------------------------------------------------------------------------------------------
+NSIGS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 31, 32, 33, 64, 65, 100, 128, 130, 257]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nsig", NSIGS)
+def test_random_graph_vs_oracle(ctx, dtype, nsig):
+    n = 3001
+    W = random_graph(n, 9, seed=nsig, hub=True, isolated=5)
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    rng = np.random.default_rng(100 + nsig)
+    x = rng.standard_normal((n, nsig))
+    perm = rng.permutation(n).astype(np.int32) if nsig % 2 else None
+    dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+    c1 = orc.compute_cheby_coeff(orc.heat_kernel(7, lmax), lmax, 25)
+    y, ms = dev.cheby_filter(c1, x, lmax)
+    ref = orc.cheby_op(L, lmax, c1, x.astype(dtype).astype(np.float64))
+    assert y.shape == (1, n, nsig) and ms > 0
+    assert rel_err(y[0], ref) < TOL[np.dtype(dtype)]
+    # a 3-filter bank (deferred combine) and its fused-flush twin
+    c3 = np.array([orc.compute_cheby_coeff(k, lmax, 12) for k in orc.mexican_hat_kernels(lmax, 3)])
+    ref3 = orc.cheby_op(L, lmax, c3, x.astype(dtype).astype(np.float64)).reshape(3, n, nsig)
+    for combine in (0, 1, 2):
+        ctx.set_option("combine", combine)
+        y3, _ = dev.cheby_filter(c3, x, lmax)
+        assert rel_err(y3, ref3) < TOL[np.dtype(dtype)], combine
+    ctx.set_option("combine", 0)
+    dev.destroy()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_kernel_variants_agree(ctx, dtype):
+    """Every tuning knob computes the same thing."""
+    n, nsig = 5000, 64
+    W = random_graph(n, 10, seed=5, hub=True, isolated=3)
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    x = np.random.default_rng(1).standard_normal((n, nsig))
+    c = orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, 30)
+    ref = orc.cheby_op(L, lmax, c, x.astype(dtype).astype(np.float64))
+    dev = engine.DeviceGraph.from_w(W, dtype=dtype, ctx=ctx)
+    tol = TOL[np.dtype(dtype)]
+    try:
+        for vec in (0, 1, 2, 4):
+            for rpw in (4, 8, 32):
+                for remap in (0, 1):
+                    ctx.set_option("vec", vec)
+                    ctx.set_option("rows_per_wave", rpw)
+                    ctx.set_option("xcd_remap", remap)
+                    y, _ = dev.cheby_filter(c, x, lmax)
+                    assert rel_err(y[0], ref) < tol, (vec, rpw, remap)
+        ctx.set_option("vec", 0)
+        ctx.set_option("rows_per_wave", 8)
+        ctx.set_option("xcd_remap", 1)
+        ctx.set_option("kernel", 2)  # narrow kernel forced on a wide panel
+        for g in (0, 2, 3):
+            ctx.set_option("narrow_g_log2", g)
+            y, _ = dev.cheby_filter(c, x[:, :16], lmax)
+            assert rel_err(y[0], ref[:, :16]) < tol, g
+        ctx.set_option("kernel", 0)
+        ctx.set_option("narrow_g_log2", 2)
+        # signal batching: 64 signals in batches of 24 (24 + 24 + 16)
+        ctx.set_option("max_batch", 24)
+        y, _ = dev.cheby_filter(c, x, lmax)
+        assert rel_err(y[0], ref) < tol
+        c3 = np.array([orc.compute_cheby_coeff(k, lmax, 9) for k in orc.mexican_hat_kernels(lmax, 3)])
+        ref3 = orc.cheby_op(L, lmax, c3, x.astype(dtype).astype(np.float64)).reshape(3, n, nsig)
+        y3, _ = dev.cheby_filter(c3, x, lmax)
+        assert rel_err(y3, ref3) < tol
+    finally:
+        for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 8), ("xcd_remap", 1),
+                         ("max_batch", 0), ("narrow_g_log2", 2)):
+            ctx.set_option(key, val)
+        dev.destroy()
+
+
+def test_host_laplacian_upload_matches_device_build(ctx):
+    """gspx_graph_create_from_l (bit-parity mode) == device-built Laplacian."""
+    W = random_graph(2000, 8, seed=9)
+    L = orc.laplacian(W, "normalized")
+    x = np.random.default_rng(2).standard_normal((2000, 6))
+    c = orc.compute_cheby_coeff(orc.heat_kernel(3, 2.0), 2.0, 20)
+    a = engine.DeviceGraph.from_w(W, "normalized", ctx=ctx)
+    b = engine.DeviceGraph.from_l(L, ctx=ctx)
+    ya, _ = a.cheby_filter(c, x, 2.0)
+    yb, _ = b.cheby_filter(c, x, 2.0)
+    ref = orc.cheby_op(L, 2.0, c, x)
+    assert rel_err(ya[0], ref) < 1e-12 and rel_err(yb[0], ref) < 1e-12
+    with pytest.raises(ValueError):
+        b.download_dw()
+
+
+def test_analysis_synthesis_adjoint():
+    """<g.filter(x), y> == <x, g.filter(y)>."""
+    G = graphs.Sensor(500, seed=3)
+    G.estimate_lmax("bounds")
+    mh = filters.MexicanHat(G, Nf=5)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((G.N, 3))
+    y = rng.standard_normal((G.N, 3, 5))
+    lhs = np.sum(mh.filter(x, order=25) * y)
+    rhs = np.sum(x * mh.filter(y, order=25))
+    assert abs(lhs - rhs) < 1e-11 * max(abs(lhs), 1.0)
+
+
+def test_device_resident_chain_and_timing(ctx):
+    """Device pointers in/out: no host round trip between two filters; HIP-event timings."""
+    G = graphs.Sensor(20000, seed=1)
+    G.estimate_lmax("bounds")
+    dev = G.device_graph()
+    lmax = G.lmax
+    c = orc.compute_cheby_coeff(orc.heat_kernel(10, lmax), lmax, 30)
+    x = np.random.default_rng(0).standard_normal((G.N, 8))
+    bx, by, bz = ctx.upload(x), ctx.alloc(x.nbytes), ctx.alloc(x.nbytes)
+    ms1 = dev.cheby_filter_dev(c, bx.ptr, by.ptr, 8, lmax)
+    ms2 = dev.cheby_filter_dev(c, by.ptr, bz.ptr, 8, lmax)
+    t = ctx.last_timing()
+    assert ms1 > 0 and ms2 > 0 and t["step_launches"] == 30
+    assert 0 < t["steps_ms"] <= t["total_ms"] * 1.001
+    z = bz.download(x.shape, np.float64)
+    L = orc.laplacian(G.W)
+    ref = orc.cheby_op(L, lmax, c, orc.cheby_op(L, lmax, c, x))
+    assert rel_err(z, ref) < 1e-11
+
+
+# ---------------------------------------------------------------------------------------------
+# sizes of BASELINE.json: size-independent properties + oracle on a column sample
+# ---------------------------------------------------------------------------------------------
+def _constant_signal_gain(c):
+    """L 1 = 0  =>  T_k(L~) 1 = (-1)^k 1, so filtering a constant multiplies it by
+    0.5 c0 + sum_k (-1)^k c_k."""
+    k = np.arange(1, len(c))
+    return 0.5 * c[0] + np.sum(((-1.0) ** k) * c[1:])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_config1_sensor100k_single_signal(dtype):
+    """BASELINE.json configs[1]: Sensor(100000), combinatorial, Heat, K=30, 1 signal."""
+    G = graphs.Sensor(100000, seed=42, compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    h = filters.Heat(G, scale=50)
+    s = np.random.default_rng(0).standard_normal(G.N)
+    y = h.filter(s, order=30)
+    L = orc.laplacian(G.W)
+    ref = orc.filter_chebyshev(L, G.lmax, [orc.heat_kernel(50, G.lmax)], s, 30)
+    assert rel_err(y, ref) < BAR[np.dtype(dtype)] * 1e-2
+    assert abs(G.L - L).max() < (1e-13 if dtype == np.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_headline_size_properties(ctx, dtype):
+    """North-star size: 1M-vertex k=8 sensor graph (~10M stored entries), 64 signals, order 30.
+    Oracle on 2 sampled columns; linearity and the constant-signal identity on all 64."""
+    N, nsig, order = 1000000, 64, 30
+    W, coords = graphs.sensor_weights(N, k=8, seed=42)
+    G = graphs.Graph(W, coords=coords, compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    lmax = G.lmax
+    c = orc.compute_cheby_coeff(orc.heat_kernel(50, lmax), lmax, order)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((N, nsig)).astype(dtype)
+    x[:, 5] = 3.0  # a constant column
+    dev = G.device_graph()
+    y, ms = dev.cheby_filter(c, x, lmax)
+    y = y[0]
+    tol = BAR[np.dtype(dtype)]
+    # constant-signal identity
+    gain = _constant_signal_gain(c)
+    assert np.max(np.abs(y[:, 5] - 3.0 * gain)) < tol * abs(3.0 * gain)
+    # oracle on two columns
+    L = orc.laplacian(W)
+    cols = [0, 63]
+    ref = orc.cheby_op(L, lmax, c, x[:, cols].astype(np.float64))
+    assert rel_err(y[:, cols], ref) < tol * 1e-1
+    # linearity: f(2 x_a - x_b) = 2 f(x_a) - f(x_b), columnwise
+    x2 = (2 * x[:, :32] - x[:, 32:]).astype(dtype)
+    y2, _ = dev.cheby_filter(c, x2, lmax)
+    lin = 2 * y[:, :32].astype(np.float64) - y[:, 32:].astype(np.float64)
+    assert rel_err(y2[0], lin) < (1e-10 if dtype == np.float64 else 1e-3)
+    # vertex order is internal: the device graph without reordering gives the same answer
+    dev_plain = engine.DeviceGraph.from_w(W, dtype=dtype, perm=None, ctx=ctx)
+    y3, _ = dev_plain.cheby_filter(c, x[:, :4], lmax)
+    assert rel_err(y3[0], y[:, :4]) < (1e-11 if dtype == np.float64 else 1e-4)
+    dev_plain.destroy()
+
+
+def test_erdos_renyi_filterbank_fp32():
+    """Scaled-down BASELINE.json configs[2]: ER graph (isolated vertices occur), MexicanHat x6,
+    K=50, fp32 engine vs fp64 oracle at the 1e-3 bar."""
+    N = 200000
+    G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=np.float32)
+    G.estimate_lmax("bounds")
+    assert G.W.dtype == np.int64
+    mh = filters.MexicanHat(G, Nf=6)
+    x = np.random.default_rng(1).standard_normal((N, 16)).astype(np.float32)
+    y = mh.filter(x, order=50)
+    assert y.shape == (N, 16, 6)
+    L = orc.laplacian(G.W.astype(np.float64))
+    ref = orc.filter_chebyshev(L, G.lmax, orc.mexican_hat_kernels(G.lmax, 6), x[:, :2].astype(np.float64), 50)
+    assert rel_err(y[:, :2, :], ref) < 1e-3 * 1e-1
+
+
+def test_sbm_normalized_isolated_rule():
+    """Scaled-down BASELINE.json configs[3]: SBM, normalized Laplacian, 16 signals."""
+    N, k = 100000, 16
+    G = graphs.StochasticBlockModel(N, k=k, p=12.0 * k / N, q=4.0 * k / (N * (k - 1)), seed=0,
+                                    lap_type="normalized")
+    G.estimate_lmax("bounds")
+    assert G.lmax == 2
+    L = orc.laplacian(G.W.astype(np.float64), "normalized")
+    assert abs(G.L - L).max() < 1e-14 and G.L.nnz == L.nnz
+    x = np.random.default_rng(2).standard_normal((N, 16))
+    y = filters.Heat(G, 10).filter(x, order=30)
+    ref = orc.filter_chebyshev(L, 2.0, [orc.heat_kernel(10, 2.0)], x[:, :3], 30)
+    assert rel_err(y[:, :3], ref) < 1e-11
+
+
+def test_plugin_patches_a_pygsp_like_module(ctx):
+    """plugin.install(): the reference's two lookup sites get the device cheby_op
+    (filters/filter.py:309 via approximations, filters/__init__.py:115 alias)."""
+    import types
+
+    from pygsp_amd import plugin
+
+    W = random_graph(300, 6, 21)
+
+    class RefGraph:  # the attributes the path reads from a reference Graph
+        def __init__(self):
+            self.W = W
+            self.N = W.shape[0]
+            self.lap_type = "combinatorial"
+            self.L = orc.laplacian(W)
+            self.lmax = upper_lmax(W)
+
+        def is_directed(self):
+            return False
+
+    fake = types.ModuleType("pygsp")
+    fake.filters = types.ModuleType("pygsp.filters")
+    fake.filters.approximations = types.ModuleType("pygsp.filters.approximations")
+    orig = lambda G, c, s, **kw: orc.cheby_op(G.L, G.lmax, c, s)  # noqa: E731
+    fake.filters.approximations.cheby_op = orig
+    fake.filters.cheby_op = orig
+    G = RefGraph()
+    c = orc.compute_cheby_coeff(orc.heat_kernel(4, G.lmax), G.lmax, 15)
+    s = np.random.default_rng(3).standard_normal((G.N, 2))
+    for mode in ("device", "host"):
+        plugin.install(fake, laplacian=mode)
+        assert fake.filters.approximations.cheby_op is filters.cheby_op
+        assert fake.filters.cheby_op is filters.cheby_op
+        y = fake.filters.approximations.cheby_op(G, c, s)
+        assert y.shape == (G.N, 2) and rel_err(y, orig(G, c, s)) < 1e-12
+        assert fake.filters.cheby_op(G, c, s[:, 0]).shape == (G.N,)
+        plugin.uninstall(fake)
+        assert fake.filters.approximations.cheby_op is orig and fake.filters.cheby_op is orig
