@@ -39,11 +39,12 @@ def compute_cheby_coeff(f, m=30, N=None, *args, **kwargs):
     if not N:
         N = m + 1
     a1 = a2 = G.lmax / 2
-    theta = np.pi * (np.arange(N) + 0.5) / N
-    samples = f._kernels[i](a1 * np.cos(theta) + a2)
+    j = np.arange(N)
+    samples = f._kernels[i](a1 * np.cos(np.pi * (j + 0.5) / N) + a2)
     c = np.empty(m + 1)
     for o in range(m + 1):
-        c[o] = 2.0 / N * np.dot(samples, np.cos(o * theta))
+        # same operation order as the reference, so the coefficients are bit-identical
+        c[o] = 2.0 / N * np.dot(samples, np.cos(np.pi * o * (j + 0.5) / N))
     return c
 
 

@@ -1,0 +1,131 @@
+"""Host-side logic of the product that needs no GPU: coefficient quadrature, kernel designs,
+filterbank handler, shape algebra (with a stubbed device call), generators, vertex ordering."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import csr_from, rel_err
+from oracle import cheby_oracle as orc
+from pygsp_amd import engine, filters, graphs
+
+
+class StubGraph:
+    """What the host-side filter code reads from a Graph."""
+
+    def __init__(self, L, lmax):
+        self.L = L
+        self.N = L.shape[0]
+        self.lmax = lmax
+        self.e = None
+
+    def _check_signal(self, s):
+        s = np.asanyarray(s)
+        if s.shape[0] != self.N:
+            raise ValueError("First dimension must be the number of vertices")
+        return s
+
+
+def test_coefficients_match_reference(golden_logo, golden_sensor123):
+    G = StubGraph(csr_from(golden_logo, "L"), float(golden_logo["lmax_bounds"]))
+    c = filters.compute_cheby_coeff(filters.Heat(G, scale=50), m=30)
+    assert isinstance(c, np.ndarray) and c.shape == (31,)
+    np.testing.assert_allclose(c, golden_logo["coeff_bounds"], rtol=1e-13, atol=1e-17)
+    G2 = StubGraph(csr_from(golden_sensor123, "Lcomb"), float(golden_sensor123["lmax"]))
+    mh = filters.MexicanHat(G2, Nf=6)
+    cl = filters.compute_cheby_coeff(mh, m=40)
+    assert isinstance(cl, list) and len(cl) == 6  # filterbank_handler: list for Nf > 1
+    np.testing.assert_allclose(np.array(cl), golden_sensor123["mh6_c"], rtol=1e-12, atol=1e-16)
+    c3 = filters.compute_cheby_coeff(mh, m=40, i=3)
+    np.testing.assert_allclose(c3, golden_sensor123["mh6_c"][3], rtol=1e-12, atol=1e-16)
+    np.testing.assert_allclose(filters.compute_log_scales(1, 10, 3), [2.0, 0.4472136, 0.1], rtol=1e-7)
+    with pytest.raises(ValueError):
+        filters.MexicanHat(G2, Nf=4, scales=[1.0])
+
+
+def test_heat_reads_lmax_lazily():
+    """heat.py:111-112: lmax is read when the kernel is evaluated, not at construction."""
+    G = StubGraph(sparse.identity(4, format="csr"), 2.0)
+    h = filters.Heat(G, scale=[1, 5])
+    assert h.Nf == 2 and len(h) == 2
+    y1 = h.evaluate(np.array([0.0, 1.0, 2.0]))
+    G.lmax = 4.0
+    y2 = h.evaluate(np.array([0.0, 1.0, 2.0]))
+    assert y1.shape == (2, 3) and not np.allclose(y1, y2)
+    np.testing.assert_allclose(y2[1], np.exp(-5 * np.array([0.0, 1.0, 2.0]) / 4.0))
+    assert isinstance(h[0], filters.Filter) and (h + h).Nf == 4
+
+
+def test_filter_shape_algebra_with_stubbed_device(monkeypatch, golden_sensor123):
+    """Filter.filter's shape rules and synthesis wiring, with the device call replaced by the
+    oracle (test-only stub): must reproduce the reference's outputs exactly in shape and value."""
+    g = golden_sensor123
+    L, lmax = csr_from(g, "Lcomb"), float(g["lmax"])
+    G = StubGraph(L, lmax)
+
+    class StubDev:
+        def cheby_filter(self, c, x, lm, mode=0):
+            if mode == 0:
+                r = orc.cheby_op(L, lm, c, x)
+                return r.reshape(c.shape[0], G.N, -1), 0.0
+            out = sum(orc.cheby_op(L, lm, c[f], x[f]) for f in range(c.shape[0]))
+            return out, 0.0
+
+    monkeypatch.setattr(filters, "_device_graph_of", lambda G_: StubDev())
+    mh = filters.MexicanHat(G, Nf=6)
+    a = mh.filter(g["signals5"], order=40)
+    assert a.shape == (123, 5, 6) and rel_err(a, g["mh6_analysis"]) < 1e-13
+    assert rel_err(mh.filter(g["mh6_analysis"], order=40), g["mh6_synthesis"]) < 1e-13
+    assert rel_err(mh.synthesize(g["mh6_analysis1"], order=40), g["mh6_synthesis1"]) < 1e-13
+    h2 = filters.Heat(G, scale=[8, 9])
+    assert rel_err(h2.compute_frame(order=30), g["heat89_frame"]) < 1e-13
+    with pytest.raises(TypeError):
+        filters.Heat(G, 10).filter(g["signal"], order=0)
+    with pytest.raises(TypeError):
+        filters.cheby_op(G, np.ones(5), g["signal"] * 1j)
+    with pytest.raises(ValueError):
+        filters.cheby_op(G, np.ones(5), np.ones(124))
+    with pytest.raises(NotImplementedError):
+        filters.Heat(G, 10).filter(g["signal"], method="exact")
+    with pytest.raises(ValueError):
+        filters.Heat(G, 10).filter(g["signal"], method="lanczos")
+
+
+def test_sensor_generator_reproduces_reference_graph(golden_sensor123, golden_doctest):
+    """Same RNG stream, same kNN rule, same weights: identical W to graphs.Sensor(N, seed=42)."""
+    W, coords = graphs.sensor_weights(123, k=6, seed=42)
+    ref = csr_from(golden_sensor123, "W")
+    np.testing.assert_array_equal(coords, golden_sensor123["coords"])
+    assert (W != ref).nnz == 0 or abs(W - ref).max() < 1e-15
+    W30, _ = graphs.sensor_weights(30, k=6, seed=42)
+    assert abs(W30 - csr_from(golden_doctest, "W")).max() < 1e-15
+
+
+def test_sbm_and_er_samplers():
+    N, k = 4000, 4
+    p, q = 0.02, 0.002
+    W, z = graphs.sbm_weights(N, k, p=p, q=q, seed=1)
+    assert W.dtype == np.int64 and (W != W.T).nnz == 0 and W.diagonal().sum() == 0
+    assert W.max() == 1  # distinct pairs: no duplicate edges
+    same = z[:, None] == z[None, :]
+    A = W.toarray().astype(bool)
+    iu = np.triu_indices(N, 1)
+    p_hat = A[iu][same[iu]].mean()
+    q_hat = A[iu][~same[iu]].mean()
+    assert abs(p_hat - p) < 0.1 * p and abs(q_hat - q) < 0.15 * q
+    We, _ = graphs.sbm_weights(3000, 1, np.zeros(3000, dtype=np.int64), 0.01, 0, seed=2)
+    deg = np.ravel(We.sum(0))
+    assert abs(deg.mean() - 0.01 * 2999) < 1.0
+
+
+def test_locality_order_is_a_permutation_and_local():
+    W, coords = graphs.sensor_weights(5000, k=6, seed=3)
+    perm = engine.locality_order(W, coords)
+    assert sorted(perm.tolist()) == list(range(5000))
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(5000)
+    coo = W.tocoo()
+    before = np.median(np.abs(coo.row - coo.col))
+    after = np.median(np.abs(inv[coo.row] - inv[coo.col]))
+    assert after < before / 50  # Morton order: neighbours become close in index
+    rcm = engine.locality_order(W, None)
+    assert sorted(rcm.tolist()) == list(range(5000))
