@@ -95,7 +95,7 @@ struct DevMem {
 struct Options {
   int64_t kernel = 0;         // 0 auto, 1 panel, 2 narrow
   int64_t vec = 0;            // 0 auto
-  int64_t rows_per_wave = 8;
+  int64_t rows_per_wave = 4;
   int64_t narrow_g_log2 = 2;
   int64_t xcd_remap = 1;
   int64_t combine = 0;        // 0 auto, 1 fused flush, 2 deferred
@@ -769,7 +769,10 @@ static void launch_panel(const StepArgs<T>& a, const Shape& s, dim3 grid, hipStr
 template <typename T>
 static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st) {
   int rpw = (int)opt.rows_per_wave;
-  if (s.kernel == 1) rpw = (rpw + 3) & ~3;  // whole row sets (up to 4 rows per wave pass)
+  if (s.kernel == 1) {
+    const int R = 64 >> s.wlog2;  // rows per row set
+    rpw = ((rpw + R - 1) / R) * R;
+  }
   a.rows_per_wave = rpw;
   int rows_per_chunk;
   if (s.kernel == 1)

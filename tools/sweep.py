@@ -46,7 +46,7 @@ def main():
     print("graph gen s:", time.time() - t0, "nnz_W", W.nnz, flush=True)
     for dtype in (np.float64, np.float32):
         elt = np.dtype(dtype).itemsize
-        for reorder in ("morton", "none"):
+        for reorder in ("morton",):
             perm = engine.locality_order(W, coords) if reorder == "morton" else None
             t0 = time.time()
             dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
@@ -60,7 +60,7 @@ def main():
             csr = dev.nnz_l * (elt + 4) + 4 * (a.n + 1)
             b_launch = (a.order * (csr + 3 * U) + U) / a.order
             vecs = (1, 2) if elt == 8 else (1, 2, 4)
-            rpws = (4, 8, 16, 32) if not a.quick else (8,)
+            rpws = (1, 2, 4, 8) if not a.quick else (4,)
             remaps = (1, 0) if reorder == "morton" else (1,)
             for vec, rpw, remap in itertools.product(vecs, rpws, remaps):
                 ctx.set_option("vec", vec)
@@ -74,7 +74,7 @@ def main():
                 res["runs"].append(run)
                 print(json.dumps(run), flush=True)
                 json.dump(res, open(a.out, "w"), indent=1)
-            for key, val in (("vec", 0), ("rows_per_wave", 8), ("xcd_remap", 1)):
+            for key, val in (("vec", 0), ("rows_per_wave", 4), ("xcd_remap", 1)):
                 ctx.set_option(key, val)
             bx.free(); by.free(); dev.destroy()
     json.dump(res, open(a.out, "w"), indent=1)
