@@ -60,7 +60,8 @@ int gspx_ctx_create(int device, gspx_ctx** out);
 int gspx_ctx_destroy(gspx_ctx* ctx);
 int gspx_ctx_sync(gspx_ctx* ctx);
 /* tuning knobs (integers).  Unknown key -> GSPX_ERR_INVALID.  Keys:
- *   "kernel"      0 auto, 1 panel (wave-per-row, scalar CSR metadata), 2 narrow (sub-wave rows)
+ *   "kernel"      0 auto, 1 panel (lane groups own rows), 2 narrow (sub-wave rows), 3 wave-row
+ *                 (one row per wave, all metadata scalar)
  *   "vec"         0 auto, else elements per lane (1,2,4)
  *   "rows_per_wave"  panel kernel: consecutive rows per wave (default 4)
  *   "narrow_g_log2"  narrow kernel: log2 of lanes splitting one row's entries

@@ -134,7 +134,8 @@ struct gspx_graph {
   DevMem lptr, lcol, lval, dw;
   // internal padded CSR, engine vertex order
   int64_t nnz_int = 0;
-  DevMem rptr, rcol, rval, fval;
+  DevMem rptr, rcol, rval, fval, coff;
+  unsigned coff_ldb = 0;  // panel row bytes the cached byte offsets were built for
   DevMem perm, iperm;
   bool has_perm = false;
   double fval_lmax = -1.0;
@@ -406,7 +407,7 @@ template <typename T> static int build_internal(gspx_graph* g) {
   if (N > 0) {
     hipLaunchKernelGGL((k_internal_build<T, false>), dim3(nb), dim3(256), 0, ctx->stream,
                        g->lptr.as<int>(), g->lcol.as<int>(), g->lval.as<T>(), N, perm, iperm,
-                       cnt.as<int>(), (const int*)nullptr, (int*)nullptr, (T*)nullptr);
+                       cnt.as<int>(), (int*)nullptr, (int*)nullptr, (T*)nullptr);
     HIPCHK(hipGetLastError());
   }
   CHK(scan_exclusive(ctx, cnt.as<int>(), g->rptr.as<int>(), N + 1));
@@ -435,6 +436,7 @@ template <typename T> static int build_internal(gspx_graph* g) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   g->fval_lmax = -1.0;
+  g->coff_ldb = 0;
   return GSPX_OK;
 }
 
@@ -466,7 +468,7 @@ static int create_from_w_t(gspx_graph* g, int64_t nnz, const int32_t* indptr,
                        wval.as<T>(), N, g->dw.as<T>());
     hipLaunchKernelGGL((k_lap_build<T, false>), dim3(nb), dim3(256), 0, ctx->stream,
                        wptr.as<int>(), wcol.as<int>(), wval.as<T>(), g->dw.as<T>(), N, lap_type,
-                       cnt.as<int>(), (const int*)nullptr, (int*)nullptr, (T*)nullptr);
+                       cnt.as<int>(), (int*)nullptr, (int*)nullptr, (T*)nullptr);
     HIPCHK(hipGetLastError());
   }
   CHK(scan_exclusive(ctx, cnt.as<int>(), g->lptr.as<int>(), N + 1));
@@ -708,7 +710,7 @@ extern "C" int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* co
 // kernel dispatch
 // ------------------------------------------------------------------------------------------------
 struct Shape {
-  int kernel;  // 1 panel, 2 narrow
+  int kernel;  // 1 panel (lane groups), 2 narrow, 3 wave-row
   int vec;
   int wlog2;
   int glog2;   // narrow only
@@ -726,6 +728,19 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
   int kernel = (ld <= 4) ? 2 : 1;
   if (opt.kernel == 2 && ld <= 64) kernel = 2;
   if (opt.kernel == 1 && ld > 4) kernel = 1;
+  // wave-row kernel: one row per wave, all 64 lanes on its signals.  Auto when the panel fills
+  // more than half a wave at one element per lane.
+  if (opt.kernel == 3 || (opt.kernel == 0 && ld > 32)) {
+    int v = 1;
+    while (v < maxvec && ld % (2 * v) == 0 && ld / v > 64) v *= 2;
+    if (opt.vec != 0 && opt.vec <= maxvec && ld % opt.vec == 0) v = (int)opt.vec;
+    s.kernel = 3;
+    s.vec = v;
+    s.wlog2 = 6;
+    s.glog2 = 0;
+    s.gridy = (int)((ld / v + 63) / 64);
+    return s;
+  }
   s.kernel = kernel;
   if (kernel == 1) {
     s.vec = vec;
@@ -766,8 +781,23 @@ static void launch_panel(const StepArgs<T>& a, const Shape& s, dim3 grid, hipStr
   return launch_panel_w<T, 1, FLUSH>(a, s.wlog2, grid, st);
 }
 
+template <typename T, bool FLUSH>
+static void launch_wrow(const StepArgs<T>& a, const unsigned* coff, const Shape& s, dim3 grid,
+                        hipStream_t st) {
+#define GSPX_LW(V)                                                                            \
+  hipLaunchKernelGGL((k_step_wrow<T, V, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff, a.val, \
+                     a.cur, a.wts, a.perm, a)
+  if constexpr (sizeof(T) == 4) {
+    if (s.vec == 4) { GSPX_LW(4); return; }
+  }
+  if (s.vec == 2) { GSPX_LW(2); return; }
+  GSPX_LW(1);
+#undef GSPX_LW
+}
+
 template <typename T>
-static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st) {
+static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st,
+                        const unsigned* coff) {
   int rpw = (int)opt.rows_per_wave;
   if (s.kernel == 1) {
     const int R = 64 >> s.wlog2;  // rows per row set
@@ -775,7 +805,7 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
   }
   a.rows_per_wave = rpw;
   int rows_per_chunk;
-  if (s.kernel == 1)
+  if (s.kernel == 1 || s.kernel == 3)
     rows_per_chunk = 4 * rpw;
   else
     rows_per_chunk = rpw * (4 << (6 - s.wlog2 - s.glog2));
@@ -787,7 +817,10 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
     gx = a.cpx * 8;
   }
   dim3 grid((unsigned)gx, (unsigned)s.gridy, 1);
-  if (s.kernel == 1) {
+  if (s.kernel == 3) {
+    if (a.flush) launch_wrow<T, true>(a, coff, s, grid, st);
+    else launch_wrow<T, false>(a, coff, s, grid, st);
+  } else if (s.kernel == 1) {
     if (a.flush) launch_panel<T, true>(a, s, grid, st);
     else launch_panel<T, false>(a, s, grid, st);
   } else {
@@ -931,6 +964,14 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   launch_permute_in<T>(x, ldx, slots, ld, N, perm, pvec, st);
   HIPCHK(hipEventRecord(e1, st));
 
+  if (shape.kernel == 3 && g->coff_ldb != ld * (unsigned)sizeof(T)) {
+    // byte offsets col*ld*sizeof(T) for this panel width (cached on the graph)
+    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
+    const int nb = std::max(1, (N + 255) / 256);
+    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
+                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), g->coff.as<unsigned>());
+    g->coff_ldb = ld * (unsigned)sizeof(T);
+  }
   StepArgs<T> a{};
   a.rowptr = g->rptr.as<int>();
   a.col = g->rcol.as<int>();
@@ -960,7 +1001,7 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
     a.flush = ps.flush;
     a.final = ps.final;
     a.wts = ctx->ws_w.as<T>() + (size_t)(k - 1) * nf * 3;
-    launch_step<T>(a, shape, opt, st);
+    launch_step<T>(a, shape, opt, st, g->coff.as<unsigned>());
   }
   HIPCHK(hipEventRecord(e2, st));
   if (deferred) {

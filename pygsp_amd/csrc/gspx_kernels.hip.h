@@ -226,9 +226,10 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   const int srow = __builtin_amdgcn_readfirstlane(c.row0 + it * R);
   if (srow >= a.N) return false;
   // rowptr is padded past N with the total entry count, so rows >= N read as empty
-  const RowVals<int, R> rs = RowVals<int, R>::make([&](int q) { return c.rowptr[srow + q]; });
+  // (low 2 bits of a rowptr entry carry that row's pad count; starts are multiples of 4)
+  const RowVals<int, R> rs = RowVals<int, R>::make([&](int q) { return c.rowptr[srow + q] & ~3; });
   const RowVals<int, R> nch = RowVals<int, R>::make(
-      [&](int q) { return (c.rowptr[srow + q + 1] - c.rowptr[srow + q]) >> 2; });  // len % 4 == 0
+      [&](int q) { return (c.rowptr[srow + q + 1] >> 2) - (c.rowptr[srow + q] >> 2); });
   const RowVals<int, R> last =
       RowVals<int, R>::make([&](int q) { return nch.at(q) > 0 ? nch.at(q) - 1 : 0; });
   int nmax = nch.at(0);
@@ -395,6 +396,155 @@ __global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowp
 }
 
 // ---------------------------------------------------------------------------------------------
+// WAVE-ROW kernel: one wave works on ONE row at a time, its 64 lanes spanning the signals.
+// Everything about the row is wave-uniform and lives in SGPRs:
+//   * row start / chunk count / pad count from rowptr (s_load),
+//   * per entry a precomputed BYTE offset col*ld*sizeof(T) ("coff", cached per panel width) and
+//     the factor value: s_load_dwordx4 / x8 per 4-entry chunk,
+//   * the gather is  buffer_load v, v_lane, s[rsrc], s_coff offen : the scalar byte offset goes
+//     straight into the instruction's soffset field, and the FMA takes the value as an SGPR
+//     operand.  Per stored entry the wave issues exactly one VMEM and VEC VALU instructions and
+//     no scalar ALU work: the MI355X SIMD issues about one instruction per 4-5 cycles whatever
+//     its type (measured, profiles/), so instructions per row - not bytes - bound the previous
+//     lane-group design.
+// Pads never reach the memory pipeline: the last chunk issues only its real entries (pad count
+// in the low bits of rowptr).  Lanes past the panel width carry an out-of-range voffset.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_coff(const int* __restrict__ rptr, const int* __restrict__ rcol, int N, u32 ldb,
+                       u32* __restrict__ coff) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int j = rptr[i] & ~3; j < (rptr[i + 1] & ~3); ++j) {
+    const int c = rcol[j];
+    coff[j] = (c == N) ? 0xFFFFFFFFu : (u32)c * ldb;
+  }
+}
+
+template <typename T, int VEC> struct VS {  // buffer load with a scalar byte offset
+  typedef VT<T, VEC> X;
+  typedef typename X::t V;
+  static __device__ __forceinline__ V ld(rsrc_t r, u32 voff, u32 soff) {
+    if constexpr (sizeof(V) == 4)
+      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    else if constexpr (sizeof(V) == 8)
+      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    else
+      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  }
+};
+
+template <typename T, int VEC, bool FLUSH>
+__global__ __launch_bounds__(256) void k_step_wrow(const int* __restrict__ rowptr,
+                                                   const u32* __restrict__ coff,
+                                                   const T* __restrict__ val,
+                                                   const T* __restrict__ cur,
+                                                   const T* __restrict__ wts,
+                                                   const int* __restrict__ perm,
+                                                   const StepArgs<T> a) {
+  typedef VT<T, VEC> X;
+  typedef typename X::t V;
+  typedef VS<T, VEC> S;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  int chunk = blockIdx.x;
+  if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);  // contiguous row range per XCD
+  if (chunk >= a.nchunks) return;
+
+  const u32 colel = (blockIdx.y * 64 + lane) * VEC;
+  const bool lane_on = colel < a.ld;
+  const u32 ldb = a.ld * (u32)sizeof(T);
+  const u32 voff = lane_on ? colel * (u32)sizeof(T) : GSPX_POISON;
+  const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cur, 0, a.curbytes, 0x00020000);
+  const rsrc_t rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
+  const rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
+  const rsrc_t rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
+
+  const int row0 = (chunk * 4 + wave) * a.rows_per_wave;
+#pragma unroll 1
+  for (int i = 0; i < a.rows_per_wave; ++i) {
+    const int row = __builtin_amdgcn_readfirstlane(row0 + i);
+    if (row >= a.N) break;
+    const int rp0 = rowptr[row], rp1 = rowptr[row + 1];
+    const int s = rp0 & ~3;
+    const int npad = rp0 & 3;
+    const int nfull = (((rp1 & ~3) - s) >> 2) - 1;  // chunks whose 4 entries are all real
+    const u32* cp = coff + s;
+    const T* vp = val + s;
+    const u32 rowoff = (u32)row * ldb;
+
+    V acc = 0;
+#pragma unroll 2
+    for (int k = 0; k < nfull; ++k) {
+      u32 co[4];
+      T vv[4];
+      V x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        co[u] = cp[4 * k + u];
+        vv[u] = vp[4 * k + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = S::ld(rc, voff, co[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += vv[u] * x[u];
+    }
+    // closing chunk: 4 - npad real entries (at least one: every row owns a diagonal slot)
+    {
+      u32 co[4];
+      T vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        co[u] = cp[4 * nfull + u];
+        vv[u] = vp[4 * nfull + u];
+      }
+      // pin the four offsets in SGPRs here: otherwise the loads are sunk into the conditionals
+      // below and issued one dword at a time, each behind its own wait
+      asm volatile("" : "+s"(co[0]), "+s"(co[1]), "+s"(co[2]), "+s"(co[3]));
+      V x0 = S::ld(rc, voff, co[0]);
+      V x1 = 0, x2 = 0, x3 = 0;
+      if (npad < 3) x1 = S::ld(rc, voff, co[1]);
+      if (npad < 2) x2 = S::ld(rc, voff, co[2]);
+      if (npad < 1) x3 = S::ld(rc, voff, co[3]);
+      // streaming reads of this row, issued after (= younger than) its gathers
+      const V ov = S::ld(rold, voff, rowoff);
+      V curv = 0, ra = 0;
+      if constexpr (FLUSH) {
+        curv = S::ld(rc, voff, rowoff);
+        ra = S::ld(rra, voff, rowoff);
+      }
+      acc += vv[0] * x0;
+      acc += vv[1] * x1;  // pad values are 0
+      acc += vv[2] * x2;
+      acc += vv[3] * x3;
+
+      V nv = a.scale * acc;
+      nv += a.gamma * ov;  // gamma == 0: the host points `old` at `cur`, the product vanishes
+      X::bstore(rout, voff + rowoff, nv);  // lanes past the panel: POISON + rowoff stays out of range
+      if constexpr (FLUSH) {
+        if (lane_on) {
+          const size_t o = (size_t)row * a.ld + colel;
+          size_t orow = (size_t)row;
+          if (a.final && perm) orow = (size_t)perm[row];
+          const size_t plane_r = (size_t)a.N * a.ld;
+          const size_t plane_y = (size_t)a.N * a.ldy;
+          for (int f = 0; f < a.nf; ++f) {
+            const T wn = wts[3 * f + 0], wc = wts[3 * f + 1], wo = wts[3 * f + 2];
+            V res = wn * nv + wc * curv + wo * ov;
+            if (a.flush == 2) res += (f == 0) ? ra : *(const V*)(a.racc + f * plane_r + o);
+            if (a.final)
+              *(V*)(a.y + f * plane_y + orow * a.ldy + colel) = res;
+            else
+              *(V*)(a.racc + f * plane_r + o) = res;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NARROW kernel (1..4 signals): several rows per wave; W lanes span the signals, G lanes split a
 // row's entries (per-lane vector loads of col/val, coalesced because a wave's rows are
 // consecutive in the padded CSR), xor-shuffle reduction across the G lanes.
@@ -428,8 +578,8 @@ __global__ __launch_bounds__(256) void k_step_narrow(const StepArgs<T> a, const 
     const bool row_on = row < a.N;
     int s = 0, e = 0;
     if (row_on) {
-      s = a.rowptr[row];
-      e = a.rowptr[row + 1];
+      s = a.rowptr[row] & ~3;  // low 2 bits carry the row's pad count
+      e = a.rowptr[row + 1] & ~3;
     }
     T acc = 0;
     for (int j = s + g; j < e; j += 2 * G) {
@@ -622,7 +772,7 @@ template <typename T, bool FILL>
 __global__ void k_internal_build(const int* __restrict__ lptr, const int* __restrict__ lcol,
                                  const T* __restrict__ lval, int N,
                                  const int* __restrict__ perm, const int* __restrict__ iperm,
-                                 int* __restrict__ cnt, const int* __restrict__ rptr,
+                                 int* __restrict__ cnt, int* __restrict__ rptr,
                                  int* __restrict__ rcol, T* __restrict__ rval) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // internal row
   if (i >= N) return;
@@ -637,7 +787,8 @@ __global__ void k_internal_build(const int* __restrict__ lptr, const int* __rest
     cnt[i] = npad;
     return;
   }
-  const int o = rptr[i];
+  const int o = rptr[i];  // multiple of 4 (every row length is)
+  rptr[i] = o | (npad - n);  // low 2 bits: number of pad entries closing this row
   int m = 0;
   for (int j = s; j < e; ++j) {
     rcol[o + m] = iperm ? iperm[lcol[j]] : lcol[j];
@@ -677,7 +828,7 @@ __global__ void k_factor(const int* __restrict__ rptr, const int* __restrict__ r
                          T* __restrict__ fval) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  for (int j = rptr[i]; j < rptr[i + 1]; ++j) {
+  for (int j = rptr[i] & ~3; j < (rptr[i + 1] & ~3); ++j) {
     const int c = rcol[j];
     T v = rval[j];
     if (c == i) v -= a2;

@@ -320,14 +320,17 @@ def test_kernel_variants_agree(ctx, dtype):
     dev = engine.DeviceGraph.from_w(W, dtype=dtype, ctx=ctx)
     tol = TOL[np.dtype(dtype)]
     try:
-        for vec in (0, 1, 2, 4):
-            for rpw in (1, 2, 4, 32):
-                for remap in (0, 1):
-                    ctx.set_option("vec", vec)
-                    ctx.set_option("rows_per_wave", rpw)
-                    ctx.set_option("xcd_remap", remap)
-                    y, _ = dev.cheby_filter(c, x, lmax)
-                    assert rel_err(y[0], ref) < tol, (vec, rpw, remap)
+        for kern in (1, 3):  # lane-group panel kernel, wave-row kernel
+            ctx.set_option("kernel", kern)
+            for vec in (0, 1, 2, 4):
+                for rpw in (1, 2, 4, 32):
+                    for remap in (0, 1):
+                        ctx.set_option("vec", vec)
+                        ctx.set_option("rows_per_wave", rpw)
+                        ctx.set_option("xcd_remap", remap)
+                        y, _ = dev.cheby_filter(c, x, lmax)
+                        assert rel_err(y[0], ref) < tol, (kern, vec, rpw, remap)
+        ctx.set_option("kernel", 0)
         ctx.set_option("vec", 0)
         ctx.set_option("rows_per_wave", 4)
         ctx.set_option("xcd_remap", 1)

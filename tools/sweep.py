@@ -62,19 +62,23 @@ def main():
             vecs = (1, 2) if elt == 8 else (1, 2, 4)
             rpws = (1, 2, 4, 8) if not a.quick else (4,)
             remaps = (1, 0) if reorder == "morton" else (1,)
-            for vec, rpw, remap in itertools.product(vecs, rpws, remaps):
+            kerns = (3, 1)
+            for kern, vec, rpw, remap in itertools.product(kerns, vecs, rpws, remaps):
+                if kern == 1 and (rpw not in (4,) or vec == 1):
+                    continue
+                ctx.set_option("kernel", kern)
                 ctx.set_option("vec", vec)
                 ctx.set_option("rows_per_wave", rpw)
                 ctx.set_option("xcd_remap", remap)
                 per, t = measure(dev, ctx, c, bx, by, a.nsig, lmax)
-                run = {"dtype": np.dtype(dtype).name, "reorder": reorder, "vec": vec, "rpw": rpw,
+                run = {"dtype": np.dtype(dtype).name, "reorder": reorder, "kernel": kern, "vec": vec, "rpw": rpw,
                        "xcd_remap": remap, "ms_per_launch": per, "GBps_alg": b_launch / per / 1e6,
                        "total_ms": t["total_ms"], "permute_ms": t["permute_ms"],
                        "build_s": build_s, "nnz_l": dev.nnz_l, "nnz_int": dev.nnz_internal}
                 res["runs"].append(run)
                 print(json.dumps(run), flush=True)
                 json.dump(res, open(a.out, "w"), indent=1)
-            for key, val in (("vec", 0), ("rows_per_wave", 4), ("xcd_remap", 1)):
+            for key, val in (("vec", 0), ("rows_per_wave", 4), ("xcd_remap", 1), ("kernel", 0)):
                 ctx.set_option(key, val)
             bx.free(); by.free(); dev.destroy()
     json.dump(res, open(a.out, "w"), indent=1)
