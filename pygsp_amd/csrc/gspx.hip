@@ -730,11 +730,11 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
   if (opt.kernel == 1 && ld > 4) kernel = 1;
   // wave-row kernel: one row per wave, all 64 lanes on its signals.  Auto when the panel fills
   // more than half a wave at one element per lane.
-  if (opt.kernel == 3 || (opt.kernel == 0 && ld > 32)) {
+  if (opt.kernel == 3 || opt.kernel == 4 || (opt.kernel == 0 && ld > 32)) {
     int v = 1;
     while (v < maxvec && ld % (2 * v) == 0 && ld / v > 64) v *= 2;
     if (opt.vec != 0 && opt.vec <= maxvec && ld % opt.vec == 0) v = (int)opt.vec;
-    s.kernel = 3;
+    s.kernel = opt.kernel == 4 ? 4 : 3;
     s.vec = v;
     s.wlog2 = 6;
     s.glog2 = 0;
@@ -784,9 +784,15 @@ static void launch_panel(const StepArgs<T>& a, const Shape& s, dim3 grid, hipStr
 template <typename T, bool FLUSH>
 static void launch_wrow(const StepArgs<T>& a, const unsigned* coff, const Shape& s, dim3 grid,
                         hipStream_t st) {
-#define GSPX_LW(V)                                                                            \
-  hipLaunchKernelGGL((k_step_wrow<T, V, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff, a.val, \
-                     a.cur, a.wts, a.perm, a)
+#define GSPX_LW(V)                                                                              \
+  do {                                                                                          \
+    if (s.kernel == 4)                                                                          \
+      hipLaunchKernelGGL((k_step_wrow2<T, V, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff,   \
+                         a.val, a.cur, a.wts, a.perm, a);                                       \
+    else                                                                                        \
+      hipLaunchKernelGGL((k_step_wrow<T, V, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff,    \
+                         a.val, a.cur, a.wts, a.perm, a);                                       \
+  } while (0)
   if constexpr (sizeof(T) == 4) {
     if (s.vec == 4) { GSPX_LW(4); return; }
   }
@@ -805,7 +811,9 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
   }
   a.rows_per_wave = rpw;
   int rows_per_chunk;
-  if (s.kernel == 1 || s.kernel == 3)
+  if (s.kernel == 4 && rpw > 32) rpw = 32;
+  a.rows_per_wave = rpw;
+  if (s.kernel == 1 || s.kernel >= 3)
     rows_per_chunk = 4 * rpw;
   else
     rows_per_chunk = rpw * (4 << (6 - s.wlog2 - s.glog2));
@@ -817,7 +825,7 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
     gx = a.cpx * 8;
   }
   dim3 grid((unsigned)gx, (unsigned)s.gridy, 1);
-  if (s.kernel == 3) {
+  if (s.kernel >= 3) {
     if (a.flush) launch_wrow<T, true>(a, coff, s, grid, st);
     else launch_wrow<T, false>(a, coff, s, grid, st);
   } else if (s.kernel == 1) {
@@ -964,7 +972,7 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   launch_permute_in<T>(x, ldx, slots, ld, N, perm, pvec, st);
   HIPCHK(hipEventRecord(e1, st));
 
-  if (shape.kernel == 3 && g->coff_ldb != ld * (unsigned)sizeof(T)) {
+  if (shape.kernel >= 3 && g->coff_ldb != ld * (unsigned)sizeof(T)) {
     // byte offsets col*ld*sizeof(T) for this panel width (cached on the graph)
     CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
     const int nb = std::max(1, (N + 255) / 256);

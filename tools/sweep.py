@@ -60,11 +60,15 @@ def main():
             csr = dev.nnz_l * (elt + 4) + 4 * (a.n + 1)
             b_launch = (a.order * (csr + 3 * U) + U) / a.order
             vecs = (1, 2) if elt == 8 else (1, 2, 4)
-            rpws = (1, 2, 4, 8) if not a.quick else (4,)
+            rpws = (2, 4, 8, 16, 32) if not a.quick else (4,)
             remaps = (1, 0) if reorder == "morton" else (1,)
-            kerns = (3, 1)
+            kerns = (4, 3, 1)
             for kern, vec, rpw, remap in itertools.product(kerns, vecs, rpws, remaps):
                 if kern == 1 and (rpw not in (4,) or vec == 1):
+                    continue
+                if kern in (3, 4) and (vec != 1 or remap == 1):
+                    continue
+                if kern == 3 and rpw not in (4, 8):
                     continue
                 ctx.set_option("kernel", kern)
                 ctx.set_option("vec", vec)
