@@ -136,6 +136,7 @@ struct gspx_graph {
   int64_t nnz_int = 0;
   DevMem rptr, rcol, rval, fval, coff;
   unsigned coff_ldb = 0;  // panel row bytes the cached byte offsets were built for
+  int coff_pad_self = -1;
   DevMem perm, iperm;
   bool has_perm = false;
   double fval_lmax = -1.0;
@@ -741,8 +742,9 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
     s.gridy = (int)((ld / v + 63) / 64);
     return s;
   }
+  if (opt.kernel == 5 && ld > 4) kernel = 5;
   s.kernel = kernel;
-  if (kernel == 1) {
+  if (kernel == 1 || kernel == 5) {
     s.vec = vec;
     const int64_t lanes = ld / vec;
     s.wlog2 = lanes <= 16 ? 4 : (lanes <= 32 ? 5 : 6);
@@ -781,6 +783,30 @@ static void launch_panel(const StepArgs<T>& a, const Shape& s, dim3 grid, hipStr
   return launch_panel_w<T, 1, FLUSH>(a, s.wlog2, grid, st);
 }
 
+template <typename T, int VEC, bool FLUSH>
+static void launch_lds_w(const StepArgs<T>& a, const unsigned* coff, int wlog2, dim3 grid,
+                         hipStream_t st) {
+#define GSPX_LL(WL)                                                                           \
+  hipLaunchKernelGGL((k_step_lds<T, VEC, WL, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff, \
+                     a.val, a.cur, a.wts, a.perm, a)
+  switch (wlog2) {
+    case 4: GSPX_LL(4); break;
+    case 5: GSPX_LL(5); break;
+    default: GSPX_LL(6); break;
+  }
+#undef GSPX_LL
+}
+
+template <typename T, bool FLUSH>
+static void launch_lds(const StepArgs<T>& a, const unsigned* coff, const Shape& s, dim3 grid,
+                       hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    if (s.vec == 4) return launch_lds_w<T, 4, FLUSH>(a, coff, s.wlog2, grid, st);
+  }
+  if (s.vec == 2) return launch_lds_w<T, 2, FLUSH>(a, coff, s.wlog2, grid, st);
+  return launch_lds_w<T, 1, FLUSH>(a, coff, s.wlog2, grid, st);
+}
+
 template <typename T, bool FLUSH>
 static void launch_wrow(const StepArgs<T>& a, const unsigned* coff, const Shape& s, dim3 grid,
                         hipStream_t st) {
@@ -805,9 +831,10 @@ template <typename T>
 static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st,
                         const unsigned* coff) {
   int rpw = (int)opt.rows_per_wave;
-  if (s.kernel == 1) {
+  if (s.kernel == 1 || s.kernel == 5) {
     const int R = 64 >> s.wlog2;  // rows per row set
     rpw = ((rpw + R - 1) / R) * R;
+    if (s.kernel == 5 && rpw > 32) rpw = 32;
   }
   a.rows_per_wave = rpw;
   int rows_per_chunk;
@@ -825,7 +852,10 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
     gx = a.cpx * 8;
   }
   dim3 grid((unsigned)gx, (unsigned)s.gridy, 1);
-  if (s.kernel >= 3) {
+  if (s.kernel == 5) {
+    if (a.flush) launch_lds<T, true>(a, coff, s, grid, st);
+    else launch_lds<T, false>(a, coff, s, grid, st);
+  } else if (s.kernel >= 3) {
     if (a.flush) launch_wrow<T, true>(a, coff, s, grid, st);
     else launch_wrow<T, false>(a, coff, s, grid, st);
   } else if (s.kernel == 1) {
@@ -972,13 +1002,17 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   launch_permute_in<T>(x, ldx, slots, ld, N, perm, pvec, st);
   HIPCHK(hipEventRecord(e1, st));
 
-  if (shape.kernel >= 3 && g->coff_ldb != ld * (unsigned)sizeof(T)) {
+  const int pad_self = (shape.kernel == 3 || shape.kernel == 4) ? 1 : 0;
+  if (shape.kernel >= 3 &&
+      (g->coff_ldb != ld * (unsigned)sizeof(T) || g->coff_pad_self != pad_self)) {
     // byte offsets col*ld*sizeof(T) for this panel width (cached on the graph)
     CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
     const int nb = std::max(1, (N + 255) / 256);
     hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
-                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), g->coff.as<unsigned>());
+                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), pad_self,
+                       g->coff.as<unsigned>());
     g->coff_ldb = ld * (unsigned)sizeof(T);
+    g->coff_pad_self = pad_self;
   }
   StepArgs<T> a{};
   a.rowptr = g->rptr.as<int>();

@@ -410,15 +410,17 @@ __global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowp
 // Pads never reach the memory pipeline: the last chunk issues only its real entries (pad count
 // in the low bits of rowptr).  Lanes past the panel width carry an out-of-range voffset.
 // ---------------------------------------------------------------------------------------------
-// pads get the offset of their own row: a dummy (L1-resident) gather, value 0
+// byte offsets col*ldb.  Pads: `pad_self` = offset of the row itself (a dummy, L1-resident gather
+// for kernels that pass the offset as the unchecked soffset), else 0x80000000 (fails the bounds
+// check once the lane offset is added: no traffic).
 template <typename T>
 __global__ void k_coff(const int* __restrict__ rptr, const int* __restrict__ rcol, int N, u32 ldb,
-                       u32* __restrict__ coff) {
+                       int pad_self, u32* __restrict__ coff) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   for (int j = rptr[i] & ~3; j < (rptr[i + 1] & ~3); ++j) {
     const int c = rcol[j];
-    coff[j] = (u32)(c == N ? i : c) * ldb;
+    coff[j] = (c == N) ? (pad_self ? (u32)i * ldb : GSPX_POISON) : (u32)c * ldb;
   }
 }
 
@@ -710,6 +712,226 @@ __global__ __launch_bounds__(256) void k_step_wrow2(const int* __restrict__ rowp
     wrow_body<T, VEC, FLUSH>(c, a, i, cA, cB, ovA, raA, ovB, raB);
     if (i + 1 >= c.nrows) break;
     wrow_body<T, VEC, FLUSH>(c, a, i + 1, cB, cA, ovB, raB, ovA, raA);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-STAGED panel kernel.  Measured on MI355X (profiles/): the gather pipeline moves ~80 B/clk/CU
+// with 16-byte-per-lane loads but only ~40 with 4-8-byte ones, and a wave that fetches its row
+// metadata through dependent global round trips spends ~6 us per row.  So:
+//   * lanes: W = 2^WLOG2 lanes x 16 bytes span one row, R = 64/W rows of a "row set" share every
+//     gather instruction (1 KiB per instruction);
+//   * the CSR slice of ALL rows of a wave (byte offsets + factor values, contiguous because the
+//     rows are consecutive) is copied once, coalesced, into a wave-private LDS region; lane group r
+//     then reads its row's 4-entry chunk with ds_read_b128 (broadcast inside the group) - no
+//     scalar loads, no cross-lane blends, no per-row rowptr fetch (the wave's rowptr block sits in
+//     one VGPR and is read with ds_bpermute / v_readlane);
+//   * per stored entry the wave issues 1/R gather + (1 + VEC)/R VALU instructions;
+//   * pads carry offset 0x80000000: with the lane offset added they fail the descriptor's bounds
+//     check and cost no memory traffic.
+// ---------------------------------------------------------------------------------------------
+#define GSPX_LDS_CAP 512  // CSR entries staged per wave
+
+template <typename T, int VEC> struct LdsCtx {
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  const u32x4* s_coff;  // this wave's LDS slice (offsets)
+  const T4* s_val;      // this wave's LDS slice (values)
+  const u32* __restrict__ coff;
+  const T* __restrict__ val;
+  const T* __restrict__ wts;
+  const int* __restrict__ perm;
+  rsrc_t rc, rold, rout, rra;
+  u32 ldb, lane_off, colel;
+  int r, row0, nsets, v_rp, seg_s;
+  bool lane_on;
+};
+
+// One row set.  ov_use/ra_use were requested by the previous set, ov_pf/ra_pf receive the request
+// for the next one (the caller alternates two register pairs: no copy, hence no wait, at the top).
+template <typename T, int VEC, int R, bool FLUSH, bool STAGED>
+__device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepArgs<T>& a, const int j,
+                                            const typename VT<T, VEC>::t& ov_use,
+                                            const typename VT<T, VEC>::t& ra_use,
+                                            typename VT<T, VEC>::t& ov_pf,
+                                            typename VT<T, VEC>::t& ra_pf) {
+  typedef VT<T, VEC> X;
+  typedef typename X::t V;
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  const int srow = c.row0 + j * R;
+  const int myrow = srow + c.r;
+  const bool row_on = myrow < a.N && c.lane_on;
+  // this lane group's row bounds, and the set's longest row (wave-uniform loop bound)
+  const int my0 = __shfl(c.v_rp, j * R + c.r) & ~3;
+  const int my1 = __shfl(c.v_rp, j * R + c.r + 1) & ~3;
+  const int my_nch = (my1 - my0) >> 2;
+  int nmax = 0;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int n = ((__builtin_amdgcn_readlane(c.v_rp, j * R + q + 1) & ~3) -
+                   (__builtin_amdgcn_readlane(c.v_rp, j * R + q) & ~3)) >> 2;
+    nmax = n > nmax ? n : nmax;
+  }
+  const int my_q = (my0 - c.seg_s) >> 2;  // first chunk of my row inside the staged slice
+
+  // Consume the previous set's streaming request HERE (it is a whole set old): the wait sits at
+  // the top of the set, and nothing below depends on a T_{k-2} load any more - otherwise the
+  // compiler guards the epilogue with vmcnt(0), which would also wait for the request issued
+  // for the NEXT set.
+  V acc = a.gamma * ov_use;  // gamma == 0: the host points `old` at `cur`, the product vanishes
+  V rbase = 0;
+  if constexpr (FLUSH) {
+    rbase = c.wts[2] * ov_use;  // w_old of filter 0 (the common single-filter case)
+    if (a.flush == 2) rbase += ra_use;
+  }
+  asm volatile("" : "+v"(acc), "+v"(rbase));
+  V sum = 0;
+  V curv = 0;
+  if constexpr (FLUSH) curv = X::bload(c.rc, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON);
+
+  // the streaming request for the next set, valid only on the last pass (else out of range)
+  const int nrow = myrow + R;
+  const bool pf_on = (j + 1 < c.nsets) && nrow < a.N;
+  const u32 pf_off = pf_on ? (u32)nrow * c.ldb + c.lane_off : GSPX_POISON;
+
+  for (int k = 0; k < nmax; k += 2) {
+    // two chunks (8 entries) per pass: offsets from LDS, 8 gathers in flight, then the values
+    const bool on0 = k < my_nch, on1 = k + 1 < my_nch;
+    u32x4 c0, c1;
+    if constexpr (STAGED) {
+      c0 = c.s_coff[on0 ? my_q + k : 0];
+      c1 = c.s_coff[on1 ? my_q + k + 1 : 0];
+    } else {
+      c0 = *(const u32x4*)(c.coff + my0 + 4 * (on0 ? k : 0));
+      c1 = *(const u32x4*)(c.coff + my0 + 4 * (on1 ? k + 1 : 0));
+    }
+    const u32 p0 = on0 ? c.lane_off : GSPX_POISON, p1 = on1 ? c.lane_off : GSPX_POISON;
+    const V x0 = X::bload(c.rc, c0.x + p0), x1 = X::bload(c.rc, c0.y + p0);
+    const V x2 = X::bload(c.rc, c0.z + p0), x3 = X::bload(c.rc, c0.w + p0);
+    const V x4 = X::bload(c.rc, c1.x + p1), x5 = X::bload(c.rc, c1.y + p1);
+    const V x6 = X::bload(c.rc, c1.z + p1), x7 = X::bload(c.rc, c1.w + p1);
+    // (unconditional: a pass that is not the last one asks for an out-of-range address, which
+    // costs an issue slot but no memory traffic and keeps the vmcnt bookkeeping exact)
+    const u32 po = (k + 2 >= nmax) ? pf_off : GSPX_POISON;
+    __builtin_amdgcn_sched_barrier(0);  // gathers first: the streaming request must be younger
+    ov_pf = X::bload(c.rold, po);
+    if constexpr (FLUSH) ra_pf = X::bload(c.rra, po);
+    __builtin_amdgcn_sched_barrier(0);  // the requests above stay above the waits below
+    T4 v0, v1;
+    if constexpr (STAGED) {
+      v0 = c.s_val[on0 ? my_q + k : 0];
+      v1 = c.s_val[on1 ? my_q + k + 1 : 0];
+    } else {
+      v0 = *(const T4*)(c.val + my0 + 4 * (on0 ? k : 0));
+      v1 = *(const T4*)(c.val + my0 + 4 * (on1 ? k + 1 : 0));
+    }
+    sum += v0.x * x0; sum += v0.y * x1; sum += v0.z * x2; sum += v0.w * x3;
+    sum += v1.x * x4; sum += v1.y * x5; sum += v1.z * x6; sum += v1.w * x7;
+  }
+
+  const V nv = a.scale * sum + acc;
+  X::bstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
+  if constexpr (FLUSH) {
+    if (row_on) {
+      const size_t o = (size_t)myrow * a.ld + c.colel;
+      size_t orow = (size_t)myrow;
+      if (a.final && c.perm) orow = (size_t)c.perm[myrow];
+      const size_t plane_r = (size_t)a.N * a.ld;
+      const size_t plane_y = (size_t)a.N * a.ldy;
+      for (int f = 0; f < a.nf; ++f) {
+        const T wn = c.wts[3 * f + 0], wc = c.wts[3 * f + 1], wo = c.wts[3 * f + 2];
+        V res = wn * nv + wc * curv;
+        if (f == 0) {
+          res += rbase;
+        } else {
+          res += wo * ov_use;
+          if (a.flush == 2) res += *(const V*)(a.racc + f * plane_r + o);
+        }
+        if (a.final)
+          *(V*)(a.y + f * plane_y + orow * a.ldy + c.colel) = res;
+        else
+          *(V*)(a.racc + f * plane_r + o) = res;
+      }
+    }
+  }
+}
+
+template <typename T, int VEC, int R, bool FLUSH, bool STAGED>
+__device__ __forceinline__ void lds_run_sets(const LdsCtx<T, VEC>& c, const StepArgs<T>& a) {
+  typedef VT<T, VEC> X;
+  typedef typename X::t V;
+  V ovA, raA = 0, ovB = 0, raB = 0;
+  {
+    const int myrow = c.row0 + c.r;
+    const u32 po = myrow < a.N ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON;
+    ovA = X::bload(c.rold, po);
+    if constexpr (FLUSH) raA = X::bload(c.rra, po);
+  }
+#pragma unroll 1
+  for (int j = 0; j < c.nsets; j += 2) {
+    if (c.row0 + j * R >= a.N) break;
+    lds_row_set<T, VEC, R, FLUSH, STAGED>(c, a, j, ovA, raA, ovB, raB);
+    if (j + 1 >= c.nsets || c.row0 + (j + 1) * R >= a.N) break;
+    lds_row_set<T, VEC, R, FLUSH, STAGED>(c, a, j + 1, ovB, raB, ovA, raA);
+  }
+}
+
+template <typename T, int VEC, int WLOG2, bool FLUSH>
+__global__ __launch_bounds__(256) void k_step_lds(const int* __restrict__ rowptr,
+                                                  const u32* __restrict__ coff,
+                                                  const T* __restrict__ val,
+                                                  const T* __restrict__ cur,
+                                                  const T* __restrict__ wts,
+                                                  const int* __restrict__ perm,
+                                                  const StepArgs<T> a) {
+  constexpr int W = 1 << WLOG2;
+  constexpr int R = 64 / W;
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  __shared__ u32x4 s_coff[4][GSPX_LDS_CAP / 4];
+  __shared__ T4 s_val[4][GSPX_LDS_CAP / 4];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = lane & (W - 1);
+
+  int chunk = blockIdx.x;
+  if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);
+  if (chunk >= a.nchunks) return;
+
+  LdsCtx<T, VEC> c;
+  c.s_coff = s_coff[wave];
+  c.s_val = s_val[wave];
+  c.coff = coff;
+  c.val = val;
+  c.wts = wts;
+  c.perm = perm;
+  c.r = lane >> WLOG2;
+  c.colel = (blockIdx.y * W + w) * VEC;
+  c.lane_on = c.colel < a.ld;
+  c.ldb = a.ld * (u32)sizeof(T);
+  c.lane_off = c.lane_on ? c.colel * (u32)sizeof(T) : GSPX_POISON;
+  c.rc = __builtin_amdgcn_make_buffer_rsrc((void*)cur, 0, a.curbytes, 0x00020000);
+  c.rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
+  c.rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
+  c.rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
+  c.row0 = (chunk * 4 + wave) * a.rows_per_wave;
+  if (c.row0 >= a.N) return;
+  c.nsets = a.rows_per_wave / R;  // rows_per_wave is a multiple of R, at most 32
+
+  // rowptr block of this wave: lane l holds rowptr[row0 + l] (rowptr is padded past N)
+  c.v_rp = rowptr[(c.row0 + lane) < a.N ? (c.row0 + lane) : a.N];
+  c.seg_s = __builtin_amdgcn_readfirstlane(c.v_rp) & ~3;
+  const int seg_e = __builtin_amdgcn_readlane(c.v_rp, a.rows_per_wave) & ~3;
+  const int seg_n = seg_e - c.seg_s;  // stored entries of the wave's rows (multiple of 4)
+
+  if (seg_n <= GSPX_LDS_CAP) {
+    // stage offsets + values: lane l copies chunks l, l + 64 (coalesced 16/32-byte loads)
+    for (int q = lane; q * 4 < seg_n; q += 64) {
+      s_coff[wave][q] = *(const u32x4*)(coff + c.seg_s + 4 * q);
+      s_val[wave][q] = *(const T4*)(val + c.seg_s + 4 * q);
+    }
+    lds_run_sets<T, VEC, R, FLUSH, true>(c, a);
+  } else {
+    lds_run_sets<T, VEC, R, FLUSH, false>(c, a);  // very long rows: metadata straight from L2
   }
 }
 

@@ -320,7 +320,7 @@ def test_kernel_variants_agree(ctx, dtype):
     dev = engine.DeviceGraph.from_w(W, dtype=dtype, ctx=ctx)
     tol = TOL[np.dtype(dtype)]
     try:
-        for kern in (1, 3, 4):  # lane-group panel, wave-row, pipelined wave-row
+        for kern in (1, 3, 4, 5):  # lane-group panel, wave-row, pipelined wave-row, LDS-staged
             ctx.set_option("kernel", kern)
             for vec in (0, 1, 2, 4):
                 for rpw in (1, 2, 4, 32):
