@@ -63,7 +63,7 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "kernel"      0 auto, 1 panel (lane groups own rows), 2 narrow (sub-wave rows), 3 wave-row
  *                 (one row per wave, all metadata scalar)
  *   "vec"         0 auto, else elements per lane (1,2,4)
- *   "rows_per_wave"  panel kernel: consecutive rows per wave (default 4)
+ *   "rows_per_wave"  consecutive rows per wave (0 = auto)
  *   "narrow_g_log2"  narrow kernel: log2 of lanes splitting one row's entries
  *   "xcd_remap"   1 (default) contiguous row ranges per XCD, 0 plain order
  *   "combine"     0 auto, 1 fused flush every 3rd step, 2 deferred combine (keep all T_k)

@@ -95,7 +95,7 @@ struct DevMem {
 struct Options {
   int64_t kernel = 0;         // 0 auto, 1 panel, 2 narrow
   int64_t vec = 0;            // 0 auto
-  int64_t rows_per_wave = 4;
+  int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
   int64_t narrow_g_log2 = 2;
   int64_t xcd_remap = 1;
   int64_t combine = 0;        // 0 auto, 1 fused flush, 2 deferred
@@ -232,8 +232,8 @@ extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value
   if (!ctx) return set_err(GSPX_ERR_INVALID, "null ctx");
   int64_t* s = option_slot(ctx->opt, key);
   if (!s) return set_err(GSPX_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
-  if (!strcmp(key, "rows_per_wave") && (value < 1 || value > 1024))
-    return set_err(GSPX_ERR_INVALID, "rows_per_wave must be in [1, 1024]");
+  if (!strcmp(key, "rows_per_wave") && (value < 0 || value > 1024))
+    return set_err(GSPX_ERR_INVALID, "rows_per_wave must be in [0, 1024] (0 = auto)");
   if (!strcmp(key, "narrow_g_log2") && (value < 0 || value > 6))
     return set_err(GSPX_ERR_INVALID, "narrow_g_log2 must be in [0, 6]");
   if (!strcmp(key, "vec") && !(value == 0 || value == 1 || value == 2 || value == 4))
@@ -729,9 +729,9 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
   int kernel = (ld <= 4) ? 2 : 1;
   if (opt.kernel == 2 && ld <= 64) kernel = 2;
   if (opt.kernel == 1 && ld > 4) kernel = 1;
-  // wave-row kernel: one row per wave, all 64 lanes on its signals.  Auto when the panel fills
-  // more than half a wave at one element per lane.
-  if (opt.kernel == 3 || opt.kernel == 4 || (opt.kernel == 0 && ld > 32)) {
+  // wave-row kernels (one row per wave, all 64 lanes on its signals): explicit choice only.
+  // Measured on MI355X (profiles/): the lane-group kernels with 16-byte gathers win.
+  if (opt.kernel == 3 || opt.kernel == 4) {
     int v = 1;
     while (v < maxvec && ld % (2 * v) == 0 && ld / v > 64) v *= 2;
     if (opt.vec != 0 && opt.vec <= maxvec && ld % opt.vec == 0) v = (int)opt.vec;
@@ -743,6 +743,9 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
     return s;
   }
   if (opt.kernel == 5 && ld > 4) kernel = 5;
+  // auto: fp32 panels -> LDS-staged kernel, fp64 panels -> scalar-metadata lane-group kernel
+  // (equal within 2 % in fp64, the LDS kernel is 25 % faster in fp32)
+  if (opt.kernel == 0 && kernel == 1 && elt == 4) kernel = 5;
   s.kernel = kernel;
   if (kernel == 1 || kernel == 5) {
     s.vec = vec;
@@ -831,6 +834,7 @@ template <typename T>
 static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st,
                         const unsigned* coff) {
   int rpw = (int)opt.rows_per_wave;
+  if (rpw <= 0) rpw = (s.kernel == 5) ? (sizeof(T) == 4 ? 16 : 8) : (s.kernel == 4 ? 8 : 4);
   if (s.kernel == 1 || s.kernel == 5) {
     const int R = 64 >> s.wlog2;  // rows per row set
     rpw = ((rpw + R - 1) / R) * R;

@@ -23,7 +23,7 @@ BAR = {np.dtype(np.float64): 1e-5, np.dtype(np.float32): 1e-3}
 def ctx():
     c = engine.default_context(0)
     yield c
-    for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 4), ("xcd_remap", 1),
+    for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 0), ("xcd_remap", 1),
                      ("combine", 0), ("max_batch", 0), ("narrow_g_log2", 2)):
         c.set_option(key, val)
 
@@ -332,7 +332,7 @@ def test_kernel_variants_agree(ctx, dtype):
                         assert rel_err(y[0], ref) < tol, (kern, vec, rpw, remap)
         ctx.set_option("kernel", 0)
         ctx.set_option("vec", 0)
-        ctx.set_option("rows_per_wave", 4)
+        ctx.set_option("rows_per_wave", 0)
         ctx.set_option("xcd_remap", 1)
         ctx.set_option("kernel", 2)  # narrow kernel forced on a wide panel
         for g in (0, 2, 3):
@@ -350,7 +350,7 @@ def test_kernel_variants_agree(ctx, dtype):
         y3, _ = dev.cheby_filter(c3, x, lmax)
         assert rel_err(y3, ref3) < tol
     finally:
-        for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 4), ("xcd_remap", 1),
+        for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 0), ("xcd_remap", 1),
                          ("max_batch", 0), ("narrow_g_log2", 2)):
             ctx.set_option(key, val)
         dev.destroy()

@@ -33,3 +33,42 @@ for f in find("pmc_*/**/*counter_collection.csv"):
             continue
         for cn, vals in cs.items():
             print("   {:60.60s} {:28s} n={:4d} mean={:.6g}".format(k, cn, len(vals), sum(vals) / len(vals)))
+
+# ---- HBM traffic per recurrence-step launch, for bench.py's roofline.traffic ---------------------
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, i.e. half
+# the bytes of a wide coalesced read (MI355X_MICROARCH.md section HBM; re-checked here on
+# k_permute_in, a pure copy).  Separate --pmc passes, as the guide prescribes.
+import json
+
+
+def per_kernel(counter):
+    res = {}
+    for f in find("pmc_%s/**/*counter_collection.csv" % counter):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            res.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return res
+
+
+fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
+tot_b, tot_n = 0.0, 0
+cal = None
+for k in fetch:
+    if k not in write:
+        continue
+    n = min(len(fetch[k]), len(write[k]))
+    b = (2.0 * sum(fetch[k][:n]) + sum(write[k][:n])) * 1024.0
+    if "k_step" in k:
+        tot_b += b
+        tot_n += n
+    if "k_permute_in" in k:
+        cal = {"fetch_KiB": fetch[k][0], "write_KiB": write[k][0]}
+if tot_n:
+    out_json = {"hbm_bytes_per_launch": tot_b / tot_n, "launches": tot_n,
+                "method": "(2*FETCH_SIZE + WRITE_SIZE) KiB per k_step_* dispatch, separate rocprofv3 --pmc passes",
+                "copy_kernel_calibration": cal}
+    print()
+    print("== traffic ==")
+    print(json.dumps(out_json))
+    json.dump(out_json, open(os.path.join(out, "traffic.json"), "w"))

@@ -84,7 +84,7 @@ def main():
                 res["runs"].append(run)
                 print(json.dumps(run), flush=True)
                 json.dump(res, open(a.out, "w"), indent=1)
-            for key, val in (("vec", 0), ("rows_per_wave", 4), ("xcd_remap", 1), ("kernel", 0)):
+            for key, val in (("vec", 0), ("rows_per_wave", 0), ("xcd_remap", 1), ("kernel", 0)):
                 ctx.set_option(key, val)
             bx.free(); by.free(); dev.destroy()
     json.dump(res, open(a.out, "w"), indent=1)
