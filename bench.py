@@ -54,8 +54,12 @@ def parse():
     p.add_argument("--cpu-cols", type=int, default=8, help="columns of the CPU-baseline sample")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-gather", action="store_true")
+    p.add_argument("--no-newton", action="store_true")
     p.add_argument("--opt", action="append", default=[], help="engine option key=value")
     p.add_argument("--reorder", default="auto")
+    p.add_argument("--evaluation", choices=["recurrence", "newton"], default="recurrence",
+                   help="recurrence = the reference's three-term Chebyshev recurrence (headline); "
+                        "newton = same polynomial, Newton form (extra line 'newton_form')")
     return p.parse_args()
 
 
@@ -110,8 +114,15 @@ def main():
         by = ctx.alloc(x.nbytes)
         y_ptr = by.ptr
 
-    def step():
+    nodes, dcoef = filters.cheb_to_newton(c[0])
+
+    def step_recurrence():
         return dev.cheby_filter_dev(c, bx.ptr, y_ptr, nsig, lmax)
+
+    def step_newton():
+        return dev.newton_filter_dev(nodes, dcoef, bx.ptr, y_ptr, nsig, lmax)
+
+    step = step_newton if a.evaluation == "newton" else step_recurrence
 
     def fence():
         ctx.sync()
@@ -136,6 +147,27 @@ def main():
         steps_ms_max = gdist.max_over_ranks(steps_ms, tdev)
     else:
         steps_ms_max = steps_ms
+
+    # ---- same polynomial in Newton form (extra, reported separately; not the headline) ----------
+    newton = None
+    if a.evaluation == "recurrence" and not a.no_newton:
+        for _ in range(a.warmup):
+            step_newton()
+        fence()
+        tn = time.perf_counter()
+        n_ms, n_launch = 0.0, 0
+        for _ in range(a.steps):
+            step_newton()
+            t = ctx.last_timing()
+            n_ms += t["steps_ms"]
+            n_launch += t["step_launches"]
+        fence()
+        n_elapsed = time.perf_counter() - tn
+        if torch is not None:
+            n_elapsed = gdist.max_over_ranks(n_elapsed, tdev)
+        newton = (n_elapsed, n_ms, n_launch)
+        step_recurrence()  # leave the headline result in y for the parity check below
+        fence()
 
     # ---- the path's one collective, outside the timed region: outputs -> rank 0 ----------------
     gather_ms = None
@@ -189,6 +221,7 @@ def main():
                 "n_edges": int(G.n_edges), "lmax": lmax, "lmax_method": "bounds",
                 "parallelism": "graph-parallel x{} (independent graphs, no data-path collective)".format(world),
                 "internal_order": "morton" if G._perm is not None else "none",
+                "evaluation": a.evaluation,
                 "engine_options": a.opt,
             },
             "roofline": {
@@ -199,6 +232,13 @@ def main():
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "avg_launch_ms": avg_launch_ms, "launches_timed": launches,
             },
+            "newton_form": None if newton is None else {
+                "note": "same interpolating polynomial in Newton form (two-term Horner recurrence, no "
+                        "accumulator): opt-in evaluation='newton'; parity-tested against the reference",
+                "value": world * N * nsig * K * a.steps / newton[0], "ms_per_step": newton[0] / a.steps * 1e3,
+                "avg_launch_ms": newton[1] / max(newton[2], 1),
+                "achieved_GBps_alg": b_alg_launch / (newton[1] / max(newton[2], 1) * 1e-3) / 1e9,
+                "frac_of_8TBps": b_alg_launch / (newton[1] / max(newton[2], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "device_ms_per_step": dev_ms / a.steps,
             "device_ms_recurrence_per_step": steps_ms_max / a.steps,
             "gather_ms": gather_ms,

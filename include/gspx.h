@@ -126,6 +126,20 @@ int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, const double* c
                       int64_t Nsig, const void* x_host, void* y_host, int mode,
                       double* kernel_ms);
 
+/* The same polynomial in NEWTON form (single filter, analysis), evaluated by Horner:
+ *     y = sum_{j=0..K} d_j prod_{i<j} (Lt - r_i I) x,    Lt = (L - a2 I)/a1,  a1 = a2 = lmax/2
+ * `nodes` = r_0..r_{K-1}, `dcoef` = d_0..d_K (host, float64).  A two-term recurrence: 3 panel
+ * passes per order and no accumulator, against 3 + 2/3 for the three-term Chebyshev recurrence
+ * of gspx_cheby_filter*.  The caller derives (nodes, dcoef) from the reference's Chebyshev
+ * coefficients in exact arithmetic (pygsp_amd/filters.py::cheb_to_newton), so both entry points
+ * evaluate the identical polynomial; they agree to rounding (~1e-14 in float64).
+ * x: [N][Nsig], y: [N][Nsig].  K < 1 -> GSPX_ERR_COEFF. */
+int gspx_newton_filter_dev(gspx_graph* g, double lmax, int K, const double* nodes,
+                           const double* dcoef, int64_t Nsig, const void* x_dev, void* y_dev,
+                           double* kernel_ms);
+int gspx_newton_filter(gspx_graph* g, double lmax, int K, const double* nodes, const double* dcoef,
+                       int64_t Nsig, const void* x_host, void* y_host, double* kernel_ms);
+
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
  *   out[0] total device time, out[1] time inside the recurrence-step launches only,
  *   out[2] number of step launches, out[3] permute-in/copy time, out[4] combine time */

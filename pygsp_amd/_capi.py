@@ -72,6 +72,10 @@ SIGNATURES = {
                                          _P, _c.c_int, _c.POINTER(_c.c_double)]),
     "gspx_cheby_filter": (_c.c_int, [_P, _c.c_double, _c.c_int, _c.c_int, _P, _c.c_int64, _P, _P,
                                      _c.c_int, _c.POINTER(_c.c_double)]),
+    "gspx_newton_filter_dev": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _P, _c.c_int64, _P, _P,
+                                          _c.POINTER(_c.c_double)]),
+    "gspx_newton_filter": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _P, _c.c_int64, _P, _P,
+                                      _c.POINTER(_c.c_double)]),
     "gspx_last_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "gspx_plan_describe": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P]),
     "gspx_bench_copy": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),

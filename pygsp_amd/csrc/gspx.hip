@@ -764,10 +764,10 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
   return s;
 }
 
-template <typename T, int VEC, bool FLUSH>
+template <typename T, int VEC, int MODE>
 static void launch_panel_w(const StepArgs<T>& a, int wlog2, dim3 grid, hipStream_t st) {
-#define GSPX_LP(WL)                                                                              \
-  hipLaunchKernelGGL((k_step_panel<T, VEC, WL, FLUSH>), grid, dim3(256), 0, st, a.rowptr, a.col, \
+#define GSPX_LP(WL)                                                                             \
+  hipLaunchKernelGGL((k_step_panel<T, VEC, WL, MODE>), grid, dim3(256), 0, st, a.rowptr, a.col, \
                      a.val, a.cur, a.wts, a.perm, a)
   switch (wlog2) {
     case 4: GSPX_LP(4); break;
@@ -777,20 +777,20 @@ static void launch_panel_w(const StepArgs<T>& a, int wlog2, dim3 grid, hipStream
 #undef GSPX_LP
 }
 
-template <typename T, bool FLUSH>
+template <typename T, int MODE>
 static void launch_panel(const StepArgs<T>& a, const Shape& s, dim3 grid, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
-    if (s.vec == 4) return launch_panel_w<T, 4, FLUSH>(a, s.wlog2, grid, st);
+    if (s.vec == 4) return launch_panel_w<T, 4, MODE>(a, s.wlog2, grid, st);
   }
-  if (s.vec == 2) return launch_panel_w<T, 2, FLUSH>(a, s.wlog2, grid, st);
-  return launch_panel_w<T, 1, FLUSH>(a, s.wlog2, grid, st);
+  if (s.vec == 2) return launch_panel_w<T, 2, MODE>(a, s.wlog2, grid, st);
+  return launch_panel_w<T, 1, MODE>(a, s.wlog2, grid, st);
 }
 
-template <typename T, int VEC, bool FLUSH>
+template <typename T, int VEC, int MODE>
 static void launch_lds_w(const StepArgs<T>& a, const unsigned* coff, int wlog2, dim3 grid,
                          hipStream_t st) {
-#define GSPX_LL(WL)                                                                           \
-  hipLaunchKernelGGL((k_step_lds<T, VEC, WL, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff, \
+#define GSPX_LL(WL)                                                                          \
+  hipLaunchKernelGGL((k_step_lds<T, VEC, WL, MODE>), grid, dim3(256), 0, st, a.rowptr, coff, \
                      a.val, a.cur, a.wts, a.perm, a)
   switch (wlog2) {
     case 4: GSPX_LL(4); break;
@@ -800,14 +800,14 @@ static void launch_lds_w(const StepArgs<T>& a, const unsigned* coff, int wlog2, 
 #undef GSPX_LL
 }
 
-template <typename T, bool FLUSH>
+template <typename T, int MODE>
 static void launch_lds(const StepArgs<T>& a, const unsigned* coff, const Shape& s, dim3 grid,
                        hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
-    if (s.vec == 4) return launch_lds_w<T, 4, FLUSH>(a, coff, s.wlog2, grid, st);
+    if (s.vec == 4) return launch_lds_w<T, 4, MODE>(a, coff, s.wlog2, grid, st);
   }
-  if (s.vec == 2) return launch_lds_w<T, 2, FLUSH>(a, coff, s.wlog2, grid, st);
-  return launch_lds_w<T, 1, FLUSH>(a, coff, s.wlog2, grid, st);
+  if (s.vec == 2) return launch_lds_w<T, 2, MODE>(a, coff, s.wlog2, grid, st);
+  return launch_lds_w<T, 1, MODE>(a, coff, s.wlog2, grid, st);
 }
 
 template <typename T, bool FLUSH>
@@ -856,15 +856,18 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
     gx = a.cpx * 8;
   }
   dim3 grid((unsigned)gx, (unsigned)s.gridy, 1);
+  const int mode = a.flush ? 1 : (a.beta != T(0) ? 2 : 0);
   if (s.kernel == 5) {
-    if (a.flush) launch_lds<T, true>(a, coff, s, grid, st);
-    else launch_lds<T, false>(a, coff, s, grid, st);
+    if (mode == 1) launch_lds<T, 1>(a, coff, s, grid, st);
+    else if (mode == 2) launch_lds<T, 2>(a, coff, s, grid, st);
+    else launch_lds<T, 0>(a, coff, s, grid, st);
   } else if (s.kernel >= 3) {
     if (a.flush) launch_wrow<T, true>(a, coff, s, grid, st);
     else launch_wrow<T, false>(a, coff, s, grid, st);
   } else if (s.kernel == 1) {
-    if (a.flush) launch_panel<T, true>(a, s, grid, st);
-    else launch_panel<T, false>(a, s, grid, st);
+    if (mode == 1) launch_panel<T, 1>(a, s, grid, st);
+    else if (mode == 2) launch_panel<T, 2>(a, s, grid, st);
+    else launch_panel<T, 0>(a, s, grid, st);
   } else {
     if (a.flush)
       hipLaunchKernelGGL((k_step_narrow<T, true>), grid, dim3(256), 0, st, a, s.wlog2, s.glog2);
@@ -1130,6 +1133,188 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
   ctx->timing[2] = (double)(ev_idx / 4) * K;
   ctx->timing[3] = t_perm;
   ctx->timing[4] = t_comb;
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Newton-form evaluation of the SAME polynomial (single filter, analysis):
+//     p(Lt) x = sum_j d_j prod_{i<j} (Lt - r_i I) x,   Lt = (L - a2 I)/a1 = F/2
+// by Horner:  h_K = d_K x,  h_j = (Lt - r_j I) h_{j+1} + d_j x,  y = h_0.
+// A two-term recurrence: per order it gathers h, reads x and writes h (3 panels) and needs NO
+// accumulator, where the three-term Chebyshev recurrence moves 3 + 2/3.  Nodes (Leja-ordered
+// Chebyshev points) and divided differences are computed by the caller in exact arithmetic from
+// the reference's Chebyshev coefficients (pygsp_amd/filters.py::cheb_to_newton), so the polynomial
+// is identical; results agree with the reference to ~1e-14 (fp64).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const double* dc, const T* x,
+                            unsigned ldx, T* y, unsigned ldy, unsigned ld, size_t& ev_idx) {
+  gspx_ctx* ctx = g->ctx;
+  Options opt = ctx->opt;
+  if (opt.kernel == 3 || opt.kernel == 4) opt.kernel = 0;  // wave-row kernels have no beta term
+  hipStream_t st = ctx->stream;
+  const int N = (int)g->N;
+  const size_t U = (size_t)N * ld;
+  int veccap = 4;
+  while (veccap > 1 && ((ldy % veccap) != 0 || (((uintptr_t)y / sizeof(T)) % veccap) != 0))
+    veccap /= 2;
+  const Shape shape = choose_shape(opt, sizeof(T), ld, veccap);
+  const int* perm = g->has_perm ? g->perm.as<int>() : nullptr;
+
+  const T hw[3] = {T(1), T(0), T(0)};  // final step: y = 1 * h_0
+  CHK(ctx->ws_w.ensure(sizeof(hw) + 64));
+  HIPCHK(hipMemcpyAsync(ctx->ws_w.p, hw, sizeof(hw), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  CHK(ctx->ws_t.ensure(3 * U * sizeof(T) + 256));
+  T* X = ctx->ws_t.as<T>();
+  T* H[2] = {X + U, X + 2 * U};
+
+  hipEvent_t e0 = pool_event(ctx, ev_idx++), e1 = pool_event(ctx, ev_idx++),
+             e2 = pool_event(ctx, ev_idx++), e3 = pool_event(ctx, ev_idx++);
+  if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
+  HIPCHK(hipEventRecord(e0, st));
+  int pvec = shape.vec;
+  while (pvec > 1 && ((ldx % pvec) != 0 || (((uintptr_t)x / sizeof(T)) % pvec) != 0)) pvec /= 2;
+  launch_permute_in<T>(x, ldx, X, ld, N, perm, pvec, st);
+  HIPCHK(hipEventRecord(e1, st));
+
+  const int pad_self = 0;
+  if (shape.kernel == 5 &&
+      (g->coff_ldb != ld * (unsigned)sizeof(T) || g->coff_pad_self != pad_self)) {
+    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
+    const int nb = std::max(1, (N + 255) / 256);
+    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
+                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), pad_self,
+                       g->coff.as<unsigned>());
+    g->coff_ldb = ld * (unsigned)sizeof(T);
+    g->coff_pad_self = pad_self;
+  }
+  StepArgs<T> a{};
+  a.rowptr = g->rptr.as<int>();
+  a.col = g->rcol.as<int>();
+  a.val = g->fval.as<T>();
+  a.N = N;
+  a.ld = ld;
+  a.curbytes = (u32)(U * sizeof(T));
+  a.nf = 1;
+  a.racc = H[0];  // never read (flush == 1) - any valid panel
+  a.y = y;
+  a.ldy = ldy;
+  a.perm = perm;
+  a.wts = ctx->ws_w.as<T>();
+  a.old = X;
+  for (int s = 0; s < K; ++s) {
+    const int j = K - 1 - s;
+    a.cur = (s == 0) ? X : H[(s - 1) & 1];
+    a.out = H[s & 1];
+    if (s == 0) {
+      a.scale = (T)(0.5 * dc[K]);
+      a.beta = T(0);
+      a.gamma = (T)(dc[j] - dc[K] * nodes[j]);
+    } else {
+      a.scale = T(0.5);
+      a.beta = (T)(-nodes[j]);
+      a.gamma = (T)dc[j];
+    }
+    a.flush = (j == 0) ? 1 : 0;
+    a.final = (j == 0) ? 1 : 0;
+    launch_step<T>(a, shape, opt, st, g->coff.as<unsigned>());
+  }
+  HIPCHK(hipEventRecord(e2, st));
+  HIPCHK(hipEventRecord(e3, st));
+  HIPCHK(hipGetLastError());
+  return GSPX_OK;
+}
+
+template <typename T>
+static int newton_dev_t(gspx_graph* g, double lmax, int K, const double* nodes, const double* dc,
+                        int64_t Nsig, const T* x, T* y) {
+  gspx_ctx* ctx = g->ctx;
+  const Options& opt = ctx->opt;
+  const int64_t N = g->N;
+  for (int i = 0; i < 5; ++i) ctx->timing[i] = 0;
+  if (N == 0 || Nsig == 0) return GSPX_OK;
+  CHK(ensure_factor<T>(g, lmax));
+  const size_t rowb = (size_t)N * sizeof(T);
+  int64_t max_ld = (int64_t)((((size_t)1 << 31) - 65536) / rowb);
+  if (max_ld < 1)
+    return set_err(GSPX_ERR_INVALID, "graph too large: one signal column exceeds 2 GiB");
+  const size_t budget = (size_t)std::max<int64_t>(opt.ws_limit_mb, 1) << 20;
+  max_ld = std::min<int64_t>(max_ld, std::max<int64_t>(1, (int64_t)(budget / (rowb * 3))));
+  if (opt.max_batch > 0) max_ld = std::min<int64_t>(max_ld, opt.max_batch);
+  if (max_ld < Nsig && max_ld >= 4) max_ld &= ~(int64_t)3;
+  size_t ev_idx = 0;
+  HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+  for (int64_t c0 = 0; c0 < Nsig; c0 += max_ld) {
+    const unsigned ld = (unsigned)std::min<int64_t>(max_ld, Nsig - c0);
+    CHK(run_batch_newton<T>(g, K, nodes, dc, x + c0, (unsigned)Nsig, y + c0, (unsigned)Nsig, ld,
+                            ev_idx));
+  }
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+  ctx->timing[0] = ms;
+  double t_perm = 0, t_steps = 0;
+  for (size_t i = 0; i + 3 < ev_idx; i += 4) {
+    float p = 0, q = 0;
+    HIPCHK(hipEventElapsedTime(&p, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+    HIPCHK(hipEventElapsedTime(&q, ctx->ev_pool[i + 1], ctx->ev_pool[i + 2]));
+    t_perm += p;
+    t_steps += q;
+  }
+  ctx->timing[1] = t_steps;
+  ctx->timing[2] = (double)(ev_idx / 4) * K;
+  ctx->timing[3] = t_perm;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_newton_filter_dev(gspx_graph* g, double lmax, int K, const double* nodes,
+                                      const double* dcoef, int64_t Nsig, const void* x_dev,
+                                      void* y_dev, double* kernel_ms) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (K < 1) return set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape");
+  if (!nodes || !dcoef) return set_err(GSPX_ERR_INVALID, "null nodes / coefficients");
+  if (Nsig < 0) return set_err(GSPX_ERR_INVALID, "negative number of signals");
+  if (!(lmax > 0.0) || !std::isfinite(lmax))
+    return set_err(GSPX_ERR_INVALID, "lmax must be positive and finite (got %g)", lmax);
+  if (Nsig > 0 && g->N > 0 && (!x_dev || !y_dev))
+    return set_err(GSPX_ERR_INVALID, "null signal pointer");
+  for (int i = 0; i < K; ++i)
+    if (!std::isfinite(nodes[i])) return set_err(GSPX_ERR_INVALID, "non-finite node");
+  for (int i = 0; i <= K; ++i)
+    if (!std::isfinite(dcoef[i])) return set_err(GSPX_ERR_INVALID, "non-finite coefficient");
+  if (Nsig >= ((int64_t)1 << 31) / 16) return set_err(GSPX_ERR_INVALID, "too many signals");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  int rc = g->dtype == GSPX_F32
+               ? newton_dev_t<float>(g, lmax, K, nodes, dcoef, Nsig, (const float*)x_dev,
+                                     (float*)y_dev)
+               : newton_dev_t<double>(g, lmax, K, nodes, dcoef, Nsig, (const double*)x_dev,
+                                      (double*)y_dev);
+  if (rc == GSPX_OK && kernel_ms) *kernel_ms = g->ctx->timing[0];
+  return rc;
+}
+
+extern "C" int gspx_newton_filter(gspx_graph* g, double lmax, int K, const double* nodes,
+                                  const double* dcoef, int64_t Nsig, const void* x_host,
+                                  void* y_host, double* kernel_ms) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (Nsig > 0 && g->N > 0 && (!x_host || !y_host))
+    return set_err(GSPX_ERR_INVALID, "null signal pointer");
+  gspx_ctx* ctx = g->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)g->N * (size_t)std::max<int64_t>(Nsig, 0) * elt_size(g->dtype);
+  if (n == 0) {
+    if (kernel_ms) *kernel_ms = 0;
+    return K < 1 ? set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape") : GSPX_OK;
+  }
+  CHK(ctx->io_x.ensure(n));
+  CHK(ctx->io_y.ensure(n));
+  HIPCHK(hipMemcpyAsync(ctx->io_x.p, x_host, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  CHK(gspx_newton_filter_dev(g, lmax, K, nodes, dcoef, Nsig, ctx->io_x.p, ctx->io_y.p, kernel_ms));
+  HIPCHK(hipMemcpyAsync(y_host, ctx->io_y.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return GSPX_OK;
 }
 

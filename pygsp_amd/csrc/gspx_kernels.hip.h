@@ -108,6 +108,7 @@ template <typename T> struct StepArgs {
   u32 ld;        // signals in this batch (elements per row)
   u32 curbytes;  // N*ld*sizeof(T)  (< 2 GiB)
   T scale, gamma;
+  T beta;        // coefficient of T_{k-1}'s own row (Newton-form steps; 0 for the recurrence)
   // flush: r_f (=|+=) w_new*T_k + w_cur*T_{k-1} + w_old*T_{k-2}
   int flush;     // 0 none, 1 write, 2 accumulate
   int final;     // 1: write to y (caller's vertex order, row stride ldy) instead of racc
@@ -214,7 +215,8 @@ template <typename T, int VEC> struct PanelCtx {
 // One row set.  `ov_use`/`ra_use` were prefetched by the previous set; `ov_pf`/`ra_pf` receive the
 // prefetch for the next one (distinct registers: the caller alternates two pairs, so no copy -
 // and therefore no wait on the in-flight prefetch - is needed at the top of the loop).
-template <typename T, int VEC, int R, bool FLUSH>
+// MODE: 0 plain step, 1 step + flush, 2 plain step with the beta * T_{k-1}[row] term
+template <typename T, int VEC, int R, int MODE>
 __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const StepArgs<T>& a,
                                               const int it,
                                               const typename VT<T, VEC>::t& ov_use,
@@ -223,6 +225,8 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
                                               typename VT<T, VEC>::t& ra_pf) {
   typedef VT<T, VEC> X;
   typedef typename X::t V;
+  constexpr bool FLUSH = MODE == 1;
+  constexpr bool SELF = MODE != 0;
   const int srow = __builtin_amdgcn_readfirstlane(c.row0 + it * R);
   if (srow >= a.N) return false;
   // rowptr is padded past N with the total entry count, so rows >= N read as empty
@@ -303,7 +307,7 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   // so being younger it never delays their wait, and it is unconditional (clamped address) so
   // that the compiler's vmcnt bookkeeping is exact and the final FMA does not wait for it.
   issue_pair(k);
-  if constexpr (FLUSH) curv = X::bload(c.rc, (u32)myrow * c.ldb + c.lane_off);
+  if constexpr (SELF) curv = X::bload(c.rc, (u32)myrow * c.ldb + c.lane_off);
   {
     const int nrow = myrow + R;
     const bool pf_on = (it + 1 < c.nsets) && nrow < a.N;
@@ -316,6 +320,7 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   // T_k = scale * (F T_{k-1}) + gamma * T_{k-2}; lanes without a row store out of range (dropped)
   V nv = a.scale * acc;
   nv += a.gamma * ov_use;  // gamma == 0: the host points `old` at `cur`, the product vanishes
+  if constexpr (SELF) nv += a.beta * curv;
   X::bstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
 
   if constexpr (FLUSH) {
@@ -339,7 +344,7 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   return true;
 }
 
-template <typename T, int VEC, int WLOG2, bool FLUSH>
+template <typename T, int VEC, int WLOG2, int MODE>
 __global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowptr,
                                                     const int* __restrict__ col,
                                                     const T* __restrict__ val,
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowp
   typedef typename VT<T, VEC>::t V;
   constexpr int W = 1 << WLOG2;
   constexpr int R = 64 / W;
+  constexpr bool FLUSH = MODE == 1;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -389,9 +395,9 @@ __global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowp
   }
 #pragma unroll 1
   for (int it = 0; it < c.nsets; it += 2) {
-    if (!panel_row_set<T, VEC, R, FLUSH>(c, a, it, ovA, raA, ovB, raB)) break;
+    if (!panel_row_set<T, VEC, R, MODE>(c, a, it, ovA, raA, ovB, raB)) break;
     if (it + 1 >= c.nsets) break;
-    if (!panel_row_set<T, VEC, R, FLUSH>(c, a, it + 1, ovB, raB, ovA, raA)) break;
+    if (!panel_row_set<T, VEC, R, MODE>(c, a, it + 1, ovB, raB, ovA, raA)) break;
   }
 }
 
@@ -748,7 +754,7 @@ template <typename T, int VEC> struct LdsCtx {
 
 // One row set.  ov_use/ra_use were requested by the previous set, ov_pf/ra_pf receive the request
 // for the next one (the caller alternates two register pairs: no copy, hence no wait, at the top).
-template <typename T, int VEC, int R, bool FLUSH, bool STAGED>
+template <typename T, int VEC, int R, int MODE, bool STAGED>
 __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepArgs<T>& a, const int j,
                                             const typename VT<T, VEC>::t& ov_use,
                                             const typename VT<T, VEC>::t& ra_use,
@@ -757,6 +763,8 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
   typedef VT<T, VEC> X;
   typedef typename X::t V;
   typedef T T4 __attribute__((ext_vector_type(4)));
+  constexpr bool FLUSH = MODE == 1;
+  constexpr bool SELF = MODE != 0;
   const int srow = c.row0 + j * R;
   const int myrow = srow + c.r;
   const bool row_on = myrow < a.N && c.lane_on;
@@ -786,7 +794,7 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
   asm volatile("" : "+v"(acc), "+v"(rbase));
   V sum = 0;
   V curv = 0;
-  if constexpr (FLUSH) curv = X::bload(c.rc, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON);
+  if constexpr (SELF) curv = X::bload(c.rc, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON);
 
   // the streaming request for the next set, valid only on the last pass (else out of range)
   const int nrow = myrow + R;
@@ -828,7 +836,8 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
     sum += v1.x * x4; sum += v1.y * x5; sum += v1.z * x6; sum += v1.w * x7;
   }
 
-  const V nv = a.scale * sum + acc;
+  V nv = a.scale * sum + acc;
+  if constexpr (SELF) nv += a.beta * curv;
   X::bstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
   if constexpr (FLUSH) {
     if (row_on) {
@@ -855,10 +864,11 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
   }
 }
 
-template <typename T, int VEC, int R, bool FLUSH, bool STAGED>
+template <typename T, int VEC, int R, int MODE, bool STAGED>
 __device__ __forceinline__ void lds_run_sets(const LdsCtx<T, VEC>& c, const StepArgs<T>& a) {
   typedef VT<T, VEC> X;
   typedef typename X::t V;
+  constexpr bool FLUSH = MODE == 1;
   V ovA, raA = 0, ovB = 0, raB = 0;
   {
     const int myrow = c.row0 + c.r;
@@ -869,13 +879,13 @@ __device__ __forceinline__ void lds_run_sets(const LdsCtx<T, VEC>& c, const Step
 #pragma unroll 1
   for (int j = 0; j < c.nsets; j += 2) {
     if (c.row0 + j * R >= a.N) break;
-    lds_row_set<T, VEC, R, FLUSH, STAGED>(c, a, j, ovA, raA, ovB, raB);
+    lds_row_set<T, VEC, R, MODE, STAGED>(c, a, j, ovA, raA, ovB, raB);
     if (j + 1 >= c.nsets || c.row0 + (j + 1) * R >= a.N) break;
-    lds_row_set<T, VEC, R, FLUSH, STAGED>(c, a, j + 1, ovB, raB, ovA, raA);
+    lds_row_set<T, VEC, R, MODE, STAGED>(c, a, j + 1, ovB, raB, ovA, raA);
   }
 }
 
-template <typename T, int VEC, int WLOG2, bool FLUSH>
+template <typename T, int VEC, int WLOG2, int MODE>
 __global__ __launch_bounds__(256) void k_step_lds(const int* __restrict__ rowptr,
                                                   const u32* __restrict__ coff,
                                                   const T* __restrict__ val,
@@ -929,9 +939,9 @@ __global__ __launch_bounds__(256) void k_step_lds(const int* __restrict__ rowptr
       s_coff[wave][q] = *(const u32x4*)(coff + c.seg_s + 4 * q);
       s_val[wave][q] = *(const T4*)(val + c.seg_s + 4 * q);
     }
-    lds_run_sets<T, VEC, R, FLUSH, true>(c, a);
+    lds_run_sets<T, VEC, R, MODE, true>(c, a);
   } else {
-    lds_run_sets<T, VEC, R, FLUSH, false>(c, a);  // very long rows: metadata straight from L2
+    lds_run_sets<T, VEC, R, MODE, false>(c, a);  // very long rows: metadata straight from L2
   }
 }
 
@@ -995,6 +1005,7 @@ __global__ __launch_bounds__(256) void k_step_narrow(const StepArgs<T> a, const 
         ov = a.old[o];
         nv += a.gamma * ov;
       }
+      if (a.beta != T(0)) nv += a.beta * a.cur[o];
       a.out[o] = nv;
       if constexpr (FLUSH) {
         const T curv = a.cur[o];

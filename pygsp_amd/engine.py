@@ -285,6 +285,39 @@ class DeviceGraph:
         return ms.value
 
 
+def _newton_methods():
+    def newton_filter(self, nodes, dcoef, x, lmax):
+        """Newton-form evaluation (single filter): host arrays in/out, x (N, Nsig) -> (N, Nsig)."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        dcoef = np.ascontiguousarray(dcoef, dtype=np.float64)
+        if dcoef.size != nodes.size + 1:
+            raise ValueError("need K nodes and K+1 coefficients")
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        if x.ndim != 2 or x.shape[0] != self.N:
+            raise ValueError("input must be (N, Nsig), got {}".format(x.shape))
+        y = np.empty_like(x)
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_newton_filter(
+            self._h, float(lmax), int(nodes.size), _capi.ptr(nodes), _capi.ptr(dcoef), x.shape[1],
+            _capi.ptr(x), _capi.ptr(y), ctypes.byref(ms)))
+        return y, ms.value
+
+    def newton_filter_dev(self, nodes, dcoef, x_ptr, y_ptr, nsig, lmax):
+        nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        dcoef = np.ascontiguousarray(dcoef, dtype=np.float64)
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_newton_filter_dev(
+            self._h, float(lmax), int(nodes.size), _capi.ptr(nodes), _capi.ptr(dcoef), int(nsig),
+            ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), ctypes.byref(ms)))
+        return ms.value
+
+    DeviceGraph.newton_filter = newton_filter
+    DeviceGraph.newton_filter_dev = newton_filter_dev
+
+
+_newton_methods()
+
+
 def plan_describe(coeffs, ctx=None):
     """The engine's step schedule for these coefficients (host-only; for schedule tests)."""
     c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))

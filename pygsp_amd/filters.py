@@ -48,6 +48,88 @@ def compute_cheby_coeff(f, m=30, N=None, *args, **kwargs):
     return c
 
 
+# How a SINGLE filter's polynomial is evaluated on the device (filterbanks and synthesis always
+# use the three-term recurrence):
+#   'recurrence' - the reference's three-term Chebyshev recurrence (approximations.py:99-112);
+#   'newton'     - the identical polynomial in Newton form on Leja-ordered Chebyshev nodes, by
+#                  Horner: a two-term recurrence, 3 instead of 3 2/3 panel passes per order.
+EVALUATION = "recurrence"
+
+
+def set_evaluation(mode):
+    global EVALUATION
+    if mode not in ("recurrence", "newton"):
+        raise ValueError("evaluation must be 'recurrence' or 'newton'")
+    EVALUATION = mode
+
+
+def _leja_order(points):
+    """Greedy Leja ordering: each next point maximises the product of distances to the chosen ones
+    (keeps the partial products of the Newton basis bounded: stable Horner evaluation)."""
+    pts = np.asarray(points, dtype=np.float64)
+    n = pts.size
+    chosen = np.empty(n)
+    left = np.ones(n, dtype=bool)
+    first = int(np.argmax(np.abs(pts)))
+    chosen[0] = pts[first]
+    left[first] = False
+    logp = np.full(n, -np.inf)
+    with np.errstate(divide="ignore"):
+        logp[left] = np.log(np.abs(pts[left] - chosen[0]))
+    for k in range(1, n):
+        cand = np.where(left, logp, -np.inf)
+        i = int(np.argmax(cand))
+        chosen[k] = pts[i]
+        left[i] = False
+        with np.errstate(divide="ignore"):
+            logp[left] += np.log(np.abs(pts[left] - chosen[k]))
+    return chosen
+
+
+_newton_cache = {}
+
+
+def cheb_to_newton(c):
+    """Chebyshev coefficients c_0..c_K of p(t) = c_0/2 + sum_k c_k T_k(t) (as compute_cheby_coeff
+    returns them) -> (nodes r_0..r_{K-1}, divided differences d_0..d_K) of the SAME polynomial,
+    p(t) = sum_j d_j prod_{i<j} (t - r_i).  Computed in 80+4K-digit decimal arithmetic from the
+    float64 inputs, so the only rounding is the final conversion of d_j to float64."""
+    import decimal
+    c = np.asarray(c, dtype=np.float64).ravel()
+    key = c.tobytes()
+    hit = _newton_cache.get(key)
+    if hit is not None:
+        return hit
+    K = c.size - 1
+    if K < 1:
+        raise TypeError("The coefficients have an invalid shape")
+    D = decimal.Decimal
+    with decimal.localcontext() as ctx:
+        ctx.prec = 80 + 4 * K
+        nodes = _leja_order(np.cos(np.pi * (np.arange(K) + 0.5) / K))
+        extra = 0.0 if np.all(np.abs(nodes) > 1e-3) else 0.987654321
+        r = [D(float(v)) for v in nodes] + [D(extra)]
+        cd = [D(float(v)) for v in c]
+
+        def p(t):
+            t0, t1 = D(1), t
+            acc = cd[0] / 2 + cd[1] * t1
+            for k in range(2, K + 1):
+                t0, t1 = t1, 2 * t * t1 - t0
+                acc += cd[k] * t1
+            return acc
+
+        d = [p(t) for t in r]
+        for j in range(1, K + 1):
+            for i in range(K, j - 1, -1):
+                d[i] = (d[i] - d[i - 1]) / (r[i] - r[i - j])
+        out = (np.ascontiguousarray(nodes), np.array([float(v) for v in d]))
+    if len(_newton_cache) > 64:
+        _newton_cache.clear()
+    _newton_cache[key] = out
+    return out
+
+
 def _as_coeff_matrix(c):
     if not isinstance(c, np.ndarray):
         c = np.array(c)
@@ -75,7 +157,15 @@ def cheby_op(G, c, signal, **kwargs):
     one_d = signal.ndim == 1
     x = signal.reshape(G.N, 1) if one_d else signal
     dev = _device_graph_of(G)
-    y, ms = dev.cheby_filter(c, x, G.lmax, _capi.ANALYSIS)
+    evaluation = kwargs.get("evaluation") or EVALUATION
+    if evaluation not in ("recurrence", "newton"):
+        raise ValueError("evaluation must be 'recurrence' or 'newton'")
+    if evaluation == "newton" and Nf == 1:
+        nodes, dcoef = cheb_to_newton(c[0])
+        y, ms = dev.newton_filter(nodes, dcoef, x, G.lmax)
+        y = y[None]
+    else:
+        y, ms = dev.cheby_filter(c, x, G.lmax, _capi.ANALYSIS)
     _record_timing(G, ms)
     r = np.asarray(y, dtype=np.float64).reshape(Nf * G.N, x.shape[1])
     return r[:, 0] if one_d else r

@@ -129,3 +129,42 @@ def test_locality_order_is_a_permutation_and_local():
     assert after < before / 50  # Morton order: neighbours become close in index
     rcm = engine.locality_order(W, None)
     assert sorted(rcm.tolist()) == list(range(5000))
+
+
+def test_newton_form_is_the_same_polynomial(golden_sensor123):
+    """cheb_to_newton: exact change of basis - checked at random points against the Chebyshev
+    series (evaluated in exact rational arithmetic), and end to end against the oracle with a
+    numpy Horner evaluation."""
+    from fractions import Fraction
+    lmax = float(golden_sensor123["lmax"])
+    L = csr_from(golden_sensor123, "Lcomb")
+    for scale, K in ((10, 30), (50, 30), (50, 50), (200, 40), (3, 1), (3, 2)):
+        c = orc.compute_cheby_coeff(orc.heat_kernel(scale, lmax), lmax, K)
+        nodes, d = filters.cheb_to_newton(c)
+        assert nodes.shape == (K,) and d.shape == (K + 1,)
+        assert len(set(nodes.tolist())) == K and np.all(np.abs(nodes) <= 1)
+        for t in (Fraction(-1), Fraction(1, 3), Fraction(7, 8), Fraction(-5, 9)):
+            t0, t1 = Fraction(1), t
+            ref = Fraction(float(c[0])) / 2 + Fraction(float(c[1])) * t1
+            for k in range(2, K + 1):
+                t0, t1 = t1, 2 * t * t1 - t0
+                ref += Fraction(float(c[k])) * t1
+            val, prod = Fraction(0), Fraction(1)
+            for j in range(K + 1):
+                val += Fraction(float(d[j])) * prod
+                if j < K:
+                    prod *= t - Fraction(float(nodes[j]))
+            scale_ref = max(abs(ref), Fraction(1, 10 ** 12))
+            assert abs(val - ref) / scale_ref < Fraction(1, 10 ** 9) or abs(val - ref) < Fraction(1, 10 ** 13)
+        # Horner evaluation with the actual matrix, float64
+        N = L.shape[0]
+        Lt = (L - (lmax / 2) * sparse.eye(N)) / (lmax / 2)
+        x = golden_sensor123["signals5"]
+        h = d[K] * x
+        for j in range(K - 1, -1, -1):
+            h = Lt.dot(h) - nodes[j] * h + d[j] * x
+        assert rel_err(h, orc.cheby_op(L, lmax, c, x)) < 1e-13
+    with pytest.raises(TypeError):
+        filters.cheb_to_newton(np.array([1.0]))
+    with pytest.raises(ValueError):
+        filters.set_evaluation("fancy")
