@@ -296,18 +296,21 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
     acc += v7 * x7;
   };
 
-  // all chunk pairs but the last
+  // all chunk pairs but the last.  Entry 0 of every row is its diagonal slot, so the first
+  // gather of the first pair IS T_{k-1}[row].
   int k = 0;
   for (; k + 2 < nmax; k += 2) {
     issue_pair(k);
     fma_pair();
+    if constexpr (SELF) {
+      if (k == 0) curv = x0;
+    }
   }
   // last pair (every row owns a diagonal slot, so nmax >= 1), then the streaming prefetch for the
   // next row set.  The prefetch is issued AFTER this set's last gathers: vmcnt retires in order,
   // so being younger it never delays their wait, and it is unconditional (clamped address) so
   // that the compiler's vmcnt bookkeeping is exact and the final FMA does not wait for it.
   issue_pair(k);
-  if constexpr (SELF) curv = X::bload(c.rc, (u32)myrow * c.ldb + c.lane_off);
   {
     const int nrow = myrow + R;
     const bool pf_on = (it + 1 < c.nsets) && nrow < a.N;
@@ -316,6 +319,9 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
     if constexpr (FLUSH) ra_pf = X::bload(c.rra, po);
   }
   fma_pair();
+  if constexpr (SELF) {
+    if (k == 0) curv = x0;
+  }
 
   // T_k = scale * (F T_{k-1}) + gamma * T_{k-2}; lanes without a row store out of range (dropped)
   V nv = a.scale * acc;
@@ -794,7 +800,6 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
   asm volatile("" : "+v"(acc), "+v"(rbase));
   V sum = 0;
   V curv = 0;
-  if constexpr (SELF) curv = X::bload(c.rc, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON);
 
   // the streaming request for the next set, valid only on the last pass (else out of range)
   const int nrow = myrow + R;
@@ -834,6 +839,9 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
     }
     sum += v0.x * x0; sum += v0.y * x1; sum += v0.z * x2; sum += v0.w * x3;
     sum += v1.x * x4; sum += v1.y * x5; sum += v1.z * x6; sum += v1.w * x7;
+    if constexpr (SELF) {
+      if (k == 0) curv = x0;  // entry 0 of every row is its diagonal slot: x0 = T_{k-1}[row]
+    }
   }
 
   V nv = a.scale * sum + acc;
@@ -1216,6 +1224,24 @@ __global__ void k_internal_build(const int* __restrict__ lptr, const int* __rest
       rcol[o + q + 1] = c;
       rval[o + q + 1] = v;
     }
+  }
+  // the diagonal slot becomes entry 0 of the row: the step kernels take T_{k-1}[row] from that
+  // gather instead of loading it again (flush and Newton-form steps)
+  {
+    int p = 0;
+    while (p < m && rcol[o + p] != i) ++p;
+    const T dv = rval[o + p];
+    if (m <= 128) {
+      for (int q = p; q > 0; --q) {  // keep the rest sorted
+        rcol[o + q] = rcol[o + q - 1];
+        rval[o + q] = rval[o + q - 1];
+      }
+    } else {
+      rcol[o + p] = rcol[o];
+      rval[o + p] = rval[o];
+    }
+    rcol[o] = i;
+    rval[o] = dv;
   }
   for (; m < npad; ++m) {
     rcol[o + m] = N;  // out-of-range sentinel: the gather's bounds check returns 0
