@@ -97,6 +97,7 @@ struct Options {
   int64_t vec = 0;            // 0 auto
   int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
   int64_t narrow_g_log2 = 2;
+  int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
   int64_t xcd_remap = 1;
   int64_t combine = 0;        // 0 auto, 1 fused flush, 2 deferred
   int64_t graph_launch = 0;
@@ -220,6 +221,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "vec")) return &o.vec;
   if (!strcmp(key, "rows_per_wave")) return &o.rows_per_wave;
   if (!strcmp(key, "narrow_g_log2")) return &o.narrow_g_log2;
+  if (!strcmp(key, "waves_per_block")) return &o.waves_per_block;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
@@ -236,6 +238,8 @@ extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value
     return set_err(GSPX_ERR_INVALID, "rows_per_wave must be in [0, 1024] (0 = auto)");
   if (!strcmp(key, "narrow_g_log2") && (value < 0 || value > 6))
     return set_err(GSPX_ERR_INVALID, "narrow_g_log2 must be in [0, 6]");
+  if (!strcmp(key, "waves_per_block") && !(value == 4 || value == 8 || value == 16))
+    return set_err(GSPX_ERR_INVALID, "waves_per_block must be 4, 8 or 16");
   if (!strcmp(key, "vec") && !(value == 0 || value == 1 || value == 2 || value == 4))
     return set_err(GSPX_ERR_INVALID, "vec must be 0, 1, 2 or 4");
   *s = value;
@@ -766,9 +770,9 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
 
 template <typename T, int VEC, int MODE>
 static void launch_panel_w(const StepArgs<T>& a, int wlog2, dim3 grid, hipStream_t st) {
-#define GSPX_LP(WL)                                                                             \
-  hipLaunchKernelGGL((k_step_panel<T, VEC, WL, MODE>), grid, dim3(256), 0, st, a.rowptr, a.col, \
-                     a.val, a.cur, a.wts, a.perm, a)
+#define GSPX_LP(WL)                                                                     \
+  hipLaunchKernelGGL((k_step_panel<T, VEC, WL, MODE>), grid, dim3(64 * a.wpb), 0, st, a.rowptr, \
+                     a.col, a.val, a.cur, a.wts, a.perm, a)
   switch (wlog2) {
     case 4: GSPX_LP(4); break;
     case 5: GSPX_LP(5); break;
@@ -844,8 +848,9 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
   int rows_per_chunk;
   if (s.kernel == 4 && rpw > 32) rpw = 32;
   a.rows_per_wave = rpw;
+  a.wpb = (s.kernel == 1) ? (int)opt.waves_per_block : 4;
   if (s.kernel == 1 || s.kernel >= 3)
-    rows_per_chunk = 4 * rpw;
+    rows_per_chunk = a.wpb * rpw;
   else
     rows_per_chunk = rpw * (4 << (6 - s.wlog2 - s.glog2));
   a.nchunks = (a.N + rows_per_chunk - 1) / rows_per_chunk;

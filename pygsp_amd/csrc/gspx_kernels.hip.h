@@ -120,7 +120,8 @@ template <typename T> struct StepArgs {
   const int* perm;  // internal row -> caller's row (nullable = identity)
   // row -> workgroup mapping
   int rows_per_wave;
-  int nchunks;      // number of (4*rows_per_wave)-row chunks
+  int wpb;          // waves per workgroup (panel kernel: 4, 8 or 16)
+  int nchunks;      // number of (wpb*rows_per_wave)-row chunks
   int cpx;          // chunks per XCD (xcd_remap) or 0 for plain order
 };
 
@@ -351,7 +352,7 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
 }
 
 template <typename T, int VEC, int WLOG2, int MODE>
-__global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowptr,
+__global__ __launch_bounds__(1024) void k_step_panel(const int* __restrict__ rowptr,
                                                     const int* __restrict__ col,
                                                     const T* __restrict__ val,
                                                     const T* __restrict__ cur,
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void k_step_panel(const int* __restrict__ rowp
   c.rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
   c.rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
   c.rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
-  c.row0 = (chunk * 4 + wave) * a.rows_per_wave;
+  c.row0 = (chunk * a.wpb + wave) * a.rows_per_wave;
   c.nsets = a.rows_per_wave / R;
 
   if (c.row0 >= a.N) return;
