@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Measure every BASELINE.json config that fits one GPU (configs[1..4] + one rank of configs[4]'s
-batch), device-resident, with a parity check against the oracle on sampled columns.
-Writes gpurun_out/configs.json."""
+"""Measure every BASELINE.json config that fits one GPU (configs[1..3] + one rank of configs[4]'s
+batch), device-resident.  Parity of the same configurations is asserted in tests/test_gpu_parity.py
+(this tool never touches oracle/); here the result is only cross-checked through the
+constant-signal identity  p(L) 1 = (c0/2 + sum (-1)^k c_k) 1.  Writes gpurun_out/configs.json."""
 import json
 import os
 import sys
@@ -11,7 +12,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import cheby_oracle as orc  # noqa: E402  (checker only)
 from pygsp_amd import engine, filters, graphs  # noqa: E402
 
 ctx = engine.default_context(0)
@@ -27,6 +27,7 @@ def run(name, G, bank, kernels, nsig, K, dtype, check_cols=2, reps=5):
     N = G.N
     dev = G.device_graph()
     x = np.random.default_rng(0).standard_normal((N, nsig)).astype(dtype)
+    x[:, 0] = 1.0  # constant column: size-independent self-check (combinatorial Laplacian only)
     bx, by = ctx.upload(x), ctx.alloc(x.nbytes * Nf)
     best, tm = 1e9, None
     for _ in range(reps):
@@ -34,10 +35,11 @@ def run(name, G, bank, kernels, nsig, K, dtype, check_cols=2, reps=5):
         if ms < best:
             best, tm = ms, ctx.last_timing()
     y = by.download((Nf, N, nsig), dtype)
-    L = orc.laplacian(G.W.astype(np.float64), G.lap_type)
-    cols = list(range(min(check_cols, nsig)))
-    ref = orc.cheby_op(L, lmax, c, x[:, cols].astype(np.float64)).reshape(Nf, N, len(cols))
-    err = float(np.max(np.abs(y[:, :, cols] - ref)) / np.max(np.abs(ref)))
+    err = None
+    if G.lap_type == "combinatorial":
+        k = np.arange(1, K + 1)
+        gain = 0.5 * c[:, 0] + (c[:, 1:] * ((-1.0) ** k)[None, :]).sum(axis=1)
+        err = float(np.max(np.abs(y[:, :, 0] - gain[:, None])) / max(np.max(np.abs(gain)), 1e-300))
     U = N * nsig * elt
     csr = dev.nnz_l * (elt + 4) + 4 * (N + 1)
     b_alg = K * (csr + 3 * U) + Nf * U
@@ -45,7 +47,7 @@ def run(name, G, bank, kernels, nsig, K, dtype, check_cols=2, reps=5):
          "K": K, "lap": G.lap_type, "total_ms": best, "steps_ms": tm["steps_ms"], "combine_ms": tm["combine_ms"],
          "permute_ms": tm["permute_ms"], "G_units_per_s": N * nsig * K / best / 1e6,
          "B_alg_GB": b_alg / 1e9, "GBps_alg": b_alg / best / 1e6, "frac_8TBps": b_alg / best / 1e6 / 8000,
-         "rel_err_vs_oracle": err, "build_ms": dev.build_ms}
+         "const_signal_identity_err": err, "build_ms": dev.build_ms}
     out.append(r)
     print(json.dumps(r), flush=True)
     bx.free(); by.free()
