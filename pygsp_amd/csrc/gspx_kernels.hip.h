@@ -27,6 +27,9 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
+#ifndef GSPX_STREAM_AUX
+#define GSPX_STREAM_AUX 0  // cache-policy bits of the streaming T_{k-2} loads / T_k stores (2 = nt)
+#endif
 #define GSPX_POISON 0x80000000u  // voffset >= num_records for every panel we accept (< 2 GiB)
 
 // ---------------------------------------------------------------------------------------------
@@ -38,6 +41,12 @@ template <> struct VT<float, 1> {
   typedef float t;
   static __device__ __forceinline__ t bload(rsrc_t r, u32 o) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0));
+  }
+  static __device__ __forceinline__ t sload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, GSPX_STREAM_AUX));
+  }
+  static __device__ __forceinline__ void sstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, v), r, o, 0, GSPX_STREAM_AUX);
   }
   static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32, v), r, o, 0, 0);
@@ -51,6 +60,12 @@ template <> struct VT<float, 2> {
   static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, o, 0, 0);
   }
+  static __device__ __forceinline__ t sload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(t, __builtin_amdgcn_raw_buffer_load_b64(r, o, 0, GSPX_STREAM_AUX));
+  }
+  static __device__ __forceinline__ void sstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, o, 0, GSPX_STREAM_AUX);
+  }
 };
 template <> struct VT<float, 4> {
   typedef float t __attribute__((ext_vector_type(4)));
@@ -59,6 +74,12 @@ template <> struct VT<float, 4> {
   }
   static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, 0);
+  }
+  static __device__ __forceinline__ t sload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(t, __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, GSPX_STREAM_AUX));
+  }
+  static __device__ __forceinline__ void sstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, GSPX_STREAM_AUX);
   }
 };
 template <> struct VT<double, 1> {
@@ -69,6 +90,12 @@ template <> struct VT<double, 1> {
   static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, o, 0, 0);
   }
+  static __device__ __forceinline__ t sload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o, 0, GSPX_STREAM_AUX));
+  }
+  static __device__ __forceinline__ void sstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, o, 0, GSPX_STREAM_AUX);
+  }
 };
 template <> struct VT<double, 2> {
   typedef double t __attribute__((ext_vector_type(2)));
@@ -77,6 +104,12 @@ template <> struct VT<double, 2> {
   }
   static __device__ __forceinline__ void bstore(rsrc_t r, u32 o, t v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, 0);
+  }
+  static __device__ __forceinline__ t sload(rsrc_t r, u32 o) {
+    return __builtin_bit_cast(t, __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, GSPX_STREAM_AUX));
+  }
+  static __device__ __forceinline__ void sstore(rsrc_t r, u32 o, t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, GSPX_STREAM_AUX);
   }
 };
 
@@ -123,6 +156,8 @@ template <typename T> struct StepArgs {
   int wpb;          // waves per workgroup (panel kernel: 4, 8 or 16)
   int nchunks;      // number of (wpb*rows_per_wave)-row chunks
   int cpx;          // chunks per XCD (xcd_remap) or 0 for plain order
+  int reverse;      // 1: sweep the rows from the end (alternate steps: the tail of the previous
+                    // step's output is still in the Infinity Cache)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -316,8 +351,8 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
     const int nrow = myrow + R;
     const bool pf_on = (it + 1 < c.nsets) && nrow < a.N;
     const u32 po = pf_on ? (u32)nrow * c.ldb + c.lane_off : GSPX_POISON;
-    ov_pf = X::bload(c.rold, po);
-    if constexpr (FLUSH) ra_pf = X::bload(c.rra, po);
+    ov_pf = X::sload(c.rold, po);
+    if constexpr (FLUSH) ra_pf = X::sload(c.rra, po);
   }
   fma_pair();
   if constexpr (SELF) {
@@ -328,7 +363,7 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   V nv = a.scale * acc;
   nv += a.gamma * ov_use;  // gamma == 0: the host points `old` at `cur`, the product vanishes
   if constexpr (SELF) nv += a.beta * curv;
-  X::bstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
+  X::sstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
 
   if constexpr (FLUSH) {
     if (row_on) {
@@ -371,6 +406,7 @@ __global__ __launch_bounds__(1024) void k_step_panel(const int* __restrict__ row
   int chunk = blockIdx.x;
   if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);  // contiguous row range per XCD
   if (chunk >= a.nchunks) return;
+  if (a.reverse) chunk = a.nchunks - 1 - chunk;
 
   PanelCtx<T, VEC> c;
   c.rowptr = rowptr;
@@ -397,8 +433,8 @@ __global__ __launch_bounds__(1024) void k_step_panel(const int* __restrict__ row
     typedef VT<T, VEC> X;
     const int myrow = c.row0 + c.r;
     const u32 po = myrow < a.N ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON;
-    ovA = X::bload(c.rold, po);
-    if constexpr (FLUSH) raA = X::bload(c.rra, po);
+    ovA = X::sload(c.rold, po);
+    if constexpr (FLUSH) raA = X::sload(c.rra, po);
   }
 #pragma unroll 1
   for (int it = 0; it < c.nsets; it += 2) {
@@ -658,7 +694,7 @@ __device__ __forceinline__ void wrow_body(const WrowCtx<T, VEC>& c, const StepAr
 
   V nv = a.scale * acc;
   nv += a.gamma * ov_use;  // gamma == 0: the host points `old` at `cur`, the product vanishes
-  X::bstore(c.rout, c.voff + rowoff, nv);
+  X::sstore(c.rout, c.voff + rowoff, nv);
   if constexpr (FLUSH) {
     if (c.lane_on) {
       const size_t o = (size_t)row * a.ld + c.colel;
@@ -827,8 +863,8 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
     // costs an issue slot but no memory traffic and keeps the vmcnt bookkeeping exact)
     const u32 po = (k + 2 >= nmax) ? pf_off : GSPX_POISON;
     __builtin_amdgcn_sched_barrier(0);  // gathers first: the streaming request must be younger
-    ov_pf = X::bload(c.rold, po);
-    if constexpr (FLUSH) ra_pf = X::bload(c.rra, po);
+    ov_pf = X::sload(c.rold, po);
+    if constexpr (FLUSH) ra_pf = X::sload(c.rra, po);
     __builtin_amdgcn_sched_barrier(0);  // the requests above stay above the waits below
     T4 v0, v1;
     if constexpr (STAGED) {
@@ -847,7 +883,7 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
 
   V nv = a.scale * sum + acc;
   if constexpr (SELF) nv += a.beta * curv;
-  X::bstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
+  X::sstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
   if constexpr (FLUSH) {
     if (row_on) {
       const size_t o = (size_t)myrow * a.ld + c.colel;
@@ -882,8 +918,8 @@ __device__ __forceinline__ void lds_run_sets(const LdsCtx<T, VEC>& c, const Step
   {
     const int myrow = c.row0 + c.r;
     const u32 po = myrow < a.N ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON;
-    ovA = X::bload(c.rold, po);
-    if constexpr (FLUSH) raA = X::bload(c.rra, po);
+    ovA = X::sload(c.rold, po);
+    if constexpr (FLUSH) raA = X::sload(c.rra, po);
   }
 #pragma unroll 1
   for (int j = 0; j < c.nsets; j += 2) {
@@ -915,6 +951,7 @@ __global__ __launch_bounds__(256) void k_step_lds(const int* __restrict__ rowptr
   int chunk = blockIdx.x;
   if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);
   if (chunk >= a.nchunks) return;
+  if (a.reverse) chunk = a.nchunks - 1 - chunk;
 
   LdsCtx<T, VEC> c;
   c.s_coff = s_coff[wave];
