@@ -66,6 +66,8 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "rows_per_wave"  consecutive rows per wave (0 = auto)
  *   "narrow_g_log2"  narrow kernel: log2 of lanes splitting one row's entries
  *   "xcd_remap"   1 (default) contiguous row ranges per XCD, 0 plain order
+ *   "synthesis"   0 (default) vector-coefficient Clenshaw: K sparse products for any Nf;
+ *                 1 the reference's per-filter loop (K*Nf products)
  *   "alternate_sweep" 1 (default) odd steps sweep the rows from the end: the tail of the previous
  *                 step's output is still in the Infinity Cache (measured -3..5 %)
  *   "waves_per_block" 4 (default), 8 or 16 waves per workgroup (kernel 1)

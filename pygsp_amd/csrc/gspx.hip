@@ -98,6 +98,7 @@ struct Options {
   int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
   int64_t narrow_g_log2 = 2;
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
+  int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
   int64_t combine = 0;        // 0 auto, 1 fused flush, 2 deferred
@@ -224,6 +225,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "narrow_g_log2")) return &o.narrow_g_log2;
   if (!strcmp(key, "waves_per_block")) return &o.waves_per_block;
   if (!strcmp(key, "alternate_sweep")) return &o.alternate_sweep;
+  if (!strcmp(key, "synthesis")) return &o.synthesis;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
@@ -863,7 +865,7 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
     gx = a.cpx * 8;
   }
   dim3 grid((unsigned)gx, (unsigned)s.gridy, 1);
-  const int mode = a.flush ? 1 : (a.beta != T(0) ? 2 : 0);
+  const int mode = a.flush ? 1 : ((a.beta != T(0) || a.nin > 0 || a.final) ? 2 : 0);
   if (s.kernel == 5) {
     if (mode == 1) launch_lds<T, 1>(a, coff, s, grid, st);
     else if (mode == 2) launch_lds<T, 2>(a, coff, s, grid, st);
@@ -1073,6 +1075,11 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
 }
 
 template <typename T>
+static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<double>& cp,
+                               const T* x, size_t plane_x, unsigned ldx, T* y, unsigned ldy,
+                               unsigned ld, size_t& ev_idx);
+
+template <typename T>
 static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                         int64_t Nsig, const T* x, T* y, int mode) {
   gspx_ctx* ctx = g->ctx;
@@ -1097,7 +1104,7 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
     return set_err(GSPX_ERR_INVALID, "graph too large: one signal column exceeds 2 GiB");
   const size_t budget = (size_t)std::max<int64_t>(opt.ws_limit_mb, 1) << 20;
   auto ws_per_col = [&](bool def) {
-    return rowb * (def ? (size_t)M : (size_t)(2 + (analysis ? Nf : 1)));
+    return rowb * (def ? (size_t)M : (size_t)(2 + Nf));
   };
   if (deferred && ws_per_col(true) * (size_t)std::min<int64_t>(Nsig, 4) > budget) deferred = false;
   max_ld = std::min<int64_t>(max_ld, std::max<int64_t>(1, (int64_t)(budget / ws_per_col(deferred))));
@@ -1113,12 +1120,18 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
       CHK(run_batch<T>(g, Nf, M, cp, x + c0, (unsigned)Nsig, y + c0, (unsigned)Nsig, ld, deferred,
                        false, true, ev_idx));
     } else {
-      // out = sum_f p_f(L) s_f  (filter.py:317-321): one single-filter recurrence per feature,
-      // accumulated on device; only the last one writes y.
-      for (int f = 0; f < Nf; ++f) {
-        std::vector<double> cf(cp.begin() + (size_t)f * M, cp.begin() + (size_t)(f + 1) * M);
-        CHK(run_batch<T>(g, 1, M, cf, x + (size_t)f * plane_x + c0, (unsigned)Nsig, y + c0,
-                         (unsigned)Nsig, ld, false, f > 0, f == Nf - 1, ev_idx));
+      // out = sum_f p_f(L) s_f  (filter.py:317-321)
+      if (opt.synthesis == 1) {
+        // the reference's scheme: one single-filter recurrence per feature, accumulated on
+        // device; only the last one writes y (K*Nf sparse products)
+        for (int f = 0; f < Nf; ++f) {
+          std::vector<double> cf(cp.begin() + (size_t)f * M, cp.begin() + (size_t)(f + 1) * M);
+          CHK(run_batch<T>(g, 1, M, cf, x + (size_t)f * plane_x + c0, (unsigned)Nsig, y + c0,
+                           (unsigned)Nsig, ld, false, f > 0, f == Nf - 1, ev_idx));
+        }
+      } else {
+        CHK(run_batch_synthesis<T>(g, Nf, M, cp, x + c0, plane_x, (unsigned)Nsig, y + c0,
+                                   (unsigned)Nsig, ld, ev_idx));
       }
     }
   }
@@ -1141,6 +1154,108 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
   ctx->timing[2] = (double)(ev_idx / 4) * K;
   ctx->timing[3] = t_perm;
   ctx->timing[4] = t_comb;
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthesis  out = sum_f p_f(L) s_f  (filter.py:313-322) by a vector-coefficient Clenshaw
+// recurrence.  By linearity  sum_f sum_k c'_fk T_k(Lt) s_f = sum_k T_k(Lt) u_k  with
+// u_k = sum_f c'_fk s_f, and Clenshaw evaluates that with ONE recurrence:
+//     b_K = u_K,   b_k = u_k + F b_{k+1} - b_{k+2}  (k = K-1..1),   out = u_0 + (F/2) b_1 - b_2
+// K sparse products instead of the reference's K*Nf (it runs cheby_op once per filter); each
+// step reads the Nf input panels at its own row, (Nf+3) panel passes per order instead of
+// Nf*(3 2/3).  Same polynomial, different summation order: agrees to rounding.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<double>& cp,
+                               const T* x, size_t plane_x, unsigned ldx, T* y, unsigned ldy,
+                               unsigned ld, size_t& ev_idx) {
+  gspx_ctx* ctx = g->ctx;
+  Options opt = ctx->opt;
+  if (opt.kernel == 3 || opt.kernel == 4) opt.kernel = 0;  // wave-row kernels lack the input sum
+  hipStream_t st = ctx->stream;
+  const int N = (int)g->N;
+  const int K = M - 1;
+  const size_t U = (size_t)N * ld;
+  int veccap = 4;
+  while (veccap > 1 && ((ldy % veccap) != 0 || (((uintptr_t)y / sizeof(T)) % veccap) != 0))
+    veccap /= 2;
+  const Shape shape = choose_shape(opt, sizeof(T), ld, veccap);
+  const int* perm = g->has_perm ? g->perm.as<int>() : nullptr;
+
+  // weights [K+1][nf]: w[k][f] = c'_fk  (c'_f0 already halved)
+  std::vector<T> hw((size_t)M * nf);
+  for (int k = 0; k < M; ++k)
+    for (int f = 0; f < nf; ++f) hw[(size_t)k * nf + f] = (T)cp[(size_t)f * M + k];
+  CHK(ctx->ws_w.ensure(hw.size() * sizeof(T) + 64));
+  HIPCHK(hipMemcpyAsync(ctx->ws_w.p, hw.data(), hw.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  CHK(ctx->ws_r.ensure((size_t)nf * U * sizeof(T) + 256));  // the nf input panels, internal order
+  CHK(ctx->ws_t.ensure(2 * U * sizeof(T) + 256));
+  T* S = ctx->ws_r.as<T>();
+  T* B[2] = {ctx->ws_t.as<T>(), ctx->ws_t.as<T>() + U};
+
+  hipEvent_t e0 = pool_event(ctx, ev_idx++), e1 = pool_event(ctx, ev_idx++),
+             e2 = pool_event(ctx, ev_idx++), e3 = pool_event(ctx, ev_idx++);
+  if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
+  HIPCHK(hipEventRecord(e0, st));
+  for (int f = 0; f < nf; ++f) {
+    const T* xf = x + (size_t)f * plane_x;
+    int pvec = shape.vec;
+    while (pvec > 1 && ((ldx % pvec) != 0 || (((uintptr_t)xf / sizeof(T)) % pvec) != 0)) pvec /= 2;
+    launch_permute_in<T>(xf, ldx, S + (size_t)f * U, ld, N, perm, pvec, st);
+  }
+  HIPCHK(hipEventRecord(e1, st));
+
+  const int pad_self = 0;
+  if (shape.kernel == 5 &&
+      (g->coff_ldb != ld * (unsigned)sizeof(T) || g->coff_pad_self != pad_self)) {
+    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
+    const int nb = std::max(1, (N + 255) / 256);
+    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
+                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), pad_self,
+                       g->coff.as<unsigned>());
+    g->coff_ldb = ld * (unsigned)sizeof(T);
+    g->coff_pad_self = pad_self;
+  }
+  StepArgs<T> a{};
+  a.rowptr = g->rptr.as<int>();
+  a.col = g->rcol.as<int>();
+  a.val = g->fval.as<T>();
+  a.N = N;
+  a.ld = ld;
+  a.curbytes = (u32)(U * sizeof(T));
+  a.nf = 1;
+  a.nin = nf;
+  a.racc = S;
+  a.y = y;
+  a.ldy = ldy;
+  a.perm = perm;
+  a.beta = T(0);
+  for (int k = K; k >= 0; --k) {
+    a.wts = ctx->ws_w.as<T>() + (size_t)k * nf;
+    a.final = (k == 0) ? 1 : 0;
+    a.flush = 0;
+    if (k == K) {  // b_K = u_K : no product needed (scale 0 on any valid panel)
+      a.cur = S;
+      a.old = S;
+      a.out = B[k & 1];
+      a.scale = T(0);
+      a.gamma = T(0);
+    } else {
+      a.cur = B[(k + 1) & 1];
+      a.out = B[k & 1];
+      const bool has_b2 = (k + 2 <= K);
+      a.old = has_b2 ? B[k & 1] : a.cur;
+      a.gamma = has_b2 ? T(-1) : T(0);
+      a.scale = (k == 0) ? T(0.5) : T(1);
+    }
+    a.reverse = (opt.alternate_sweep && (k & 1)) ? 1 : 0;
+    launch_step<T>(a, shape, opt, st, g->coff.as<unsigned>());
+  }
+  HIPCHK(hipEventRecord(e2, st));
+  HIPCHK(hipEventRecord(e3, st));
+  HIPCHK(hipGetLastError());
   return GSPX_OK;
 }
 

@@ -146,7 +146,9 @@ template <typename T> struct StepArgs {
   int flush;     // 0 none, 1 write, 2 accumulate
   int final;     // 1: write to y (caller's vertex order, row stride ldy) instead of racc
   int nf;
-  const T* wts;  // device, [nf][3]
+  int nin;       // MODE 2 only: number of extra input panels summed into the row (synthesis
+                 // by Clenshaw: out += sum_f wts[f] * racc[f][row]); 0 otherwise
+  const T* wts;  // device, [nf][3] (flush) or [nin] (extra inputs)
   T* racc;       // [nf][N][ld] internal accumulators
   T* y;          // [nf][N][ldy] (already offset to the batch's first column)
   u32 ldy;
@@ -363,6 +365,21 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   V nv = a.scale * acc;
   nv += a.gamma * ov_use;  // gamma == 0: the host points `old` at `cur`, the product vanishes
   if constexpr (SELF) nv += a.beta * curv;
+  if constexpr (MODE == 2) {
+    if (a.nin > 0 || a.final) {
+      // extra input panels (vector-coefficient Clenshaw) and/or a final store in caller order
+      if (row_on) {
+        const size_t o = (size_t)myrow * a.ld + c.colel;
+        const size_t plane_r = (size_t)a.N * a.ld;
+        for (int f = 0; f < a.nin; ++f) nv += c.wts[f] * *(const V*)(a.racc + f * plane_r + o);
+        if (a.final) {
+          const size_t orow = c.perm ? (size_t)c.perm[myrow] : (size_t)myrow;
+          *(V*)(a.y + orow * a.ldy + c.colel) = nv;
+        }
+      }
+      if (a.final) return true;
+    }
+  }
   X::sstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
 
   if constexpr (FLUSH) {
@@ -883,6 +900,20 @@ __device__ __forceinline__ void lds_row_set(const LdsCtx<T, VEC>& c, const StepA
 
   V nv = a.scale * sum + acc;
   if constexpr (SELF) nv += a.beta * curv;
+  if constexpr (MODE == 2) {
+    if (a.nin > 0 || a.final) {
+      if (row_on) {
+        const size_t o = (size_t)myrow * a.ld + c.colel;
+        const size_t plane_r = (size_t)a.N * a.ld;
+        for (int f = 0; f < a.nin; ++f) nv += c.wts[f] * *(const V*)(a.racc + f * plane_r + o);
+        if (a.final) {
+          const size_t orow = c.perm ? (size_t)c.perm[myrow] : (size_t)myrow;
+          *(V*)(a.y + orow * a.ldy + c.colel) = nv;
+        }
+      }
+      if (a.final) return;
+    }
+  }
   X::sstore(c.rout, row_on ? (u32)myrow * c.ldb + c.lane_off : GSPX_POISON, nv);
   if constexpr (FLUSH) {
     if (row_on) {
@@ -1052,6 +1083,15 @@ __global__ __launch_bounds__(256) void k_step_narrow(const StepArgs<T> a, const 
         nv += a.gamma * ov;
       }
       if (a.beta != T(0)) nv += a.beta * a.cur[o];
+      if (!FLUSH && (a.nin > 0 || a.final)) {
+        const size_t plane_in = (size_t)a.N * a.ld;
+        for (int f = 0; f < a.nin; ++f) nv += a.wts[f] * a.racc[f * plane_in + o];
+        if (a.final) {
+          const size_t orow2 = a.perm ? (size_t)a.perm[row] : (size_t)row;
+          a.y[orow2 * a.ldy + w] = nv;
+          continue;
+        }
+      }
       a.out[o] = nv;
       if constexpr (FLUSH) {
         const T curv = a.cur[o];

@@ -595,3 +595,31 @@ def test_newton_form_through_filter_api(golden_sensor123, golden_logo):
         filters.set_evaluation("recurrence")
     assert rel_err(filters.cheby_op(G, filters.compute_cheby_coeff(h, m=30), g["signal"],
                                     evaluation="newton"), g["heat10_y"]) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_synthesis_clenshaw_equals_per_filter_loop(ctx, dtype):
+    """Synthesis by one vector-coefficient Clenshaw recurrence (K products) == the reference's
+    per-filter loop (K*Nf products) == the oracle, for several panel widths and orders."""
+    n = 4001
+    W = random_graph(n, 8, seed=77, hub=True, isolated=2)
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    tol = TOL[np.dtype(dtype)] * 10
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n).astype(np.int32)
+    dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+    try:
+        for nf, order, nsig in ((3, 12, 1), (6, 30, 5), (2, 1, 16), (4, 2, 33), (5, 20, 64)):
+            c = np.array([orc.compute_cheby_coeff(k, lmax, order) for k in orc.mexican_hat_kernels(lmax, nf)])
+            s = rng.standard_normal((nf, n, nsig))
+            s64 = s.astype(dtype).astype(np.float64)
+            ref = sum(orc.cheby_op(L, lmax, c[f], s64[f]) for f in range(nf))
+            for mode in (0, 1):
+                ctx.set_option("synthesis", mode)
+                y, _ = dev.cheby_filter(c, s, lmax, _capi.SYNTHESIS)
+                assert y.shape == (n, nsig)
+                assert rel_err(y, ref) < tol, (nf, order, nsig, mode)
+    finally:
+        ctx.set_option("synthesis", 0)
+        dev.destroy()
