@@ -159,6 +159,12 @@ int gspx_last_timing(gspx_ctx* ctx, double out[5]);
  * `plan` must hold (M-1)*(4+3*Nf) doubles.  a1 = a2 = lmax/2 as approximations.py:93-96. */
 int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, double* plan);
 
+/* Largest eigenvalue of L by Lanczos on the device (replaces the ARPACK call of
+ * pygsp/graphs/graph.py:911-917).  Deterministic (fixed start vector).  Returns the largest Ritz
+ * value (<= lambda_max); stops when it changes by less than `tol` (relative; the reference uses
+ * 5e-3) or after `max_iter` steps.  The caller applies the reference's 1 % margin (graph.py:920). */
+int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int* iterations);
+
 /* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two
  * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */
 int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);

@@ -1505,6 +1505,132 @@ extern "C" int gspx_last_timing(gspx_ctx* ctx, double out[5]) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// lambda_max by Lanczos ON DEVICE (replaces the ARPACK call of
+// graph.py:911-917, 3.3 s on the host at N = 1M).  Plain three-term Lanczos on L with a fixed
+// start vector (deterministic, unlike ARPACK's random start); the largest Ritz value of the
+// tridiagonal matrix is found by bisection on the host.  Stops when it moves by less than `tol`
+// (relative) or after max_iter steps.  Returns the Ritz value itself (<= lambda_max); the caller
+// applies the reference's 1 % safety factor (graph.py:920).
+// ------------------------------------------------------------------------------------------------
+static double tridiag_max_eig(const std::vector<double>& al, const std::vector<double>& be) {
+  // Gershgorin bracket + Sturm-sequence bisection for the largest eigenvalue
+  const int m = (int)al.size();
+  double lo = al[0], hi = al[0];
+  for (int i = 0; i < m; ++i) {
+    const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(be[i]) : 0.0);
+    lo = std::min(lo, al[i] - r);
+    hi = std::max(hi, al[i] + r);
+  }
+  auto count_below = [&](double x) {  // eigenvalues < x
+    int cnt = 0;
+    double q = al[0] - x;
+    if (q < 0) ++cnt;
+    for (int i = 1; i < m; ++i) {
+      const double d = (q == 0.0) ? 1e-300 : q;
+      q = al[i] - x - be[i - 1] * be[i - 1] / d;
+      if (q < 0) ++cnt;
+    }
+    return cnt;
+  };
+  for (int it = 0; it < 200 && hi - lo > 1e-14 * std::max(1.0, std::fabs(hi)); ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (count_below(mid) >= m) hi = mid; else lo = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+template <typename T>
+static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* iters) {
+  gspx_ctx* ctx = g->ctx;
+  hipStream_t st = ctx->stream;
+  const int N = (int)g->N;
+  *out = 0.0;
+  if (iters) *iters = 0;
+  if (N == 0) return GSPX_OK;
+  // L v = 0.5 * F v + v  with F = 2 (L - I), i.e. the factor matrix for lmax = 2
+  CHK(ensure_factor<T>(g, 2.0));
+  Options opt = ctx->opt;
+  opt.kernel = 2;  // one signal: narrow kernel
+  const Shape shape = choose_shape(opt, sizeof(T), 1, 1);
+  DevMem vbuf, partial, scal;
+  CHK(vbuf.alloc((size_t)3 * N * sizeof(T)));
+  const int nb = std::min(1024, std::max(1, (N + 255) / 256));
+  CHK(partial.alloc((size_t)nb * sizeof(double)));
+  CHK(scal.alloc(sizeof(double)));
+  T* v[3] = {vbuf.as<T>(), vbuf.as<T>() + N, vbuf.as<T>() + 2 * (size_t)N};
+  auto dot = [&](const T* x, const T* y, double* res) -> int {
+    hipLaunchKernelGGL((k_dot_partial<T>), dim3(nb), dim3(256), 0, st, x, y, (size_t)N,
+                       partial.as<double>());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, partial.as<double>(), nb,
+                       scal.as<double>());
+    HIPCHK(hipMemcpyAsync(res, scal.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return GSPX_OK;
+  };
+  hipLaunchKernelGGL((k_start_vector<T>), dim3(nb), dim3(256), 0, st, v[0], (size_t)N);
+  double nrm2 = 0;
+  CHK(dot(v[0], v[0], &nrm2));
+  if (!(nrm2 > 0)) return GSPX_OK;
+  hipLaunchKernelGGL((k_axpby<T>), dim3(nb), dim3(256), 0, st, T(0), v[0], (T)(1.0 / std::sqrt(nrm2)),
+                     v[0], (size_t)N);
+  StepArgs<T> a{};
+  a.rowptr = g->rptr.as<int>();
+  a.col = g->rcol.as<int>();
+  a.val = g->fval.as<T>();
+  a.N = N;
+  a.ld = 1;
+  a.curbytes = (u32)((size_t)N * sizeof(T));
+  a.scale = T(0.5);
+  a.gamma = T(0);
+  a.beta = T(1);
+  std::vector<double> al, be;
+  double theta_prev = 0, theta = 0, beta_prev = 0;
+  int cur = 0, prev = 2;
+  for (int j = 0; j < max_iter && j < N; ++j) {
+    const int nxt = 3 - cur - prev;  // the third buffer
+    a.cur = v[cur];
+    a.old = v[cur];
+    a.out = v[nxt];
+    launch_step<T>(a, shape, opt, st, nullptr);  // w = L v_j
+    if (j > 0)
+      hipLaunchKernelGGL((k_axpby<T>), dim3(nb), dim3(256), 0, st, (T)(-beta_prev), v[prev], T(1),
+                         v[nxt], (size_t)N);
+    double alpha = 0;
+    CHK(dot(v[nxt], v[cur], &alpha));
+    hipLaunchKernelGGL((k_axpby<T>), dim3(nb), dim3(256), 0, st, (T)(-alpha), v[cur], T(1), v[nxt],
+                       (size_t)N);
+    double b2 = 0;
+    CHK(dot(v[nxt], v[nxt], &b2));
+    al.push_back(alpha);
+    theta = tridiag_max_eig(al, be);
+    if (iters) *iters = j + 1;
+    const double beta = std::sqrt(std::max(b2, 0.0));
+    if (j >= 4 && std::fabs(theta - theta_prev) <= tol * std::fabs(theta)) break;
+    if (!(beta > 1e-300 * std::max(1.0, std::fabs(theta)))) break;  // invariant subspace
+    theta_prev = theta;
+    be.push_back(beta);
+    hipLaunchKernelGGL((k_axpby<T>), dim3(nb), dim3(256), 0, st, T(0), v[nxt], (T)(1.0 / beta),
+                       v[nxt], (size_t)N);
+    beta_prev = beta;
+    prev = cur;
+    cur = nxt;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  *out = theta;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax,
+                                 int* iterations) {
+  if (!g || !lmax) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (max_iter < 1 || !(tol > 0)) return set_err(GSPX_ERR_INVALID, "max_iter >= 1 and tol > 0");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  return g->dtype == GSPX_F32 ? lanczos_t<float>(g, max_iter, tol, lmax, iterations)
+                              : lanczos_t<double>(g, max_iter, tol, lmax, iterations);
+}
+
+// ------------------------------------------------------------------------------------------------
 // calibration: streaming copy with the engine's own 16-byte-per-lane copy kernel (k_permute_in
 // without a permutation) - the measured HBM ceiling quoted beside every roofline fraction.
 // ------------------------------------------------------------------------------------------------

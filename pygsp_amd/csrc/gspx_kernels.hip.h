@@ -1342,6 +1342,52 @@ __global__ void k_factor(const int* __restrict__ rptr, const int* __restrict__ r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// small vector kernels for the device Lanczos estimate of lambda_max (graph.py:907-920)
+// ---------------------------------------------------------------------------------------------
+// partial[b] = sum over the block's grid-stride elements of x*y (double accumulation)
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot_partial(const T* __restrict__ x, const T* __restrict__ y,
+                                                     size_t n, double* __restrict__ partial) {
+  __shared__ double ws[4];
+  double acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    acc += (double)x[i] * (double)y[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// out[0] = sum(partial[0..n)) in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int n,
+                                                      double* __restrict__ out) {
+  __shared__ double ws[4];
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// y = a*x + b*y
+template <typename T>
+__global__ void k_axpby(T a, const T* __restrict__ x, T b, T* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + b * y[i];
+}
+// deterministic start vector: a fixed hash of the index mapped to [-1, 1)
+template <typename T> __global__ void k_start_vector(T* v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    v[i] = (T)((double)h / 2147483648.0 - 1.0);
+  }
+}
+
 template <typename T> __global__ void k_fill(T* p, size_t n, T v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)

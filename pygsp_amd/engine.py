@@ -249,6 +249,14 @@ class DeviceGraph:
         _capi.check(_capi.load().gspx_graph_download_dw(self._h, _capi.ptr(dw)))
         return dw
 
+    def lanczos_lmax(self, max_iter=60, tol=5e-4):
+        """Largest Ritz value of L after a device Lanczos run: (value, iterations)."""
+        v = ctypes.c_double(0)
+        it = ctypes.c_int(0)
+        _capi.check(_capi.load().gspx_lanczos_lmax(self._h, int(max_iter), float(tol),
+                                                   ctypes.byref(v), ctypes.byref(it)))
+        return v.value, it.value
+
     # ---- the hot path -------------------------------------------------------------------------
     def cheby_filter(self, coeffs, x, lmax, mode=_capi.ANALYSIS):
         """Host arrays in / out.  coeffs: (Nf, M) float64.
