@@ -171,6 +171,45 @@ def cheby_op(G, c, signal, **kwargs):
     return r[:, 0] if one_d else r
 
 
+def cheby_rect(G, bounds, signal, **kwargs):
+    """Ideal band-pass [bounds[0], bounds[1]] by its Chebyshev expansion (approximations.py:117-163):
+    the same recurrence as cheby_op with closed-form coefficients
+    c_0 = 2 (b1 - b2)/pi,  c_k = 2/(k pi) (sin k b1 - sin k b2),  b = arccos(2 bounds/lmax - 1)."""
+    if not (isinstance(bounds, (list, np.ndarray)) and len(bounds) == 2):
+        raise ValueError("Bounds of wrong shape.")
+    bounds = np.array(bounds, dtype=np.float64)
+    order = int(kwargs.pop("order", 30))
+    b1, b2 = np.arccos(2.0 * bounds / G.lmax - 1.0)
+    k = np.arange(1, order + 1)
+    c = np.empty(order + 1)
+    c[0] = 2.0 * (b1 - b2) / np.pi  # cheby_op halves c_0
+    c[1:] = 2.0 / (k * np.pi) * (np.sin(k * b1) - np.sin(k * b2))
+    return cheby_op(G, c, signal, **kwargs)
+
+
+def compute_jackson_cheby_coeff(filter_bounds, delta_lambda, m):
+    """Chebyshev and Jackson-damped coefficients of the ideal band-pass [a, b] on
+    [lambda_min, lambda_max] (approximations.py:166-225).  Unlike the reference this does not
+    rescale the caller's `filter_bounds` list in place."""
+    if delta_lambda[0] > filter_bounds[0] or delta_lambda[1] < filter_bounds[1]:
+        raise ValueError("Bounds of the filter are out of the lambda values")
+    if delta_lambda[0] > delta_lambda[1]:
+        raise ValueError("lambda_min is greater than lambda_max")
+    a1 = (delta_lambda[1] - delta_lambda[0]) / 2
+    a2 = (delta_lambda[1] + delta_lambda[0]) / 2
+    lo = (filter_bounds[0] - a2) / a1
+    hi = (filter_bounds[1] - a2) / a1
+    ch = np.empty(m + 1, dtype=float)
+    ch[0] = (2 / np.pi) * (np.arccos(lo) - np.arccos(hi))
+    i = np.arange(1, m + 1)
+    ch[1:] = (2 / (np.pi * i)) * (np.sin(i * np.arccos(lo)) - np.sin(i * np.arccos(hi)))
+    alpha = np.pi / (m + 2)
+    i = np.arange(m + 1)
+    jch = (1 / np.sin(alpha)) * ((1 - i / (m + 2)) * np.sin(alpha) * np.cos(i * alpha)
+                                + (1 / (m + 2)) * np.cos(alpha) * np.sin(i * alpha))
+    return ch, ch * jch
+
+
 def _device_graph_of(G):
     """The libgspx graph of `G`: our own Graph builds it on device from W; a reference
     pygsp.graphs.Graph (plugin mode) gets one attached lazily from its host-built G.L."""

@@ -79,6 +79,14 @@ def sensor123():
     # low orders (order=1, 2 work; order=0 raises TypeError)
     out["heat10_order1"] = g.filter(sig, method="chebyshev", order=1)
     out["heat10_order2"] = g.filter(sig, method="chebyshev", order=2)
+    # same-recurrence siblings (approximations.py:117-225)
+    from pygsp.filters import approximations as apx
+    b = [0.2 * G.lmax, 0.6 * G.lmax]
+    out["rect_bounds"] = np.array(b)
+    out["rect_y"] = apx.cheby_rect(G, list(b), sig, order=30)
+    out["rect_y5"] = apx.cheby_rect(G, list(b), sigs, order=25)
+    ch, jch = apx.compute_jackson_cheby_coeff(list(b), [0, G.lmax], 30)
+    out["jackson_ch"], out["jackson_jch"] = ch, jch
     # normalized Laplacian
     G.compute_laplacian("normalized")
     out.update(csr_parts(G.L, "Lnorm"))

@@ -654,3 +654,12 @@ def test_device_lanczos_lmax(golden_logo, dtype):
     assert abs(Gl.lmax - 13.92) < 0.05
     with pytest.raises(ValueError):
         Gl.estimate_lmax("fancy")
+
+
+def test_cheby_rect_golden(golden_sensor123):
+    """approximations.py:117-163: ideal band-pass, same recurrence, closed-form coefficients."""
+    g = golden_sensor123
+    G = graphs.Graph(csr_from(g, "W"))
+    G._lmax = float(g["lmax"])
+    assert rel_err(filters.cheby_rect(G, list(g["rect_bounds"]), g["signal"], order=30), g["rect_y"]) < 1e-12
+    assert rel_err(filters.cheby_rect(G, g["rect_bounds"], g["signals5"], order=25), g["rect_y5"]) < 1e-12

@@ -168,3 +168,17 @@ def test_newton_form_is_the_same_polynomial(golden_sensor123):
         filters.cheb_to_newton(np.array([1.0]))
     with pytest.raises(ValueError):
         filters.set_evaluation("fancy")
+
+
+def test_jackson_coefficients(golden_sensor123):
+    g = golden_sensor123
+    b = list(g["rect_bounds"])
+    keep = list(b)
+    ch, jch = filters.compute_jackson_cheby_coeff(b, [0, float(g["lmax"])], 30)
+    np.testing.assert_allclose(ch, g["jackson_ch"], rtol=1e-13, atol=1e-16)
+    np.testing.assert_allclose(jch, g["jackson_jch"], rtol=1e-13, atol=1e-16)
+    assert b == keep  # the caller's list is left alone
+    with pytest.raises(ValueError):
+        filters.compute_jackson_cheby_coeff([0.1, 5.0], [0.0, 2.0], 10)
+    with pytest.raises(ValueError):
+        filters.cheby_rect(None, [1.0], np.ones(3))

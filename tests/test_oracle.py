@@ -110,3 +110,10 @@ def test_doctest_value(golden_doctest):
     s3 = orc.filter_chebyshev(L, lmax, mh, s2, 30)
     assert rel_err(s2, g["s2"]) < 1e-13
     assert "{:.5f}".format(np.linalg.norm(g["s1"] - s3)) == "0.27649"
+
+
+def test_cheby_rect(golden_sensor123):
+    g = golden_sensor123
+    L, lmax = csr_from(g, "Lcomb"), float(g["lmax"])
+    assert rel_err(orc.cheby_rect(L, lmax, g["rect_bounds"], g["signal"], 30), g["rect_y"]) < 1e-14
+    assert rel_err(orc.cheby_rect(L, lmax, g["rect_bounds"], g["signals5"], 25), g["rect_y5"]) < 1e-14
