@@ -953,7 +953,14 @@ template <typename T> static int ensure_factor(gspx_graph* g, double lmax) {
   return GSPX_OK;
 }
 
-static hipEvent_t pool_event(gspx_ctx* ctx, size_t i) {
+static hipEvent_t pool_event(gspx_ctx* ctx, size_t& i_ref) {
+  // at most 1024 timing events per call: calls split into more batches than that (huge panels)
+  // reuse the last quadruple - their per-phase timings are then only a lower bound
+  size_t i = i_ref - 1;
+  if (i >= 1024) {
+    i = 1020 + (i & 3);
+    i_ref = i + 1;
+  }
   while (ctx->ev_pool.size() <= i) {
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
@@ -1007,8 +1014,8 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   T* slots = ctx->ws_t.as<T>();
   T* racc = ctx->ws_r.as<T>();
 
-  hipEvent_t e0 = pool_event(ctx, ev_idx++), e1 = pool_event(ctx, ev_idx++),
-             e2 = pool_event(ctx, ev_idx++), e3 = pool_event(ctx, ev_idx++);
+  hipEvent_t e0 = pool_event(ctx, ++ev_idx), e1 = pool_event(ctx, ++ev_idx),
+             e2 = pool_event(ctx, ++ev_idx), e3 = pool_event(ctx, ++ev_idx);
   if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
 
   HIPCHK(hipEventRecord(e0, st));
@@ -1195,8 +1202,8 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
   T* S = ctx->ws_r.as<T>();
   T* B[2] = {ctx->ws_t.as<T>(), ctx->ws_t.as<T>() + U};
 
-  hipEvent_t e0 = pool_event(ctx, ev_idx++), e1 = pool_event(ctx, ev_idx++),
-             e2 = pool_event(ctx, ev_idx++), e3 = pool_event(ctx, ev_idx++);
+  hipEvent_t e0 = pool_event(ctx, ++ev_idx), e1 = pool_event(ctx, ++ev_idx),
+             e2 = pool_event(ctx, ++ev_idx), e3 = pool_event(ctx, ++ev_idx);
   if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
   HIPCHK(hipEventRecord(e0, st));
   for (int f = 0; f < nf; ++f) {
@@ -1292,8 +1299,8 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   T* X = ctx->ws_t.as<T>();
   T* H[2] = {X + U, X + 2 * U};
 
-  hipEvent_t e0 = pool_event(ctx, ev_idx++), e1 = pool_event(ctx, ev_idx++),
-             e2 = pool_event(ctx, ev_idx++), e3 = pool_event(ctx, ev_idx++);
+  hipEvent_t e0 = pool_event(ctx, ++ev_idx), e1 = pool_event(ctx, ++ev_idx),
+             e2 = pool_event(ctx, ++ev_idx), e3 = pool_event(ctx, ++ev_idx);
   if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
   HIPCHK(hipEventRecord(e0, st));
   int pvec = shape.vec;

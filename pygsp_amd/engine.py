@@ -5,6 +5,7 @@ pygsp_amd/csrc.  Vertex reordering (a graph-setup step, like building the Laplac
 only host-side preparation, see ``locality_order``.
 """
 import ctypes
+import sys
 import threading
 
 import numpy as np
@@ -24,15 +25,11 @@ class Context:
         self.device = int(device)
 
     def close(self):
+        """Explicit teardown.  (No __del__: graphs and buffers hold a pointer to their context, so
+        a context must outlive them; default contexts simply live until the process exits.)"""
         if getattr(self, "_h", None):
             _capi.load().gspx_ctx_destroy(self._h)
             self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def set_option(self, key, value):
         _capi.check(_capi.load().gspx_ctx_set_option(self._h, key.encode(), int(value)))
@@ -97,6 +94,8 @@ class DeviceBuffer:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may already be gone; the OS reclaims the memory
+            return
         try:
             self.free()
         except Exception:
@@ -210,6 +209,8 @@ class DeviceGraph:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.destroy()
         except Exception:
