@@ -64,7 +64,7 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *                 (one row per wave, all metadata scalar)
  *   "vec"         0 auto, else elements per lane (1,2,4)
  *   "rows_per_wave"  consecutive rows per wave (0 = auto)
- *   "narrow_g_log2"  narrow kernel: log2 of lanes splitting one row's entries
+ *   "narrow_g_log2"  narrow kernel: log2 of lanes splitting one row's entries (-1 = auto)
  *   "xcd_remap"   1 (default) contiguous row ranges per XCD, 0 plain order
  *   "synthesis"   0 (default) vector-coefficient Clenshaw: K sparse products for any Nf;
  *                 1 the reference's per-filter loop (K*Nf products)

@@ -96,7 +96,7 @@ struct Options {
   int64_t kernel = 0;         // 0 auto, 1 panel, 2 narrow
   int64_t vec = 0;            // 0 auto
   int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
-  int64_t narrow_g_log2 = 2;
+  int64_t narrow_g_log2 = -1;  // -1 = auto (4 lanes per row in total)
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
@@ -240,8 +240,8 @@ extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value
   if (!s) return set_err(GSPX_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
   if (!strcmp(key, "rows_per_wave") && (value < 0 || value > 1024))
     return set_err(GSPX_ERR_INVALID, "rows_per_wave must be in [0, 1024] (0 = auto)");
-  if (!strcmp(key, "narrow_g_log2") && (value < 0 || value > 6))
-    return set_err(GSPX_ERR_INVALID, "narrow_g_log2 must be in [0, 6]");
+  if (!strcmp(key, "narrow_g_log2") && (value < -1 || value > 6))
+    return set_err(GSPX_ERR_INVALID, "narrow_g_log2 must be in [-1, 6] (-1 = auto)");
   if (!strcmp(key, "waves_per_block") && !(value == 4 || value == 8 || value == 16))
     return set_err(GSPX_ERR_INVALID, "waves_per_block must be 4, 8 or 16");
   if (!strcmp(key, "vec") && !(value == 0 || value == 1 || value == 2 || value == 4))
@@ -766,7 +766,9 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
     int wl = 0;
     while ((1 << wl) < ld) ++wl;
     s.wlog2 = wl;
-    s.glog2 = (int)std::min<int64_t>(opt.narrow_g_log2, 6 - wl);
+    // auto: 4 lanes per row in total (measured best on the cache-resident config 1)
+    const int64_t gl = opt.narrow_g_log2 >= 0 ? opt.narrow_g_log2 : std::max(0, 2 - wl);
+    s.glog2 = (int)std::min<int64_t>(gl, 6 - wl);
     s.gridy = 1;
   }
   return s;
@@ -842,7 +844,8 @@ template <typename T>
 static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st,
                         const unsigned* coff) {
   int rpw = (int)opt.rows_per_wave;
-  if (rpw <= 0) rpw = (s.kernel == 5) ? (sizeof(T) == 4 ? 16 : 8) : (s.kernel == 4 ? 8 : 4);
+  if (rpw <= 0)
+    rpw = (s.kernel == 5) ? (sizeof(T) == 4 ? 16 : 8) : (s.kernel == 4 ? 8 : (s.kernel == 2 ? 1 : 4));
   if (s.kernel == 1 || s.kernel == 5) {
     const int R = 64 >> s.wlog2;  // rows per row set
     rpw = ((rpw + R - 1) / R) * R;

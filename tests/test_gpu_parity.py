@@ -24,7 +24,7 @@ def ctx():
     c = engine.default_context(0)
     yield c
     for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 0), ("xcd_remap", 1),
-                     ("combine", 0), ("max_batch", 0), ("narrow_g_log2", 2)):
+                     ("combine", 0), ("max_batch", 0), ("narrow_g_log2", -1)):
         c.set_option(key, val)
 
 
@@ -340,7 +340,7 @@ def test_kernel_variants_agree(ctx, dtype):
             y, _ = dev.cheby_filter(c, x[:, :16], lmax)
             assert rel_err(y[0], ref[:, :16]) < tol, g
         ctx.set_option("kernel", 0)
-        ctx.set_option("narrow_g_log2", 2)
+        ctx.set_option("narrow_g_log2", -1)
         # signal batching: 64 signals in batches of 24 (24 + 24 + 16)
         ctx.set_option("max_batch", 24)
         y, _ = dev.cheby_filter(c, x, lmax)
@@ -351,7 +351,7 @@ def test_kernel_variants_agree(ctx, dtype):
         assert rel_err(y3, ref3) < tol
     finally:
         for key, val in (("kernel", 0), ("vec", 0), ("rows_per_wave", 0), ("xcd_remap", 1),
-                         ("max_batch", 0), ("narrow_g_log2", 2)):
+                         ("max_batch", 0), ("narrow_g_log2", -1)):
             ctx.set_option(key, val)
         dev.destroy()
 
