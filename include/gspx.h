@@ -169,6 +169,9 @@ int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int
  * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */
 int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);
 
+/* Calibration: read-only GB/s of a `bytes`-sized buffer streamed `passes` times in one launch. */
+int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
+
 #ifdef __cplusplus
 }
 #endif

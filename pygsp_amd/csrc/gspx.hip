@@ -98,6 +98,7 @@ struct Options {
   int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
   int64_t narrow_g_log2 = -1;  // -1 = auto (4 lanes per row in total)
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
+  int64_t interleave = 0;       // panel kernel: waves of a workgroup advance as one front
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
@@ -224,6 +225,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "rows_per_wave")) return &o.rows_per_wave;
   if (!strcmp(key, "narrow_g_log2")) return &o.narrow_g_log2;
   if (!strcmp(key, "waves_per_block")) return &o.waves_per_block;
+  if (!strcmp(key, "interleave")) return &o.interleave;
   if (!strcmp(key, "alternate_sweep")) return &o.alternate_sweep;
   if (!strcmp(key, "synthesis")) return &o.synthesis;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
@@ -856,6 +858,7 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
   if (s.kernel == 4 && rpw > 32) rpw = 32;
   a.rows_per_wave = rpw;
   a.wpb = (s.kernel == 1) ? (int)opt.waves_per_block : 4;
+  a.interleave = (s.kernel == 1 && opt.interleave) ? 1 : 0;
   if (s.kernel == 1 || s.kernel >= 3)
     rows_per_chunk = a.wpb * rpw;
   else
@@ -1665,5 +1668,32 @@ extern "C" int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* 
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
   *gbps = 2.0 * (double)rows * ld * sizeof(float) * iters / (ms * 1e-3) / 1e9;
+  return GSPX_OK;
+}
+
+// calibration: read-only bandwidth of a `bytes`-sized buffer streamed `passes` times inside one
+// launch (cache-level bandwidth as seen by the CUs)
+extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps) {
+  if (!ctx || !gbps || bytes < 4096 || passes < 1)
+    return set_err(GSPX_ERR_INVALID, "gspx_bench_read: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevMem a, sink;
+  CHK(a.alloc((size_t)bytes));
+  CHK(sink.alloc(64));
+  const size_t n4 = (size_t)bytes / 16;
+  hipLaunchKernelGGL((k_fill<float>), dim3(4096), dim3(256), 0, ctx->stream, a.as<float>(), n4 * 4,
+                     1.0f);
+  const unsigned nb = (unsigned)std::min<size_t>((n4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_read_loop, dim3(nb), dim3(256), 0, ctx->stream, (const float4*)a.p, n4, 1,
+                     sink.as<float>());
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+  hipLaunchKernelGGL(k_read_loop, dim3(nb), dim3(256), 0, ctx->stream, (const float4*)a.p, n4,
+                     passes, sink.as<float>());
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+  *gbps = (double)n4 * 16.0 * passes / (ms * 1e-3) / 1e9;
   return GSPX_OK;
 }

@@ -156,6 +156,9 @@ template <typename T> struct StepArgs {
   // row -> workgroup mapping
   int rows_per_wave;
   int wpb;          // waves per workgroup (panel kernel: 4, 8 or 16)
+  int interleave;   // panel kernel: 1 = the workgroup's waves advance through its rows as one
+                    // front (wave w takes row sets w, w+wpb, ...), 0 = each wave owns a
+                    // contiguous run of rows
   int nchunks;      // number of (wpb*rows_per_wave)-row chunks
   int cpx;          // chunks per XCD (xcd_remap) or 0 for plain order
   int reverse;      // 1: sweep the rows from the end (alternate steps: the tail of the previous
@@ -246,6 +249,7 @@ template <typename T, int VEC> struct PanelCtx {
   int r;          // this lane's row within the set
   LaneSel sel;
   int row0;       // first row of this wave
+  int set_stride; // rows between consecutive sets of this wave
   int nsets;
   bool lane_on;
 };
@@ -265,7 +269,7 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   typedef typename X::t V;
   constexpr bool FLUSH = MODE == 1;
   constexpr bool SELF = MODE != 0;
-  const int srow = __builtin_amdgcn_readfirstlane(c.row0 + it * R);
+  const int srow = __builtin_amdgcn_readfirstlane(c.row0 + it * c.set_stride);
   if (srow >= a.N) return false;
   // rowptr is padded past N with the total entry count, so rows >= N read as empty
   // (low 2 bits of a rowptr entry carry that row's pad count; starts are multiples of 4)
@@ -350,7 +354,7 @@ __device__ __forceinline__ bool panel_row_set(const PanelCtx<T, VEC>& c, const S
   // that the compiler's vmcnt bookkeeping is exact and the final FMA does not wait for it.
   issue_pair(k);
   {
-    const int nrow = myrow + R;
+    const int nrow = myrow + c.set_stride;
     const bool pf_on = (it + 1 < c.nsets) && nrow < a.N;
     const u32 po = pf_on ? (u32)nrow * c.ldb + c.lane_off : GSPX_POISON;
     ov_pf = X::sload(c.rold, po);
@@ -441,7 +445,9 @@ __global__ __launch_bounds__(1024) void k_step_panel(const int* __restrict__ row
   c.rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
   c.rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
   c.rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
-  c.row0 = (chunk * a.wpb + wave) * a.rows_per_wave;
+  c.row0 = a.interleave ? chunk * a.wpb * a.rows_per_wave + wave * R
+                        : (chunk * a.wpb + wave) * a.rows_per_wave;
+  c.set_stride = a.interleave ? a.wpb * R : R;
   c.nsets = a.rows_per_wave / R;
 
   if (c.row0 >= a.N) return;
@@ -1386,6 +1392,20 @@ template <typename T> __global__ void k_start_vector(T* v, size_t n) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     v[i] = (T)((double)h / 2147483648.0 - 1.0);
   }
+}
+
+// calibration: every workgroup streams the same `n4` float4s `passes` times (read-only), so the
+// data is served by whichever cache level holds `16*n4` bytes
+__global__ __launch_bounds__(256) void k_read_loop(const float4* __restrict__ p, size_t n4, int passes,
+                                                   float* __restrict__ sink) {
+  float acc = 0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (int r = 0; r < passes; ++r)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 v = p[i];
+      acc += v.x + v.y + v.z + v.w;
+    }
+  if (acc == 123456.789f) sink[0] = acc;  // keep the loads alive
 }
 
 template <typename T> __global__ void k_fill(T* p, size_t n, T v) {

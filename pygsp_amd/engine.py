@@ -58,6 +58,12 @@ class Context:
         _capi.check(_capi.load().gspx_bench_copy(self._h, int(nbytes), int(iters), ctypes.byref(v)))
         return v.value
 
+    def bench_read(self, nbytes, passes=50):
+        """Read-only GB/s of an nbytes buffer streamed `passes` times in one launch."""
+        v = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_bench_read(self._h, int(nbytes), int(passes), ctypes.byref(v)))
+        return v.value
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         buf = DeviceBuffer(self, arr.nbytes)
