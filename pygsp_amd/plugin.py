@@ -28,8 +28,8 @@ def device_graph_for(G):
     ctx = engine.default_context(_config["device"])
     perm = None
     coords = getattr(G, "coords", None)
-    if _config["reorder"] == "auto" and coords is not None and G.N >= 4096:
-        perm = engine.locality_order(G.W, coords)
+    if _config["reorder"] == "auto" and G.N >= 4096:
+        perm = engine.auto_order(G.W, coords)
     elif _config["reorder"] == "rcm":
         perm = engine.locality_order(G.W, None)
     if _config["laplacian"] == "device":

@@ -182,3 +182,13 @@ def test_jackson_coefficients(golden_sensor123):
         filters.compute_jackson_cheby_coeff([0.1, 5.0], [0.0, 2.0], 10)
     with pytest.raises(ValueError):
         filters.cheby_rect(None, [1.0], np.ones(3))
+
+
+def test_auto_order_keeps_already_local_graphs():
+    W, coords = graphs.sensor_weights(20000, k=6, seed=5)
+    assert engine.auto_order(W, coords) is not None          # random vertex order -> Morton
+    assert engine.auto_order(W, None) is not None            # no coordinates -> RCM helps
+    perm = engine.locality_order(W, coords)
+    Wm = W[perm][:, perm].tocsr()                            # already Morton-ordered graph
+    assert engine.auto_order(Wm, None) is None               # RCM would not improve it
+    assert engine.locality_score(Wm) > 0.95 > engine.locality_score(W) + 0.3

@@ -58,12 +58,17 @@ G = graphs.Sensor(100000, seed=42, compute_dtype=np.float64)
 run("C1 Sensor(1e5) comb, Heat K=30, 1 signal", G, filters.Heat(G, 50), None, 1, 30, np.float64, reps=20)
 N = 1000000
 for dt in (np.float32,):
-    G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=dt)
-    run("C2 ER(1e6, p=1e-5), MexicanHat x6 K=50, 64 signals", G, filters.MexicanHat(G, Nf=6), None, 64, 50, dt, reps=3)
+    for ro in ("auto", "none"):
+        G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=dt, reorder=ro)
+        run("C2 ER(1e6, p=1e-5), MexicanHat x6 K=50, 64 signals [reorder=%s]" % ro, G,
+            filters.MexicanHat(G, Nf=6), None, 64, 50, dt, reps=3)
 N, k = 2000000, 16
 for dt in (np.float64, np.float32):
-    G = graphs.StochasticBlockModel(N, k=k, p=9.6e-5, q=2.13e-6, seed=0, lap_type="normalized", compute_dtype=dt)
-    run("C3 SBM(2e6, k=16) normalized, Heat K=30, 16 signals", G, filters.Heat(G, 10), None, 16, 30, dt, reps=3)
+    for ro in ("auto", "none"):
+        G = graphs.StochasticBlockModel(N, k=k, p=9.6e-5, q=2.13e-6, seed=0, lap_type="normalized",
+                                        compute_dtype=dt, reorder=ro)
+        run("C3 SBM(2e6, k=16) normalized, Heat K=30, 16 signals [reorder=%s]" % ro, G,
+            filters.Heat(G, 10), None, 16, 30, dt, reps=3)
 for dt in (np.float64, np.float32):
     G = graphs.Sensor(500000, seed=0, compute_dtype=dt)
     run("C4 (one rank) Sensor(5e5), Heat K=30, 32 signals", G, filters.Heat(G, 50), None, 32, 30, dt)
