@@ -73,7 +73,6 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "waves_per_block" 4 (default), 8 or 16 waves per workgroup (kernel 1)
  *   "ws_limit_mb" / "max_batch"  workspace budget / cap on signals per batch
  *   "combine"     0 auto, 1 fused flush every 3rd step, 2 deferred combine (keep all T_k)
- *   "graph_launch" 1 capture the K-step loop in a hipGraph (default 0)
  */
 int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value);
 int gspx_ctx_get_option(gspx_ctx* ctx, const char* key, int64_t* value);

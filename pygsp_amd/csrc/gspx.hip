@@ -103,7 +103,6 @@ struct Options {
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
   int64_t combine = 0;        // 0 auto, 1 fused flush, 2 deferred
-  int64_t graph_launch = 0;
   int64_t ws_limit_mb = 65536;  // workspace budget per filter call
   int64_t max_batch = 0;        // 0 = no extra cap on signals per batch
 };
@@ -230,7 +229,6 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "synthesis")) return &o.synthesis;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
-  if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
   if (!strcmp(key, "max_batch")) return &o.max_batch;
   return nullptr;

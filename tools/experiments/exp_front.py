@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import sys; sys.path.insert(0,'.')  # run from the repo root
 import numpy as np
 from pygsp_amd import engine, graphs, filters
 
