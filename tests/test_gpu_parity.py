@@ -663,3 +663,66 @@ def test_cheby_rect_golden(golden_sensor123):
     G._lmax = float(g["lmax"])
     assert rel_err(filters.cheby_rect(G, list(g["rect_bounds"]), g["signal"], order=30), g["rect_y"]) < 1e-12
     assert rel_err(filters.cheby_rect(G, g["rect_bounds"], g["signals5"], order=25), g["rect_y5"]) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases: tiny graphs, very long rows (LDS kernel's unstaged path, chunk loops), options API
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tiny_graphs_and_huge_hub(ctx, dtype):
+    tol = TOL[np.dtype(dtype)] * 10
+    rng = np.random.default_rng(11)
+    # N = 1, 2, 3 (including an isolated vertex and a lone self loop)
+    for W in (np.zeros((1, 1)), np.array([[0.0, 2.0], [2.0, 0.0]]),
+              np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.5]])):
+        n = W.shape[0]
+        L = orc.laplacian(W)
+        dev = engine.DeviceGraph.from_w(W, dtype=dtype, ctx=ctx)
+        for nsig in (1, 5, 64):
+            x = rng.standard_normal((n, nsig))
+            c = orc.compute_cheby_coeff(orc.heat_kernel(2, 5.0), 5.0, 7)
+            y, _ = dev.cheby_filter(c, x, 5.0)
+            ref = orc.cheby_op(L, 5.0, c, x.astype(dtype).astype(np.float64))
+            assert np.max(np.abs(y[0] - ref)) < tol * max(1.0, np.max(np.abs(ref)))
+        dev.destroy()
+    # a hub with 3000 neighbours: rows far longer than the LDS slice / the prefetched chunks
+    n = 6000
+    r = np.zeros(3000, dtype=np.int64)
+    c_ = rng.choice(n - 1, size=3000, replace=False) + 1
+    hub = sparse.coo_matrix((rng.uniform(0.1, 1, 3000), (r, c_)), shape=(n, n)).tocsr()
+    W = random_graph(n, 6, seed=12) + hub + hub.T
+    W = sparse.csr_matrix(W)
+    W.sum_duplicates()
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    cc = orc.compute_cheby_coeff(orc.heat_kernel(30, lmax), lmax, 20)
+    nodes, d = filters.cheb_to_newton(cc)
+    for perm in (None, rng.permutation(n).astype(np.int32)):
+        dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+        for nsig in (1, 16, 64):
+            x = rng.standard_normal((n, nsig))
+            ref = orc.cheby_op(L, lmax, cc, x.astype(dtype).astype(np.float64))
+            for kern in (0, 1, 5) if nsig > 4 else (0,):
+                ctx.set_option("kernel", kern)
+                y, _ = dev.cheby_filter(cc, x, lmax)
+                assert rel_err(y[0], ref) < tol, (nsig, kern)
+                y, _ = dev.newton_filter(nodes, d, x, lmax)
+                assert rel_err(y, ref) < tol, (nsig, kern, "newton")
+            ctx.set_option("kernel", 0)
+        dev.destroy()
+
+
+def test_options_api(ctx):
+    assert ctx.get_option("xcd_remap") == 1 and ctx.get_option("alternate_sweep") == 1
+    ctx.set_option("rows_per_wave", 8)
+    assert ctx.get_option("rows_per_wave") == 8
+    ctx.set_option("rows_per_wave", 0)
+    for key, bad in (("vec", 3), ("waves_per_block", 5), ("rows_per_wave", -1), ("narrow_g_log2", 9)):
+        with pytest.raises(ValueError):
+            ctx.set_option(key, bad)
+    with pytest.raises(ValueError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        ctx.get_option("no_such_option")
+    assert ctx.bench_copy(64 << 20, 3) > 100.0  # GB/s: sanity of the calibration kernels
+    assert ctx.bench_read(8 << 20, 20) > 100.0
