@@ -145,6 +145,17 @@ int gspx_newton_filter_dev(gspx_graph* g, double lmax, int K, const double* node
 int gspx_newton_filter(gspx_graph* g, double lmax, int K, const double* nodes, const double* dcoef,
                        int64_t Nsig, const void* x_host, void* y_host, double* kernel_ms);
 
+/* Optional acceleration structure for gspx_newton_filter*: two-level row tiles (32-row blocks) of
+ * the internal vertex order, computed on the host from the internal pattern
+ * (pygsp_amd/tiling.py).  With tiles set (and option "newton_pair" = 1, the default) two Horner
+ * steps run per launch with the panel staged in LDS: the pass moves fewer bytes than the
+ * algorithmic count of two steps.  block_rows == 0 drops the tiles. */
+int gspx_graph_download_internal(gspx_graph* g, int32_t* rowptr, int32_t* col);
+int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
+                         const int32_t* s1rows, const int32_t* s2ptr, const int32_t* s2rows,
+                         const uint16_t* lidx1, const uint32_t* occ_off, int64_t n_lidx2,
+                         const uint16_t* lidx2, int max_n1, int max_n2);
+
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
  *   out[0] total device time, out[1] time inside the recurrence-step launches only,
  *   out[2] number of step launches, out[3] permute-in/copy time, out[4] combine time */

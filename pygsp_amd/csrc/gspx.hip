@@ -99,6 +99,7 @@ struct Options {
   int64_t narrow_g_log2 = -1;  // -1 = auto (4 lanes per row in total)
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
   int64_t interleave = 0;       // panel kernel: waves of a workgroup advance as one front
+  int64_t newton_pair = 1;      // use the fused two-step kernel when the graph carries tiles
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
@@ -142,6 +143,9 @@ struct gspx_graph {
   int coff_pad_self = -1;
   DevMem perm, iperm;
   bool has_perm = false;
+  // two-level row tiles of the fused Newton-pair kernel (optional; pygsp_amd/tiling.py)
+  DevMem t_s1ptr, t_s1rows, t_s2ptr, t_s2rows, t_lidx1, t_occ, t_lidx2;
+  int tile_rows = 0, tile_nb = 0, tile_max_n1 = 0, tile_max_n2 = 0;
   double fval_lmax = -1.0;
   double build_ms = 0.0;
 };
@@ -227,6 +231,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "interleave")) return &o.interleave;
   if (!strcmp(key, "alternate_sweep")) return &o.alternate_sweep;
   if (!strcmp(key, "synthesis")) return &o.synthesis;
+  if (!strcmp(key, "newton_pair")) return &o.newton_pair;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
@@ -627,6 +632,53 @@ extern "C" int gspx_graph_download_dw(gspx_graph* g, void* dw) {
   HIPCHK(hipSetDevice(g->ctx->device));
   if (g->N > 0)
     HIPCHK(hipMemcpy(dw, g->dw.p, (size_t)g->N * elt_size(g->dtype), hipMemcpyDeviceToHost));
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_download_internal(gspx_graph* g, int32_t* rowptr, int32_t* col) {
+  if (!g || !rowptr) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (g->nnz_int > 0 && !col) return set_err(GSPX_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipMemcpy(rowptr, g->rptr.p, (size_t)(g->N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (g->nnz_int > 0)
+    HIPCHK(hipMemcpy(col, g->rcol.p, (size_t)g->nnz_int * sizeof(int), hipMemcpyDeviceToHost));
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
+                                    const int32_t* s1rows, const int32_t* s2ptr,
+                                    const int32_t* s2rows, const uint16_t* lidx1,
+                                    const uint32_t* occ_off, int64_t n_lidx2, const uint16_t* lidx2,
+                                    int max_n1, int max_n2) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (block_rows == 0) {  // drop the tiles
+    g->tile_rows = 0;
+    return GSPX_OK;
+  }
+  if (block_rows != 32) return set_err(GSPX_ERR_INVALID, "tiles must use 32-row blocks");
+  if (!s1ptr || !s1rows || !s2ptr || !s2rows || !lidx1 || !occ_off || !lidx2 || nb < 1 ||
+      nb != (int)((g->N + block_rows - 1) / block_rows) || max_n1 < 1 || max_n2 < max_n1)
+    return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: bad argument");
+  const int n_s1 = s1ptr[nb], n_s2 = s2ptr[nb];
+  HIPCHK(hipSetDevice(g->ctx->device));
+  CHK(g->t_s1ptr.alloc((size_t)(nb + 1) * 4));
+  CHK(g->t_s2ptr.alloc((size_t)(nb + 1) * 4));
+  CHK(g->t_s1rows.alloc((size_t)n_s1 * 4));
+  CHK(g->t_s2rows.alloc((size_t)n_s2 * 4));
+  CHK(g->t_lidx1.alloc((size_t)g->nnz_int * 2 + 64));
+  CHK(g->t_occ.alloc((size_t)(n_s1 + 1) * 4));
+  CHK(g->t_lidx2.alloc((size_t)n_lidx2 * 2 + 64));
+  HIPCHK(hipMemcpy(g->t_s1ptr.p, s1ptr, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_s2ptr.p, s2ptr, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_s1rows.p, s1rows, (size_t)n_s1 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_s2rows.p, s2rows, (size_t)n_s2 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_lidx1.p, lidx1, (size_t)g->nnz_int * 2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_occ.p, occ_off, (size_t)(n_s1 + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_lidx2.p, lidx2, (size_t)n_lidx2 * 2, hipMemcpyHostToDevice));
+  g->tile_rows = block_rows;
+  g->tile_nb = nb;
+  g->tile_max_n1 = max_n1;
+  g->tile_max_n2 = max_n2;
   return GSPX_OK;
 }
 
@@ -1337,7 +1389,67 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   a.perm = perm;
   a.wts = ctx->ws_w.as<T>();
   a.old = X;
+
+  // fused two-step kernel: needs tiles, 16-byte lanes on every panel it touches, and an LDS
+  // footprint (h tile on S2 + g tile on S1, 256-byte row chunks) the CU can hold
+  constexpr int PVEC = 16 / (int)sizeof(T);
+  const size_t pair_lds = ((size_t)g->tile_max_n1 + (size_t)g->tile_max_n2) * 256;
+  const bool pair_ok = opt.newton_pair && g->tile_rows == 32 && K >= 2 && (ld % PVEC) == 0 &&
+                       (ldy % PVEC) == 0 && (((uintptr_t)y / sizeof(T)) % PVEC) == 0 &&
+                       pair_lds <= 160 * 1024;
+  auto step_params = [&](int s, T& sc, T& be, T& ga) {
+    const int j = K - 1 - s;
+    if (s == 0) {
+      sc = (T)(0.5 * dc[K]);
+      be = T(0);
+      ga = (T)(dc[j] - dc[K] * nodes[j]);
+    } else {
+      sc = T(0.5);
+      be = (T)(-nodes[j]);
+      ga = (T)dc[j];
+    }
+  };
+  int s_first_pair = K;  // steps >= this index run as fused pairs
+  if (pair_ok) s_first_pair = K & 1;
+  int pair_cur = (pair_ok && (K & 1)) ? 0 : -1;  // panel holding h before the next pair (-1 = X)
+  if (pair_ok) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_newton_pair<T>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
+  }
   for (int s = 0; s < K; ++s) {
+    if (s >= s_first_pair) {
+      PairArgs<T> p{};
+      p.rowptr = g->rptr.as<int>();
+      p.fval = g->fval.as<T>();
+      p.s1ptr = g->t_s1ptr.as<int>();
+      p.s1rows = g->t_s1rows.as<int>();
+      p.s2ptr = g->t_s2ptr.as<int>();
+      p.s2rows = g->t_s2rows.as<int>();
+      p.lidx1 = g->t_lidx1.as<unsigned short>();
+      p.occ_off = g->t_occ.as<unsigned>();
+      p.lidx2 = g->t_lidx2.as<unsigned short>();
+      // the pair reads h on other blocks' rows too, so it never writes the panel it reads
+      const int out_buf = (pair_cur == 0) ? 1 : 0;
+      p.h_in = (pair_cur < 0) ? X : H[pair_cur];
+      p.x = X;
+      p.h_out = H[out_buf];
+      pair_cur = out_buf;
+      p.N = N;
+      p.ld = ld;
+      p.block_rows = 32;
+      p.max_n2 = g->tile_max_n2;
+      step_params(s, p.sA, p.bA, p.gA);
+      step_params(s + 1, p.sB, p.bB, p.gB);
+      p.final = (s + 1 == K - 1) ? 1 : 0;
+      p.y = y;
+      p.ldy = ldy;
+      p.perm = perm;
+      const unsigned gy = (unsigned)(((size_t)ld * sizeof(T) + 255) / 256);
+      hipLaunchKernelGGL((k_newton_pair<T>), dim3((unsigned)g->tile_nb, gy, 1), dim3(512), pair_lds,
+                         st, p);
+      ++s;  // two steps done
+      continue;
+    }
     const int j = K - 1 - s;
     a.cur = (s == 0) ? X : H[(s - 1) & 1];
     a.out = H[s & 1];

@@ -1029,6 +1029,133 @@ __global__ __launch_bounds__(256) void k_step_lds(const int* __restrict__ rowptr
 }
 
 // ---------------------------------------------------------------------------------------------
+// FUSED NEWTON PAIR: two Horner steps of the Newton-form evaluation in ONE pass over the panel.
+//     g  = sA (F h)[r] + bA h[r] + gA x[r]      for r in S1 = 1-hop closure of the block's rows
+//     h' = sB (F g)[i] + bB g[i] + gB x[i]      for the block's own rows i
+// h is staged once in LDS on the 2-hop closure S2, g lives only in LDS: per TWO polynomial orders
+// a panel row is read ~once (plus halo) and written once, where two separate steps read it twice
+// as a gather source, stream x twice and write twice.  This is the temporally blocked form the
+// HBM-bound analysis in DESIGN.md asks for: it moves fewer bytes than the algorithmic count.
+// Tiles (S1, S2, 16-bit local indices) come from pygsp_amd/tiling.py.
+//   workgroup = 512 threads = 32 groups of 16 lanes x 16 bytes (one 256-byte row chunk per group);
+//   blockIdx.y walks the 256-byte column chunks of wider panels.
+// ---------------------------------------------------------------------------------------------
+#define GSPX_PAD16 0xFFFFu
+typedef unsigned short u16;
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct PairArgs {
+  const int* rowptr;
+  const T* fval;
+  const int* s1ptr;
+  const int* s1rows;
+  const int* s2ptr;
+  const int* s2rows;
+  const u16* lidx1;
+  const u32* occ_off;
+  const u16* lidx2;
+  const T* h_in;
+  const T* x;
+  T* h_out;
+  int N;
+  u32 ld;
+  int block_rows;
+  int max_n2;  // rows reserved for the h tile (the g tile follows it in LDS)
+  T sA, bA, gA, sB, bB, gB;
+  int final;
+  T* y;
+  u32 ldy;
+  const int* perm;
+};
+
+// sum_j val_j * tile[idx_j] over one padded CSR row (4 entries per step), tile rows of 16 lanes;
+// also returns the row's first gathered value (entry 0 = the diagonal slot = the row itself)
+template <typename T, typename V>
+__device__ __forceinline__ V tile_row_dot(const T* __restrict__ val, const u16* __restrict__ idx, int len,
+                                          const V* tile, int lane16, V& self) {
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  V acc = 0;
+  self = 0;
+  for (int j = 0; j < len; j += 4) {
+    const u16x4 id = *(const u16x4*)(idx + j);
+    const T4 vv = *(const T4*)(val + j);
+    const V t0 = tile[(id.x == GSPX_PAD16 ? 0 : id.x) * 16 + lane16];
+    const V t1 = tile[(id.y == GSPX_PAD16 ? 0 : id.y) * 16 + lane16];
+    const V t2 = tile[(id.z == GSPX_PAD16 ? 0 : id.z) * 16 + lane16];
+    const V t3 = tile[(id.w == GSPX_PAD16 ? 0 : id.w) * 16 + lane16];
+    if (j == 0) self = t0;
+    acc += vv.x * t0;  // pad values are 0
+    acc += vv.y * t1;
+    acc += vv.z * t2;
+    acc += vv.w * t3;
+  }
+  return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void k_newton_pair(const PairArgs<T> a) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef typename VT<T, VEC>::t V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gspx_smem[];
+  V* tile_h = (V*)gspx_smem;                       // [n2][16]
+  V* tile_g = tile_h + (size_t)a.max_n2 * 16;      // [n1][16]
+
+  const int tid = threadIdx.x;
+  const int lane16 = tid & 15;
+  const int grp = tid >> 4;  // 0..31
+  const int b = blockIdx.x;
+  const u32 col0 = (blockIdx.y * 16 + lane16) * VEC;
+  const bool on = col0 < a.ld;
+
+  const int s2lo = a.s2ptr[b], n2 = a.s2ptr[b + 1] - s2lo;
+  const int s1lo = a.s1ptr[b], n1 = a.s1ptr[b + 1] - s1lo;
+
+  // ---- phase 0: stage h on S2 ---------------------------------------------------------------
+  for (int u = grp; u < n2; u += 32) {
+    const int row = a.s2rows[s2lo + u];
+    V v = 0;
+    if (on) v = *(const V*)(a.h_in + (size_t)row * a.ld + col0);
+    tile_h[u * 16 + lane16] = v;
+  }
+  __syncthreads();
+
+  // ---- phase 1: g on S1 (into LDS) ----------------------------------------------------------
+  for (int o = grp; o < n1; o += 32) {
+    const int r = a.s1rows[s1lo + o];
+    const int s = a.rowptr[r] & ~3;
+    const int len = (a.rowptr[r + 1] & ~3) - s;
+    const u32 lo = a.occ_off[s1lo + o];
+    V xr = 0;
+    if (on) xr = *(const V*)(a.x + (size_t)r * a.ld + col0);
+    V self;
+    const V acc = tile_row_dot<T, V>(a.fval + s, a.lidx2 + lo, len, tile_h, lane16, self);
+    tile_g[o * 16 + lane16] = a.sA * acc + a.bA * self + a.gA * xr;
+  }
+  __syncthreads();
+
+  // ---- phase 2: h' on the block's own rows ----------------------------------------------------
+  for (int i = grp; i < a.block_rows; i += 32) {
+    const int row = b * a.block_rows + i;
+    if (row >= a.N) break;
+    const int s = a.rowptr[row] & ~3;
+    const int len = (a.rowptr[row + 1] & ~3) - s;
+    V xr = 0;
+    if (on) xr = *(const V*)(a.x + (size_t)row * a.ld + col0);
+    V self;
+    const V acc = tile_row_dot<T, V>(a.fval + s, a.lidx1 + s, len, tile_g, lane16, self);
+    const V hn = a.sB * acc + a.bB * self + a.gB * xr;
+    if (on) {
+      if (a.final) {
+        const size_t orow = a.perm ? (size_t)a.perm[row] : (size_t)row;
+        *(V*)(a.y + orow * a.ldy + col0) = hn;
+      } else {
+        *(V*)(a.h_out + (size_t)row * a.ld + col0) = hn;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NARROW kernel (1..4 signals): several rows per wave; W lanes span the signals, G lanes split a
 // row's entries (per-lane vector loads of col/val, coalesced because a wave's rows are
 // consecutive in the padded CSR), xor-shuffle reduction across the G lanes.

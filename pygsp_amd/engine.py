@@ -379,8 +379,36 @@ def _newton_methods():
             ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), ctypes.byref(ms)))
         return ms.value
 
+    def download_internal(self):
+        """(rowptr, col) of the engine's internal padded CSR (internal vertex order)."""
+        rp = np.empty(self.N + 1, dtype=np.int32)
+        col = np.empty(self.nnz_internal, dtype=np.int32)
+        _capi.check(_capi.load().gspx_graph_download_internal(self._h, _capi.ptr(rp), _capi.ptr(col)))
+        return rp, col
+
+    def enable_pair_tiles(self):
+        """Build (numpy) and upload the two-level tiles of the fused Newton-pair kernel.
+        Returns the tile statistics.  A graph-setup step, ~seconds at N = 1M."""
+        from . import tiling
+        rp, col = self.download_internal()
+        t = tiling.build_tiles(rp, col, self.N, 32)
+        c = np.ascontiguousarray
+        _capi.check(_capi.load().gspx_graph_set_tiles(
+            self._h, 32, t["nb"], _capi.ptr(c(t["s1ptr"])), _capi.ptr(c(t["s1rows"])),
+            _capi.ptr(c(t["s2ptr"])), _capi.ptr(c(t["s2rows"])), _capi.ptr(c(t["lidx1"])),
+            _capi.ptr(c(t["occ_off"])), t["lidx2"].size, _capi.ptr(c(t["lidx2"])), t["max_n1"],
+            t["max_n2"]))
+        return {k: t[k] for k in ("nb", "max_n1", "max_n2", "mean_n1", "mean_n2")}
+
+    def disable_pair_tiles(self):
+        _capi.check(_capi.load().gspx_graph_set_tiles(self._h, 0, 0, None, None, None, None, None,
+                                                      None, 0, None, 0, 0))
+
     DeviceGraph.newton_filter = newton_filter
     DeviceGraph.newton_filter_dev = newton_filter_dev
+    DeviceGraph.download_internal = download_internal
+    DeviceGraph.enable_pair_tiles = enable_pair_tiles
+    DeviceGraph.disable_pair_tiles = disable_pair_tiles
 
 
 _newton_methods()

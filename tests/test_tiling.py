@@ -1,0 +1,75 @@
+"""Two-level tiles of the fused Newton-pair kernel: structure invariants and a numpy emulation of
+the kernel's three phases against two explicit sparse products.  CPU only."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import cheby_oracle as orc
+from pygsp_amd import engine, graphs, tiling
+
+
+def host_internal_csr(L, perm):
+    """The engine's internal padded CSR (diag slot first, rest ascending, padded to 4 with col=N),
+    rebuilt on the host for a small graph."""
+    N = L.shape[0]
+    inv = np.empty(N, dtype=np.int64)
+    inv[perm] = np.arange(N)
+    L = sparse.csr_matrix(L)
+    rptr = [0]
+    rcol, rval = [], []
+    for i in range(N):
+        old = perm[i]
+        cols = inv[L.indices[L.indptr[old]:L.indptr[old + 1]]]
+        vals = L.data[L.indptr[old]:L.indptr[old + 1]]
+        d = vals[cols == i].sum() if (cols == i).any() else 0.0
+        m = cols != i
+        order = np.argsort(cols[m])
+        c = [i] + cols[m][order].tolist()
+        v = [d] + vals[m][order].tolist()
+        while len(c) % 4:
+            c.append(N)
+            v.append(0.0)
+        rcol += c
+        rval += v
+        rptr.append(len(rcol))
+    return np.array(rptr, dtype=np.int32), np.array(rcol, dtype=np.int32), np.array(rval)
+
+
+@pytest.mark.parametrize("block_rows", [8, 32, 64])
+def test_tiles_reproduce_two_steps(block_rows):
+    W, coords = graphs.sensor_weights(700, k=6, seed=4)
+    L = orc.laplacian(W)
+    N = L.shape[0]
+    perm = engine.locality_order(W, coords).astype(np.int64)
+    rptr, rcol, rval = host_internal_csr(L, perm)
+    lmax = 2 * float(np.ravel(W.sum(0)).max())
+    a1 = a2 = lmax / 2
+    fval = np.where(rcol == np.repeat(np.arange(N), np.diff(rptr)), rval - a2, rval) * (2 / a1)
+    fval[rcol == N] = 0.0
+    t = tiling.build_tiles(rptr, rcol, N, block_rows)
+    nb = t["nb"]
+    assert nb == (N + block_rows - 1) // block_rows
+    # invariants: S1 contains the block's own rows, S2 contains S1, local indices point back
+    for b in (0, nb // 2, nb - 1):
+        s1 = t["s1rows"][t["s1ptr"][b]:t["s1ptr"][b + 1]]
+        s2 = t["s2rows"][t["s2ptr"][b]:t["s2ptr"][b + 1]]
+        own = np.arange(b * block_rows, min((b + 1) * block_rows, N))
+        assert np.all(np.diff(s1) > 0) and np.all(np.diff(s2) > 0)
+        assert np.isin(own, s1).all() and np.isin(s1, s2).all()
+        for i in own:
+            e = np.arange(rptr[i], rptr[i + 1])
+            real = rcol[e] < N
+            assert np.array_equal(s1[t["lidx1"][e][real]], rcol[e][real])
+            assert np.all(t["lidx1"][e][~real] == tiling.PAD)
+            assert s1[t["lidx1"][e[0]]] == i  # entry 0 is the diagonal slot
+    assert t["max_n1"] <= t["max_n2"] < tiling.PAD
+    # the emulated kernel == two explicit steps
+    F = sparse.csr_matrix((fval, rcol.clip(max=N - 1), rptr), shape=(N, N))
+    rng = np.random.default_rng(0)
+    h = rng.standard_normal((N, 3))
+    x = rng.standard_normal((N, 3))
+    A, B = (0.5, -0.3, 1.7), (0.5, 0.9, -0.4)
+    g = A[0] * F.dot(h) + A[1] * h + A[2] * x
+    ref = B[0] * F.dot(g) + B[1] * g + B[2] * x
+    out = tiling.emulate_pair(t, rptr, rcol, fval, N, h, x, A, B)
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
