@@ -73,6 +73,9 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "waves_per_block" 4 (default), 8 or 16 waves per workgroup (kernel 1)
  *   "ws_limit_mb" / "max_batch"  workspace budget / cap on signals per batch
  *   "combine"     0 auto, 1 fused flush every 3rd step, 2 deferred combine (keep all T_k)
+ *   "newton_pair" 1 (default) Newton-form filtering runs two orders per launch when the graph
+ *                 carries tiles (gspx_graph_set_tiles); 0 one order per launch
+ *   "pair_workgroups" persistent workgroups of the fused pair kernel (0 = two per CU)
  */
 int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value);
 int gspx_ctx_get_option(gspx_ctx* ctx, const char* key, int64_t* value);
@@ -155,6 +158,10 @@ int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s
                          const int32_t* s1rows, const int32_t* s2ptr, const int32_t* s2rows,
                          const uint16_t* lidx1, const uint32_t* occ_off, int64_t n_lidx2,
                          const uint16_t* lidx2, int max_n1, int max_n2);
+/* out[0] row blocks, out[1] blocks handled by the unstaged fallback kernel (tiles too large to hold
+ * their matrix entries in LDS, or rows longer than 32 entries), out[2] dynamic LDS bytes per
+ * workgroup, out[3] rows per block (0: no tiles set) */
+int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
 
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
  *   out[0] total device time, out[1] time inside the recurrence-step launches only,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "gspx_newton_filter": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _P, _c.c_int64, _P, _P,
                                       _c.POINTER(_c.c_double)]),
     "gspx_graph_download_internal": (_c.c_int, [_P, _P, _P]),
+    "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),
     "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,
                                         _c.c_int, _c.c_int]),
     "gspx_last_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),

@@ -100,6 +100,7 @@ struct Options {
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
   int64_t interleave = 0;       // panel kernel: waves of a workgroup advance as one front
   int64_t newton_pair = 1;      // use the fused two-step kernel when the graph carries tiles
+  int64_t pair_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
@@ -110,6 +111,7 @@ struct Options {
 
 struct gspx_ctx {
   int device = 0;
+  int cu_count = 256;
   hipStream_t stream = nullptr;
   Options opt;
   // workspace (grow-only, reused across calls)
@@ -144,7 +146,10 @@ struct gspx_graph {
   DevMem perm, iperm;
   bool has_perm = false;
   // two-level row tiles of the fused Newton-pair kernel (optional; pygsp_amd/tiling.py)
-  DevMem t_s1ptr, t_s1rows, t_s2ptr, t_s2rows, t_lidx1, t_occ, t_lidx2;
+  DevMem t_hdr, t_hdr_s, t_desc, t_s2rows, t_lidx1, t_lidx2, t_fb;
+  int tile_nfb = 0;          // blocks the staged pair kernel leaves to the fallback kernel
+  size_t tile_lds = 0;       // dynamic LDS bytes of the fallback pair kernel (its largest tiles)
+  size_t tile_top = 0;       // staged pair kernel: bytes of the top part of its 80 KB
   int tile_rows = 0, tile_nb = 0, tile_max_n1 = 0, tile_max_n2 = 0;
   double fval_lmax = -1.0;
   double build_ms = 0.0;
@@ -181,6 +186,10 @@ extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
   HIPCHK(hipSetDevice(device));
   gspx_ctx* ctx = new gspx_ctx();
   ctx->device = device;
+  if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device) !=
+          hipSuccess ||
+      ctx->cu_count < 1)
+    ctx->cu_count = 256;
   hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete ctx;
@@ -232,6 +241,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "alternate_sweep")) return &o.alternate_sweep;
   if (!strcmp(key, "synthesis")) return &o.synthesis;
   if (!strcmp(key, "newton_pair")) return &o.newton_pair;
+  if (!strcmp(key, "pair_workgroups")) return &o.pair_workgroups;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
@@ -661,24 +671,108 @@ extern "C" int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const
     return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: bad argument");
   const int n_s1 = s1ptr[nb], n_s2 = s2ptr[nb];
   HIPCHK(hipSetDevice(g->ctx->device));
-  CHK(g->t_s1ptr.alloc((size_t)(nb + 1) * 4));
-  CHK(g->t_s2ptr.alloc((size_t)(nb + 1) * 4));
-  CHK(g->t_s1rows.alloc((size_t)n_s1 * 4));
+  // per-block header and per-(block, S1 row) descriptors: everything a workgroup needs to issue
+  // all of its loads at once (no pointer chasing through rowptr / occ_off on the device)
+  std::vector<int> rp((size_t)g->N + 1);
+  HIPCHK(hipMemcpy(rp.data(), g->rptr.p, ((size_t)g->N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  for (auto& r : rp) r &= ~3;
+  std::vector<int> hdr((size_t)nb * 8);
+  std::vector<int> desc((size_t)n_s1 * 4);
+  std::vector<int> fb, hdr_s;
+  // LDS: two workgroups per CU when the largest tiles fit 80 KB; what a block's tiles leave free
+  // holds its staged matrix entries
+  // LDS: the staged kernel takes 80 KB (two workgroups per CU); the fallback kernel as much as
+  // its largest tiles need
+  const size_t tiles_max = ((size_t)max_n1 + (size_t)max_n2) * 256;
+  const size_t lds_staged = (size_t)80 * 1024;
+  const size_t lds = std::max(tiles_max, (size_t)1024);
+  const size_t esz = elt_size(g->dtype) + 2;
+  std::vector<char> cand((size_t)nb, 0);
+  std::vector<size_t> need_bot((size_t)nb), need_top((size_t)nb);
+  for (int b = 0; b < nb; ++b) {
+    const int lo = s1ptr[b], hi = s1ptr[b + 1];
+    const int r0 = b * block_rows, r1 = (int)std::min<int64_t>((int64_t)r0 + block_rows, g->N);
+    bool longrow = false;
+    for (int o = lo; o < hi; ++o) {
+      const int r = s1rows[o];
+      if (r < 0 || r >= g->N) return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: bad S1 row");
+      const int len = rp[r + 1] - rp[r];
+      if ((int64_t)occ_off[o + 1] - (int64_t)occ_off[o] != len)
+        return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: occ_off does not match the rows");
+      desc[(size_t)o * 4 + 0] = r;
+      desc[(size_t)o * 4 + 1] = rp[r];
+      desc[(size_t)o * 4 + 2] = len;
+      desc[(size_t)o * 4 + 3] = (int)(occ_off[o] - occ_off[lo]);
+      longrow |= len > 32;
+    }
+    for (int r = r0; r < r1; ++r) longrow |= rp[r + 1] - rp[r] > 32;
+    int* h = &hdr[(size_t)b * 8];
+    h[0] = lo;
+    h[1] = hi - lo;
+    h[2] = s2ptr[b];
+    h[3] = s2ptr[b + 1] - s2ptr[b];
+    h[4] = (int)occ_off[lo];
+    h[5] = (int)(occ_off[hi] - occ_off[lo]);
+    h[6] = rp[r0];
+    h[7] = rp[r1] - rp[r0];
+    if (h[1] > max_n1 || h[3] > max_n2)
+      return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: max_n1 / max_n2 too small");
+    need_bot[b] = (size_t)h[3] * 256 + (size_t)h[5] * esz;
+    need_top[b] = (size_t)h[1] * 256 + (size_t)h[7] * esz;
+    cand[b] = !longrow && h[1] <= 128 && h[3] <= 256;
+  }
+  // split of the staged kernel's LDS into [bottom | top]: the split that stages the most blocks
+  size_t best_top = 0;
+  int best_cnt = -1;
+  for (size_t topb = 1024; topb + 1024 <= lds_staged; topb += 1024) {
+    int cnt = 0;
+    for (int b = 0; b < nb; ++b)
+      cnt += cand[b] && need_top[b] <= topb && need_bot[b] + 1024 <= lds_staged - topb;
+    if (cnt > best_cnt) {
+      best_cnt = cnt;
+      best_top = topb;
+    }
+  }
+  for (int b = 0; b < nb; ++b) {
+    const int* h = &hdr[(size_t)b * 8];
+    if (cand[b] && need_top[b] <= best_top && need_bot[b] + 1024 <= lds_staged - best_top) {
+      const int hs[8] = {h[0], h[1] | (h[3] << 16), h[2], b, h[4], h[5], h[6], h[7]};
+      hdr_s.insert(hdr_s.end(), hs, hs + 8);
+    } else {
+      fb.push_back(b);
+    }
+  }
+  g->tile_top = best_top;
+  CHK(g->t_hdr_s.alloc(hdr_s.size() * 4 + 64));
+  if (!hdr_s.empty())
+    HIPCHK(hipMemcpy(g->t_hdr_s.p, hdr_s.data(), hdr_s.size() * 4, hipMemcpyHostToDevice));
+  g->tile_nfb = (int)fb.size();
+  g->tile_lds = lds;
+  CHK(g->t_fb.alloc(fb.size() * 4 + 16));
+  if (!fb.empty()) HIPCHK(hipMemcpy(g->t_fb.p, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
+  CHK(g->t_hdr.alloc(hdr.size() * 4));
+  CHK(g->t_desc.alloc(desc.size() * 4 + 64));
   CHK(g->t_s2rows.alloc((size_t)n_s2 * 4));
   CHK(g->t_lidx1.alloc((size_t)g->nnz_int * 2 + 64));
-  CHK(g->t_occ.alloc((size_t)(n_s1 + 1) * 4));
   CHK(g->t_lidx2.alloc((size_t)n_lidx2 * 2 + 64));
-  HIPCHK(hipMemcpy(g->t_s1ptr.p, s1ptr, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->t_s2ptr.p, s2ptr, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->t_s1rows.p, s1rows, (size_t)n_s1 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_hdr.p, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->t_desc.p, desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g->t_s2rows.p, s2rows, (size_t)n_s2 * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g->t_lidx1.p, lidx1, (size_t)g->nnz_int * 2, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->t_occ.p, occ_off, (size_t)(n_s1 + 1) * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g->t_lidx2.p, lidx2, (size_t)n_lidx2 * 2, hipMemcpyHostToDevice));
   g->tile_rows = block_rows;
   g->tile_nb = nb;
   g->tile_max_n1 = max_n1;
   g->tile_max_n2 = max_n2;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]) {
+  if (!g || !out) return set_err(GSPX_ERR_INVALID, "null argument");
+  out[0] = g->tile_rows ? g->tile_nb : 0;
+  out[1] = g->tile_rows ? g->tile_nfb : 0;
+  out[2] = g->tile_rows ? (int64_t)g->tile_lds : 0;
+  out[3] = g->tile_rows;
   return GSPX_OK;
 }
 
@@ -1393,10 +1487,14 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   // fused two-step kernel: needs tiles, 16-byte lanes on every panel it touches, and an LDS
   // footprint (h tile on S2 + g tile on S1, 256-byte row chunks) the CU can hold
   constexpr int PVEC = 16 / (int)sizeof(T);
-  const size_t pair_lds = ((size_t)g->tile_max_n1 + (size_t)g->tile_max_n2) * 256;
+  // (two workgroups per CU when the tiles fit 80 KB; what the tiles leave free holds the staged
+  // matrix entries, block by block)
+  const size_t pair_lds = g->tile_lds;
   const bool pair_ok = opt.newton_pair && g->tile_rows == 32 && K >= 2 && (ld % PVEC) == 0 &&
                        (ldy % PVEC) == 0 && (((uintptr_t)y / sizeof(T)) % PVEC) == 0 &&
-                       pair_lds <= 160 * 1024;
+                       pair_lds <= 160 * 1024 && (size_t)N * ld * sizeof(T) < ((size_t)1 << 31) &&
+                       (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31) &&
+                       g->t_lidx2.bytes < ((size_t)1 << 31);
   auto step_params = [&](int s, T& sc, T& be, T& ga) {
     const int j = K - 1 - s;
     if (s == 0) {
@@ -1414,6 +1512,8 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   int pair_cur = (pair_ok && (K & 1)) ? 0 : -1;  // panel holding h before the next pair (-1 = X)
   if (pair_ok) {
     HIPCHK(hipFuncSetAttribute((const void*)k_newton_pair<T>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_newton_pair_g<T>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
   }
   for (int s = 0; s < K; ++s) {
@@ -1421,12 +1521,11 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       PairArgs<T> p{};
       p.rowptr = g->rptr.as<int>();
       p.fval = g->fval.as<T>();
-      p.s1ptr = g->t_s1ptr.as<int>();
-      p.s1rows = g->t_s1rows.as<int>();
-      p.s2ptr = g->t_s2ptr.as<int>();
+      p.hdr = g->t_hdr.as<int>();
+      p.hdr_s = g->t_hdr_s.as<int>();
+      p.desc = g->t_desc.as<int4>();
       p.s2rows = g->t_s2rows.as<int>();
       p.lidx1 = g->t_lidx1.as<unsigned short>();
-      p.occ_off = g->t_occ.as<unsigned>();
       p.lidx2 = g->t_lidx2.as<unsigned short>();
       // the pair reads h on other blocks' rows too, so it never writes the panel it reads
       const int out_buf = (pair_cur == 0) ? 1 : 0;
@@ -1436,17 +1535,31 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       pair_cur = out_buf;
       p.N = N;
       p.ld = ld;
-      p.block_rows = 32;
-      p.max_n2 = g->tile_max_n2;
+      p.lds_bytes = 80 * 1024;
+      p.top_bytes = (int)g->tile_top;
+      p.panel_bytes = (unsigned)((size_t)N * ld * sizeof(T));
+      p.fval_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
+      p.lidx1_bytes = (unsigned)((size_t)g->nnz_int * 2);
+      p.lidx2_bytes = (unsigned)g->t_lidx2.bytes;
       step_params(s, p.sA, p.bA, p.gA);
       step_params(s + 1, p.sB, p.bB, p.gB);
       p.final = (s + 1 == K - 1) ? 1 : 0;
       p.y = y;
       p.ldy = ldy;
       p.perm = perm;
-      const unsigned gy = (unsigned)(((size_t)ld * sizeof(T) + 255) / 256);
-      hipLaunchKernelGGL((k_newton_pair<T>), dim3((unsigned)g->tile_nb, gy, 1), dim3(512), pair_lds,
-                         st, p);
+      p.nb = g->tile_nb;
+      p.ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
+      p.nsb = p.nb - g->tile_nfb;
+      p.per_xcd = (int)(((int64_t)p.nsb * p.ncol + 7) / 8);
+      // persistent workgroups: two per CU (LDS), a multiple of 8 so every XCD gets the same count
+      unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)ctx->cu_count) / 8 * 8);
+      if (opt.pair_workgroups > 0)
+        nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.pair_workgroups, 1 << 20) / 8 * 8);
+      if (p.nsb > 0)
+        hipLaunchKernelGGL((k_newton_pair<T>), dim3(nwg, 1, 1), dim3(512), 80 * 1024, st, p);
+      if (g->tile_nfb > 0)
+        hipLaunchKernelGGL((k_newton_pair_g<T>), dim3((unsigned)g->tile_nfb * p.ncol, 1, 1), dim3(512),
+                           pair_lds, st, p, g->t_fb.as<int>());
       ++s;  // two steps done
       continue;
     }

@@ -398,7 +398,11 @@ def _newton_methods():
             _capi.ptr(c(t["s2ptr"])), _capi.ptr(c(t["s2rows"])), _capi.ptr(c(t["lidx1"])),
             _capi.ptr(c(t["occ_off"])), t["lidx2"].size, _capi.ptr(c(t["lidx2"])), t["max_n1"],
             t["max_n2"]))
-        return {k: t[k] for k in ("nb", "max_n1", "max_n2", "mean_n1", "mean_n2")}
+        st = {k: t[k] for k in ("nb", "max_n1", "max_n2", "mean_n1", "mean_n2")}
+        out = np.zeros(4, dtype=np.int64)
+        _capi.check(_capi.load().gspx_graph_tile_stats(self._h, _capi.ptr(out)))
+        st["unstaged_blocks"], st["lds_bytes"] = int(out[1]), int(out[2])
+        return st
 
     def disable_pair_tiles(self):
         _capi.check(_capi.load().gspx_graph_set_tiles(self._h, 0, 0, None, None, None, None, None,

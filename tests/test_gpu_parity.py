@@ -742,6 +742,8 @@ def test_newton_pair_kernel(ctx, dtype):
         dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
         stats = dev.enable_pair_tiles()
         assert stats["max_n1"] <= stats["max_n2"]
+        if perm is not None:  # locality order: (nearly) every block stages its entries in LDS
+            assert stats["unstaged_blocks"] * 20 < stats["nb"], stats
         for nsig in (4, 8, 32, 64, 100, 128):
             x = rng.standard_normal((W.shape[0], nsig))
             for order in (30, 7, 2, 1):
@@ -762,7 +764,8 @@ def test_newton_pair_kernel(ctx, dtype):
     Lr = orc.laplacian(Wr)
     lm = upper_lmax(Wr)
     dev = engine.DeviceGraph.from_w(Wr, dtype=dtype, perm=engine.locality_order(Wr, None), ctx=ctx)
-    dev.enable_pair_tiles()
+    st = dev.enable_pair_tiles()
+    assert st["unstaged_blocks"] >= 1  # the hub's row is longer than 32 entries
     x = rng.standard_normal((5000, 16))
     c = orc.compute_cheby_coeff(orc.heat_kernel(9, lm), lm, 12)
     nodes, d = filters.cheb_to_newton(c)
