@@ -162,23 +162,28 @@ def main():
         steps_ms_max = steps_ms
 
     # ---- same polynomial in Newton form (extra, reported separately; not the headline) ----------
-    newton = None
-    if a.evaluation == "recurrence" and not a.no_newton:
+    def time_newton():
         for _ in range(a.warmup):
             step_newton()
         fence()
         tn = time.perf_counter()
-        n_ms, n_launch = 0.0, 0
+        n_ms = 0.0
         for _ in range(a.steps):
             step_newton()
-            t = ctx.last_timing()
-            n_ms += t["steps_ms"]
-            n_launch += t["step_launches"]
+            n_ms += ctx.last_timing()["steps_ms"]
         fence()
         n_elapsed = time.perf_counter() - tn
         if torch is not None:
             n_elapsed = gdist.max_over_ranks(n_elapsed, rdev)
-        newton = (n_elapsed, n_ms, n_launch)
+        return n_elapsed, n_ms
+
+    newton = newton_pair = None
+    if a.evaluation == "recurrence" and not a.no_newton:
+        newton = time_newton()
+        # the same, two orders per launch (fused pair kernel; needs the host-built row tiles)
+        tiles = dev.enable_pair_tiles()
+        newton_pair = time_newton() + (tiles,)
+        dev.disable_pair_tiles()
         step_recurrence()  # leave the headline result in y for the parity check below
         fence()
 
@@ -193,6 +198,20 @@ def main():
         if rank == 0:
             assert len(blocks) == world
         del blocks
+
+    def newton_report(r, pair):
+        ms_order = r[1] / (K * a.steps)
+        out = {"note": ("same polynomial in Newton form, two orders per launch with the h panel staged in "
+                        "LDS (fused pair kernel, opt-in: DeviceGraph.enable_pair_tiles())") if pair else
+                       ("same interpolating polynomial in Newton form (two-term Horner recurrence, no "
+                        "accumulator): opt-in evaluation='newton'; parity-tested against the reference"),
+               "value": world * N * nsig * K * a.steps / r[0], "ms_per_step": r[0] / a.steps * 1e3,
+               "ms_per_order": ms_order,
+               "achieved_GBps_alg": b_alg_launch / (ms_order * 1e-3) / 1e9,
+               "frac_of_8TBps": b_alg_launch / (ms_order * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if pair:
+            out["tiles"] = r[2]
+        return out
 
     # ---- roofline of the dominant kernel (the recurrence step) ---------------------------------
     nnz_l = dev.nnz_l
@@ -247,13 +266,8 @@ def main():
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "avg_launch_ms": avg_launch_ms, "launches_timed": launches,
             },
-            "newton_form": None if newton is None else {
-                "note": "same interpolating polynomial in Newton form (two-term Horner recurrence, no "
-                        "accumulator): opt-in evaluation='newton'; parity-tested against the reference",
-                "value": world * N * nsig * K * a.steps / newton[0], "ms_per_step": newton[0] / a.steps * 1e3,
-                "avg_launch_ms": newton[1] / max(newton[2], 1),
-                "achieved_GBps_alg": b_alg_launch / (newton[1] / max(newton[2], 1) * 1e-3) / 1e9,
-                "frac_of_8TBps": b_alg_launch / (newton[1] / max(newton[2], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "newton_form": None if newton is None else newton_report(newton, False),
+            "newton_form_pair": None if newton_pair is None else newton_report(newton_pair, True),
             "device_ms_per_step": dev_ms / a.steps,
             "device_ms_recurrence_per_step": steps_ms_max / a.steps,
             "gather_ms": gather_ms,

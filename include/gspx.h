@@ -160,7 +160,8 @@ int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s
                          const uint16_t* lidx2, int max_n1, int max_n2);
 /* out[0] row blocks, out[1] blocks handled by the unstaged fallback kernel (tiles too large to hold
  * their matrix entries in LDS, or rows longer than 32 entries), out[2] dynamic LDS bytes per
- * workgroup, out[3] rows per block (0: no tiles set) */
+ * workgroup of that fallback kernel (the staged kernel always takes 80 KB), out[3] rows per block
+ * (0: no tiles set) */
 int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
 
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):

@@ -701,8 +701,11 @@ extern "C" int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const
         return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: occ_off does not match the rows");
       desc[(size_t)o * 4 + 0] = r;
       desc[(size_t)o * 4 + 1] = rp[r];
-      desc[(size_t)o * 4 + 2] = len;
-      desc[(size_t)o * 4 + 3] = (int)(occ_off[o] - occ_off[lo]);
+      const int64_t rel = (int64_t)occ_off[o] - (int64_t)occ_off[lo];
+      const bool packable = rel < (1 << 24) && len < 128;
+      desc[(size_t)o * 4 + 2] = packable ? ((int)rel | (len << 24)) : 0;  // staged kernel
+      desc[(size_t)o * 4 + 3] = (int)rel;                                  // fallback kernel
+      longrow |= !packable;
       longrow |= len > 32;
     }
     for (int r = r0; r < r1; ++r) longrow |= rp[r + 1] - rp[r] > 32;
@@ -1507,11 +1510,15 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       ga = (T)dc[j];
     }
   };
+  const int pair_ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
+  // (one chunk: straight-line build; more: the runtime-count build, which measured faster than an
+  // unrolled two-chunk build - that one spills)
+  void (*pair_kernel)(const PairArgs<T>) = pair_ncol == 1 ? k_newton_pair<T, 1> : k_newton_pair<T, 0>;
   int s_first_pair = K;  // steps >= this index run as fused pairs
   if (pair_ok) s_first_pair = K & 1;
   int pair_cur = (pair_ok && (K & 1)) ? 0 : -1;  // panel holding h before the next pair (-1 = X)
   if (pair_ok) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_newton_pair<T>,
+    HIPCHK(hipFuncSetAttribute((const void*)pair_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_newton_pair_g<T>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
@@ -1550,13 +1557,13 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       p.nb = g->tile_nb;
       p.ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
       p.nsb = p.nb - g->tile_nfb;
-      p.per_xcd = (int)(((int64_t)p.nsb * p.ncol + 7) / 8);
+      p.per_xcd = (p.nsb + 7) / 8;
       // persistent workgroups: two per CU (LDS), a multiple of 8 so every XCD gets the same count
       unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)ctx->cu_count) / 8 * 8);
       if (opt.pair_workgroups > 0)
         nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.pair_workgroups, 1 << 20) / 8 * 8);
       if (p.nsb > 0)
-        hipLaunchKernelGGL((k_newton_pair<T>), dim3(nwg, 1, 1), dim3(512), 80 * 1024, st, p);
+        hipLaunchKernelGGL(pair_kernel, dim3(nwg, 1, 1), dim3(512), 80 * 1024, st, p);
       if (g->tile_nfb > 0)
         hipLaunchKernelGGL((k_newton_pair_g<T>), dim3((unsigned)g->tile_nfb * p.ncol, 1, 1), dim3(512),
                            pair_lds, st, p, g->t_fb.as<int>());

@@ -1049,7 +1049,8 @@ template <typename T> struct PairArgs {
   const T* fval;
   const int* hdr;      // [nb][8]: s1lo, n1, s2lo, n2, occ_base, ent1, rp0, ent2 (fallback kernel)
   const int* hdr_s;    // [nsb][8], stageable blocks only: s1lo, n1 | n2 << 16, s2lo, block, then as hdr
-  const int4* desc;    // per (block, S1 row): internal row, first entry in fval, entries, lidx2 offset
+  const int4* desc;    // per (block, S1 row): internal row, first entry in fval, lidx2 offset | entries << 24
+                       // (staged kernel; 0 when that does not fit), lidx2 offset (fallback kernel)
   const int* s2rows;
   const u16* lidx1;
   const u16* lidx2;
@@ -1064,7 +1065,7 @@ template <typename T> struct PairArgs {
   int nb;      // row blocks
   int ncol;    // 256-byte column chunks per row
   int nsb;     // stageable blocks (entries of hdr_s)
-  int per_xcd; // items (stageable block, column chunk) per XCD
+  int per_xcd; // stageable blocks per XCD
   T sA, bA, gA, sB, bB, gB;
   int final;
   T* y;
@@ -1151,7 +1152,7 @@ __device__ __forceinline__ V lds_row_dot(const T* val, const u16* idx, int len, 
 //            and the block headers two blocks ahead, so one memory latency is exposed per block.
 //   phase 1  g = sA F h + bA h + gA x on S1, from LDS into LDS
 //   phase 2  h' = sB F g + bB g + gB x on the block's rows, from LDS; the only store of the pass
-template <typename T>
+template <typename T, int NCOL>  // NCOL = 1: one column chunk per row (straight-line passes); 0: a.ncol chunks
 __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
   constexpr int VEC = 16 / (int)sizeof(T);
   typedef typename VT<T, VEC>::t V;
@@ -1160,16 +1161,16 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
   const int tid = threadIdx.x;
   const int lane16 = tid & 15;
   const int grp = tid >> 4;  // 0..31
-  // items = (stageable block, column chunk), chunk fastest; per_xcd counts items.  XCD x owns the
-  // items [x * per_xcd, (x + 1) * per_xcd); its nwx workgroups take them round-robin, so at any
-  // moment they work on nwx consecutive blocks and find each other's rows in the XCD's L2.
+  // XCD x owns the stageable blocks [x * per_xcd, (x + 1) * per_xcd) of hdr_s; its nwx workgroups
+  // take them round-robin, so at any moment they work on nwx consecutive blocks and find each
+  // other's rows in the XCD's L2.  A workgroup does all column chunks of a block back to back:
+  // the matrix entries are staged once per block.
   const int nwx = (int)(gridDim.x >> 3);
   const int xlo = (int)(blockIdx.x & 7) * a.per_xcd;
-  int xhi = xlo + a.per_xcd;
-  if (xhi > a.nsb * a.ncol) xhi = a.nsb * a.ncol;
-  const int i0 = xlo + (int)(blockIdx.x >> 3);
-  const int i1 = xhi;
-  if (i0 >= i1) return;
+  int k1 = xlo + a.per_xcd;
+  if (k1 > a.nsb) k1 = a.nsb;
+  const int k0 = xlo + (int)(blockIdx.x >> 3);
+  if (k0 >= k1) return;
 
   // 32-bit offsets into buffer descriptors; an offset with bit 31 set is out of range and loads 0
   constexpr u32 POISON = 0x80000000u;
@@ -1181,9 +1182,9 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
   const u32 ldb = a.ld * (u32)sizeof(T);
 
   struct Hdr { int4 p, q; };   // p: s1lo, n1 | n2 << 16, s2lo, block; q: occ_base, ent1, rp0, ent2
-  struct Meta { int4 d[4]; int rows[8]; int rs, re; };
-  auto load_hdr = [&](int i) {
-    const int k = i / a.ncol;
+  struct Desc { int x, y, z; };  // row, first entry in fval, lidx2 offset | entries << 24
+  struct Meta { Desc d[4]; int rows[8]; int rs, re; };
+  auto load_hdr = [&](int k) {
     Hdr h;
     h.p = *(const int4*)(a.hdr_s + (size_t)k * 8);
     h.q = *(const int4*)(a.hdr_s + (size_t)k * 8 + 4);
@@ -1195,7 +1196,10 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int o = grp + 32 * t;
-      m.d[t] = a.desc[h.p.x + (o < n1 ? o : 0)];
+      const int4 dd = a.desc[h.p.x + (o < n1 ? o : 0)];
+      m.d[t].x = dd.x;
+      m.d[t].y = dd.y;
+      m.d[t].z = dd.z;
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -1226,8 +1230,8 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
                                                  (u32)m.rows[t] * ldb + cb, 0, 0, 0);
     }
   };
-  auto chunk_off = [&](int i) {
-    const u32 col0 = ((i % a.ncol) * 16 + lane16) * VEC;
+  auto chunk_off = [&](int c) {
+    const u32 col0 = (c * 16 + lane16) * VEC;
     return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
   };
 
@@ -1240,16 +1244,18 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
     u.q.z = __builtin_amdgcn_readfirstlane(h.q.z); u.q.w = __builtin_amdgcn_readfirstlane(h.q.w);
     return u;
   };
-  Hdr H = uniform(load_hdr(i0));
+  Hdr H = uniform(load_hdr(k0));
   Meta M = load_meta(H);
-  Hdr Hn = uniform(load_hdr(i0 + nwx < i1 ? i0 + nwx : i0));
-  stage_h(M, H.p.y >> 16, chunk_off(i0));
+  Hdr Hn = uniform(load_hdr(k0 + nwx < k1 ? k0 + nwx : k0));
+  stage_h(M, H.p.y >> 16, chunk_off(0));
   // lanes with nothing to stage write here (end of the bottom part, never read); one slot per
   // lane of the wave, or the writes would pile up on one LDS bank
   const int dump_v = a.lds_bytes - a.top_bytes - 1024 + (tid & 63) * (int)sizeof(T);
   const int dump_i = a.lds_bytes - a.top_bytes - 512 + (tid & 63) * 2;
 
-  for (int i = i0; i < i1; i += nwx) {
+  int k = k0;
+  // one pass = one column chunk c of block k; returns false after the workgroup's last pass
+  auto pass = [&](const int c, const bool first, const bool last) __attribute__((always_inline)) {
     const int n1 = H.p.y & 0xFFFF, n2 = H.p.y >> 16, b = H.p.w;
     const u32 occ_base = (u32)H.q.x;
     const int ent1 = H.q.y, rp0 = H.q.z, ent2 = H.q.w;
@@ -1263,69 +1269,80 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
     const int s2s = M.rs & ~3;
     const int len2 = (M.re & ~3) - s2s;
     const int m2 = s2s - rp0;
-    const u32 col0 = ((i % a.ncol) * 16 + lane16) * VEC;
+    const u32 col0 = (c * 16 + lane16) * VEC;
     const bool on = col0 < a.ld;
     const u32 cb = on ? col0 * (u32)sizeof(T) : POISON;
 
     // entries of this group's S1 rows and own row: lane l takes entries l and l + 16
     u16 ei[5][2];
     T ev[5][2];
+    if (first) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int e = lane16 + 16 * q;
+          const u32 pm = e < (M.d[t].z >> 24) ? 0u : POISON;
+          ei[t][q] = (u16)__builtin_amdgcn_raw_buffer_load_b16(ri2, ((occ_base + (u32)(M.d[t].z & 0xFFFFFF) + e) * 2u) | pm, 0, 0);
+          ev[t][q] = VT<T, 1>::bload(rv, ((u32)(M.d[t].y + e) * (u32)sizeof(T)) | pm);
+        }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int e = lane16 + 16 * q;
-        const u32 pm = e < M.d[t].z ? 0u : POISON;
-        ei[t][q] = (u16)__builtin_amdgcn_raw_buffer_load_b16(ri2, ((occ_base + (u32)M.d[t].w + e) * 2u) | pm, 0, 0);
-        ev[t][q] = VT<T, 1>::bload(rv, ((u32)(M.d[t].y + e) * (u32)sizeof(T)) | pm);
+        const u32 pm = e < len2 ? 0u : POISON;
+        ei[4][q] = (u16)__builtin_amdgcn_raw_buffer_load_b16(ri1, ((u32)(s2s + e) * 2u) | pm, 0, 0);
+        ev[4][q] = VT<T, 1>::bload(rv, ((u32)(s2s + e) * (u32)sizeof(T)) | pm);
       }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = lane16 + 16 * q;
-      const u32 pm = e < len2 ? 0u : POISON;
-      ei[4][q] = (u16)__builtin_amdgcn_raw_buffer_load_b16(ri1, ((u32)(s2s + e) * 2u) | pm, 0, 0);
-      ev[4][q] = VT<T, 1>::bload(rv, ((u32)(s2s + e) * (u32)sizeof(T)) | pm);
     }
     V x1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) x1[t] = VT<T, VEC>::bload(rx, (u32)M.d[t].x * ldb + cb);
-    const V x2 = VT<T, VEC>::bload(rx, (u32)row2c * ldb + cb);
     int dz[4], dw[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      dz[t] = M.d[t].z;
-      dw[t] = M.d[t].w;
+      dz[t] = M.d[t].z >> 24;
+      dw[t] = M.d[t].z & 0xFFFFFF;
     }
-    // the next item's row lists and the header after that: in flight during this item's phases
-    M = load_meta(Hn);
-    H = Hn;
-    const Hdr Hv = load_hdr(i + 2 * nwx < i1 ? i + 2 * nwx : i);
-    __builtin_amdgcn_sched_barrier(0);  // every load of the item is issued before the first wait
+    // last chunk of the block: the next block's row lists and the header after that go in flight
+    Hdr Hv;
+    if (last) {
+      M = load_meta(Hn);
+      Hv = load_hdr(k + 2 * nwx < k1 ? k + 2 * nwx : k);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load of the pass is issued before the first wait
 
-    // S1 entries -> bottom (nobody reads the bottom between phase 1 of the previous item and here);
-    // a lane with nothing to stage writes to its dump slot: no branches, so no load gets sunk into one
+    // S1 entries -> bottom (nobody reads them between phase 1 of the previous block and here); a
+    // lane with nothing to stage writes to its dump slot: no divergent branch for a load to sink into
+    if (first) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int e = lane16 + 16 * q;
+          const bool ok = grp + 32 * t < n1 && e < dz[t];
+          const int av = ok ? (int)((unsigned char*)(mval1 + dw[t] + e) - gspx_smem) : dump_v;
+          const int ai = ok ? (int)((unsigned char*)(midx1 + dw[t] + e) - gspx_smem) : dump_i;
+          *(T*)(gspx_smem + av) = ev[t][q];
+          *(u16*)(gspx_smem + ai) = ei[t][q] == GSPX_PAD16 ? (u16)0 : ei[t][q];
+        }
+    }
+    __syncthreads();  // h tile and S1 entries in place; everybody is done with the previous phase 2
+    // the header is the youngest load issued above and the entries (older) have landed: this wait is
+    // short, and no wait of the next pass will have to reach past the tile loads issued further down
+    Hdr Hnn = Hn;
+    if (last) Hnn = uniform(Hv);
+    const V x2 = VT<T, VEC>::bload(rx, (u32)row2c * ldb + cb);  // due at the end of phase 2
+    if (first) {      // own-row entries -> top (read in phase 2)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int e = lane16 + 16 * q;
-        const bool ok = grp + 32 * t < n1 && e < dz[t];
-        const int av = ok ? (int)((unsigned char*)(mval1 + dw[t] + e) - gspx_smem) : dump_v;
-        const int ai = ok ? (int)((unsigned char*)(midx1 + dw[t] + e) - gspx_smem) : dump_i;
-        *(T*)(gspx_smem + av) = ev[t][q];
-        *(u16*)(gspx_smem + ai) = ei[t][q] == GSPX_PAD16 ? (u16)0 : ei[t][q];
+        const bool ok = ok2 && e < len2;
+        const int av = ok ? (int)((unsigned char*)(mval2 + m2 + e) - gspx_smem) : dump_v;
+        const int ai = ok ? (int)((unsigned char*)(midx2 + m2 + e) - gspx_smem) : dump_i;
+        *(T*)(gspx_smem + av) = ev[4][q];
+        *(u16*)(gspx_smem + ai) = ei[4][q] == GSPX_PAD16 ? (u16)0 : ei[4][q];
       }
-    __syncthreads();  // the previous item's phase 2 is done with the top
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = lane16 + 16 * q;
-      const bool ok = ok2 && e < len2;
-      const int av = ok ? (int)((unsigned char*)(mval2 + m2 + e) - gspx_smem) : dump_v;
-      const int ai = ok ? (int)((unsigned char*)(midx2 + m2 + e) - gspx_smem) : dump_i;
-      *(T*)(gspx_smem + av) = ev[4][q];
-      *(u16*)(gspx_smem + ai) = ei[4][q] == GSPX_PAD16 ? (u16)0 : ei[4][q];
     }
-    __syncthreads();  // h tile and S1 entries in place
     // ---- phase 1 ----------------------------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1336,12 +1353,15 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
         tile_g[o * 16 + lane16] = a.sA * acc + a.bA * self + a.gA * x1[t];
       }
     }
-    __syncthreads();  // g tile complete; the bottom is free
-    // (the header is the youngest load of this item: everything prefetched has landed, and the
-    // waits of the next item never have to reach past the tile loads issued below)
-    Hn = uniform(Hv);
+    __syncthreads();  // g tile (and the own-row entries) complete; the h tile is free
+    bool more = true;
+    if (last) {
+      H = Hn;
+      Hn = Hnn;
+      more = k + nwx < k1;
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if (i + nwx < i1) stage_h(M, H.p.y >> 16, chunk_off(i + nwx));
+    if (more) stage_h(M, H.p.y >> 16, chunk_off(last ? 0 : c + 1));
     // ---- phase 2 ----------------------------------------------------------------------------
     if (ok2) {
       V self;
@@ -1355,6 +1375,17 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
           *(V*)(a.h_out + (size_t)row2 * a.ld + col0) = hn;
         }
       }
+    }
+    if (last) k += nwx;
+    return more;
+  };
+  for (;;) {
+    if constexpr (NCOL == 1) {
+      if (!pass(0, true, true)) break;
+    } else {
+      bool more = true;
+      for (int c = 0; c < a.ncol; ++c) more = pass(c, c == 0, c == a.ncol - 1);
+      if (!more) break;
     }
   }
 }
@@ -1401,7 +1432,8 @@ __global__ __launch_bounds__(512) void k_newton_pair_g(const PairArgs<T> a, cons
     V xr = 0;
     if (on) xr = *(const V*)(a.x + (size_t)dd.x * a.ld + col0);
     V self;
-    const V acc = tile_row_dot<T, V, true>(a.fval + dd.y, a.lidx2 + occ_base + (u32)dd.w, dd.z, tile_h, lane16, self);
+    const int dlen = (a.rowptr[dd.x + 1] & ~3) - dd.y;
+    const V acc = tile_row_dot<T, V, true>(a.fval + dd.y, a.lidx2 + occ_base + (u32)dd.w, dlen, tile_h, lane16, self);
     tile_g[o * 16 + lane16] = a.sA * acc + a.bA * self + a.gA * xr;
   }
   __syncthreads();

@@ -401,7 +401,7 @@ def _newton_methods():
         st = {k: t[k] for k in ("nb", "max_n1", "max_n2", "mean_n1", "mean_n2")}
         out = np.zeros(4, dtype=np.int64)
         _capi.check(_capi.load().gspx_graph_tile_stats(self._h, _capi.ptr(out)))
-        st["unstaged_blocks"], st["lds_bytes"] = int(out[1]), int(out[2])
+        st["unstaged_blocks"], st["fallback_lds_bytes"] = int(out[1]), int(out[2])
         return st
 
     def disable_pair_tiles(self):

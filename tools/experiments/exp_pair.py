@@ -24,11 +24,4 @@ for dtype in (np.float32,np.float64):
         print(np.dtype(dtype).name,"pair",pair,"xcd_remap",remap,"ms per order %.4f"%best,flush=True)
     y1=by.download((N,64),dtype); y0=bz.download((N,64),dtype)
     print("max rel diff pair vs single %.2e"%(np.max(abs(y1-y0))/np.max(abs(y0))),flush=True)
-    for wg in (256,512):
-        ctx.set_option("newton_pair",1); ctx.set_option("pair_workgroups",wg)
-        best=1e9
-        for _ in range(3):
-            dev.newton_filter_dev(nodes,d,bx.ptr,by.ptr,64,lmax); t=ctx.last_timing(); best=min(best,t["steps_ms"]/30)
-        print(np.dtype(dtype).name,"workgroups",wg,"ms per order %.4f"%best,flush=True)
-    ctx.set_option("pair_workgroups",0)
     bx.free(); by.free(); bz.free(); dev.destroy()
