@@ -164,6 +164,39 @@ int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s
  * (0: no tiles set) */
 int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
 
+/* ---- operators on the same device CSR --------------------------------
+ * Panels are DEVICE pointers (gspx_buf_ptr or any other device allocation), row-major N x Nsig,
+ * compute dtype of the graph, caller's vertex order.
+ *
+ * y = L x: the product inside Graph.dirichlet_energy (pygsp/graphs/graph.py:702) and inside the
+ * operator of learning.regression_tikhonov (pygsp/learning.py:330). */
+int gspx_laplacian_apply_dev(gspx_graph* g, int64_t Nsig, const void* x_dev, void* y_dev,
+                             double* kernel_ms);
+/* gram_host[Nsig*Nsig] (double, row-major, HOST) = X^T (L X): Graph.dirichlet_energy,
+ * graph.py:642-702 (a scalar for one signal). */
+int gspx_dirichlet_energy_dev(gspx_graph* g, int64_t Nsig, const void* x_dev, double* gram_host,
+                              double* kernel_ms);
+/* Tikhonov regression with tau > 0 (pygsp/learning.py:324-337): solves (diag(M) + tau L) x = M y,
+ * one conjugate-gradient run per column with scipy.sparse.linalg.cg's recurrence and stopping rule
+ * (x0 = 0, ||r|| < max(atol, rtol ||b||); scipy's defaults are rtol 1e-5, atol 0, maxiter 10 N).
+ * mask_dev: N values of the compute dtype (1 = measured, 0 = not).  iterations: Nsig ints (HOST)
+ * or NULL. */
+int gspx_tikhonov_cg_dev(gspx_graph* g, double tau, const void* mask_dev, int64_t Nsig,
+                         const void* y_dev, void* x_dev, double rtol, double atol, int64_t maxiter,
+                         int32_t* iterations, double* kernel_ms);
+/* Differential operator D (L = D D^T) of an UNDIRECTED graph without self loops created from W
+ * (pygsp/graphs/difference.py:26-166).  Edges = stored entries (i, j > i) in row-major order, the
+ * order of Graph.get_edge_list (graph.py:1019-1029).  Built on the device at first use.
+ * download: any output may be NULL; d_source / d_target are D[i, k] at the edge's source (negative)
+ * and target (positive). */
+int gspx_graph_n_edges(gspx_graph* g, int64_t* n_edges);
+int gspx_graph_download_edges(gspx_graph* g, int32_t* sources, int32_t* targets, void* weights,
+                              void* d_source, void* d_target);
+/* grad: y (n_edges x Nsig) = D^T x   (difference.py:168-244)
+ * div:  z (N x Nsig)       = D y     (difference.py:246-331) */
+int gspx_grad_dev(gspx_graph* g, int64_t Nsig, const void* x_dev, void* y_dev, double* kernel_ms);
+int gspx_div_dev(gspx_graph* g, int64_t Nsig, const void* y_dev, void* z_dev, double* kernel_ms);
+
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
  *   out[0] total device time, out[1] time inside the recurrence-step launches only,
  *   out[2] number of step launches, out[3] permute-in/copy time, out[4] combine time */

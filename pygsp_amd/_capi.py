@@ -77,6 +77,14 @@ SIGNATURES = {
     "gspx_newton_filter": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _P, _c.c_int64, _P, _P,
                                       _c.POINTER(_c.c_double)]),
     "gspx_graph_download_internal": (_c.c_int, [_P, _P, _P]),
+    "gspx_laplacian_apply_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
+    "gspx_dirichlet_energy_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
+    "gspx_tikhonov_cg_dev": (_c.c_int, [_P, _c.c_double, _P, _c.c_int64, _P, _P, _c.c_double,
+                                         _c.c_double, _c.c_int64, _P, _P]),
+    "gspx_graph_n_edges": (_c.c_int, [_P, _P]),
+    "gspx_graph_download_edges": (_c.c_int, [_P, _P, _P, _P, _P, _P]),
+    "gspx_grad_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
+    "gspx_div_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
     "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),
     "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,
                                         _c.c_int, _c.c_int]),

@@ -153,6 +153,11 @@ struct gspx_graph {
   int tile_rows = 0, tile_nb = 0, tile_max_n1 = 0, tile_max_n2 = 0;
   double fval_lmax = -1.0;
   double build_ms = 0.0;
+  // differential operator (built on first use; gspx_ops.hip.h)
+  int lap_type = GSPX_LAP_COMBINATORIAL;
+  bool edges_built = false;
+  int64_t n_edges = 0;
+  DevMem e_off, e_toff, e_src, e_dst, e_tedge, e_cs, e_ct, e_w;
 };
 
 static size_t elt_size(int dtype) { return dtype == GSPX_F32 ? 4 : 8; }
@@ -556,6 +561,7 @@ static int graph_create_common(gspx_ctx* ctx, int64_t N, int64_t nnz, const int3
   g->N = N;
   g->dtype = compute_dtype;
   g->from_w = from_w;
+  g->lap_type = lap_type;
   int rc = upload_perm(g, perm);
   if (rc == GSPX_OK) {
     if (from_w) {
@@ -1927,3 +1933,5 @@ extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double*
   *gbps = (double)n4 * 16.0 * passes / (ms * 1e-3) / 1e9;
   return GSPX_OK;
 }
+
+#include "gspx_ops.hip.h"

@@ -1,0 +1,266 @@
+// gspx_ops_kernels.hip.h - device kernels of the operators that reuse the engine's CSR next to the
+// Chebyshev path: L x, Dirichlet energy, the conjugate-gradient
+// loop of Tikhonov regression, gradient / divergence.  gfx950 only.
+//
+// Reference call sites:
+//   Graph.dirichlet_energy          pygsp/graphs/graph.py:642-702      x.T.dot(L.dot(x))
+//   compute_differential_operator   pygsp/graphs/difference.py:26-166  D (incidence matrix)
+//   grad / div                      pygsp/graphs/difference.py:168-331 D.T.dot(x), D.dot(y)
+//   regression_tikhonov (tau > 0)   pygsp/learning.py:324-337          scipy.sparse.linalg.cg
+#pragma once
+
+#include "gspx_kernels.hip.h"
+
+namespace gspx {
+
+// A = s * L + diag(m) on the internal layout (same pattern as L: every row owns a diagonal slot).
+// m is indexed by internal row; null = no diagonal term.
+template <typename T>
+__global__ void k_affine_values(const int* __restrict__ rptr, const int* __restrict__ rcol,
+                                const T* __restrict__ rval, int N, T s, const T* __restrict__ m,
+                                T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const T mi = m ? m[i] : T(0);
+  for (int j = rptr[i] & ~3; j < (rptr[i + 1] & ~3); ++j) {
+    const int c = rcol[j];
+    T v = s * rval[j];
+    if (c == i) v += mi;
+    out[j] = (c == N) ? T(0) : v;
+  }
+}
+
+// ---- column-wise reductions over N x ld row-major panels ------------------------------------------
+// partial[b][c] = sum over the block's rows of A[i][c] * B[i][c]  (double accumulation, fixed order).
+// ldp = power of two >= ld (<= 256): thread t works on column t % ldp, rows t / ldp + k * (256 / ldp).
+template <typename T>
+__global__ __launch_bounds__(256) void k_coldot_partial(const T* __restrict__ A, const T* __restrict__ B,
+                                                        int N, int ld, int ldp,
+                                                        double* __restrict__ partial) {
+  __shared__ double ws[256];
+  const int c = threadIdx.x & (ldp - 1);
+  const int r0 = threadIdx.x / ldp;
+  const int rstep = 256 / ldp;
+  double acc = 0;
+  if (c < ld) {
+    for (size_t i = (size_t)blockIdx.x * rstep + r0; i < (size_t)N; i += (size_t)gridDim.x * rstep)
+      acc += (double)A[i * ld + c] * (double)B[i * ld + c];
+  }
+  ws[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < ldp) {
+    double s = 0;
+    for (int k = 0; k < rstep; ++k) s += ws[k * ldp + threadIdx.x];
+    if (threadIdx.x < ld) partial[(size_t)blockIdx.x * ld + threadIdx.x] = s;
+  }
+}
+// out[c] = sum_b partial[b][c], fixed order
+__global__ void k_colsum(const double* __restrict__ partial, int nb, int ld, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  double s = 0;
+  for (int b = 0; b < nb; ++b) s += partial[(size_t)b * ld + c];
+  out[c] = s;
+}
+
+// Gram block: partial[b][a][c] = sum over the block's rows of X[i][a0 + a] * Y[i][c0 + c]
+// (na, nc <= 16; one thread per (a, c) pair, rows staged through LDS 64 at a time)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gram_partial(const T* __restrict__ X, const T* __restrict__ Y,
+                                                      int N, int ld, int a0, int na, int c0, int nc,
+                                                      double* __restrict__ partial) {
+  __shared__ double xs[64][16], ys[64][16];
+  const int ta = threadIdx.x >> 4, tc = threadIdx.x & 15;
+  double acc = 0;
+  for (size_t base = (size_t)blockIdx.x * 64; base < (size_t)N; base += (size_t)gridDim.x * 64) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int r = e >> 4, q = e & 15;
+      const size_t row = base + r;
+      xs[r][q] = (row < (size_t)N && q < na) ? (double)X[row * ld + a0 + q] : 0.0;
+      ys[r][q] = (row < (size_t)N && q < nc) ? (double)Y[row * ld + c0 + q] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) acc += xs[r][ta] * ys[r][tc];
+    __syncthreads();
+  }
+  partial[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+// ---- conjugate gradient, one independent system per column (scipy.sparse.linalg.cg's recurrence) ---
+struct CgScalars {  // per column, device resident
+  double* rho_prev;
+  double* rho_cur;
+  double* pq;
+  double* atol;     // max(atol, rtol * ||b||)
+  double* alpha;
+  double* beta;
+  int* active;      // 1 while the column iterates
+  int* iters;
+  int* any_active;  // [1]
+};
+
+// start of an iteration (scipy _isolve.cg: "if bnrm2 ... if norm(r) < atol: return"): freeze the
+// columns that have converged, beta = rho_cur / rho_prev for the others (0 on the first iteration)
+__global__ void k_cg_pre(CgScalars s, const double* __restrict__ rr, int ld, int first) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  int act = s.active[c];
+  if (act && sqrt(rr[c]) < s.atol[c]) act = 0;
+  s.active[c] = act;
+  if (act) {
+    s.rho_cur[c] = rr[c];
+    s.beta[c] = first ? 0.0 : rr[c] / s.rho_prev[c];
+    s.iters[c] += 1;
+    atomicOr(s.any_active, 1);
+  }
+}
+// p = r + beta p on the active columns
+template <typename T>
+__global__ void k_cg_p(const T* __restrict__ r, T* __restrict__ p, size_t total, int ld, CgScalars s) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)ld);
+    if (s.active[c]) p[i] = r[i] + (T)s.beta[c] * p[i];
+  }
+}
+__global__ void k_cg_post(CgScalars s, const double* __restrict__ pq, int ld) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  if (s.active[c]) {
+    s.alpha[c] = s.rho_cur[c] / pq[c];
+    s.rho_prev[c] = s.rho_cur[c];
+  }
+}
+// x += alpha p; r -= alpha q on the active columns
+template <typename T>
+__global__ void k_cg_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+                        const T* __restrict__ q, size_t total, int ld, CgScalars s) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)ld);
+    if (s.active[c]) {
+      const T al = (T)s.alpha[c];
+      x[i] += al * p[i];
+      r[i] -= al * q[i];
+    }
+  }
+}
+__global__ void k_cg_init(CgScalars s, const double* __restrict__ bb, int ld, double rtol, double atol) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  const double t = rtol * sqrt(bb[c]);
+  s.atol[c] = t > atol ? t : atol;
+  s.active[c] = bb[c] > 0.0 ? 1 : 0;  // scipy returns x = 0 at once for a zero right-hand side
+  s.iters[c] = 0;
+  s.rho_prev[c] = 1.0;
+}
+// out[i][c] = m[i] * y[i][c]  (panels in the same order as m)
+template <typename T>
+__global__ void k_rowscale(const T* __restrict__ m, const T* __restrict__ y, T* __restrict__ out,
+                           size_t total, int ld) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = m[i / (size_t)ld] * y[i];
+}
+
+// ---- differential operator of an undirected graph (difference.py:140-166) --------------------------
+// Edges = stored entries (i, j) of the canonical Laplacian with j > i, in row-major order - the order
+// of sparse.triu(W, format='coo') that Graph.get_edge_list returns (graph.py:1019-1029).
+__global__ void k_edge_count(const int* __restrict__ lptr, const int* __restrict__ lcol, int N,
+                             int* __restrict__ up, int* __restrict__ low) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int u = 0, l = 0;
+  for (int j = lptr[i]; j < lptr[i + 1]; ++j) {
+    u += lcol[j] > i;
+    l += lcol[j] < i;
+  }
+  up[i] = u;
+  low[i] = l;
+}
+// src, dst, D values at the source (negative) and the target (positive) of every edge, its weight,
+// and for every vertex the list of edges that end in it (tedge, via the lower-triangular entries)
+template <typename T>
+__global__ void k_edge_fill(const int* __restrict__ lptr, const int* __restrict__ lcol,
+                            const T* __restrict__ lval, const T* __restrict__ dw, int N, int lap_type,
+                            const int* __restrict__ eoff, const int* __restrict__ toff,
+                            int* __restrict__ esrc, int* __restrict__ edst, T* __restrict__ cs,
+                            T* __restrict__ ct, T* __restrict__ ew, int* __restrict__ tedge) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int e = eoff[i], t = toff[i];
+  for (int j = lptr[i]; j < lptr[i + 1]; ++j) {
+    const int c = lcol[j];
+    if (c > i) {
+      esrc[e] = i;
+      edst[e] = c;
+      if (lap_type == 0) {  // combinatorial: W_ij = -L_ij
+        const T w = -lval[j];
+        ew[e] = w;
+        cs[e] = -sqrt(w);
+        ct[e] = sqrt(w);
+      } else {              // normalized: L_ij = -W_ij / (sqrt(d_i) sqrt(d_j))
+        const T w = -lval[j] * sqrt(dw[i]) * sqrt(dw[c]);
+        ew[e] = w;
+        cs[e] = -sqrt(w / dw[i]);
+        ct[e] = sqrt(w / dw[c]);
+      }
+      ++e;
+    } else if (c < i) {
+      // edge (c, i): its id = eoff[c] + rank of i among the columns > c of row c (sorted)
+      int lo = lptr[c], hi = lptr[c + 1];
+      int first_up = lo;
+      {  // first entry of row c with column > c
+        int a = lo, b = hi;
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (lcol[mid] > c) b = mid; else a = mid + 1;
+        }
+        first_up = a;
+      }
+      int a = first_up, b = hi;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (lcol[mid] >= i) b = mid; else a = mid + 1;
+      }
+      tedge[t++] = eoff[c] + (a - first_up);
+    }
+  }
+}
+// grad: y[k][:] = cs[k] * x[src[k]][:] + ct[k] * x[dst[k]][:]      (D.T.dot(x), difference.py:244)
+template <typename T>
+__global__ void k_grad(const int* __restrict__ esrc, const int* __restrict__ edst,
+                       const T* __restrict__ cs, const T* __restrict__ ct, const T* __restrict__ x,
+                       T* __restrict__ y, size_t E, int ld) {
+  const size_t total = E * (size_t)ld;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = idx / (size_t)ld;
+    const int c = (int)(idx - k * (size_t)ld);
+    y[idx] = cs[k] * x[(size_t)esrc[k] * ld + c] + ct[k] * x[(size_t)edst[k] * ld + c];
+  }
+}
+// div: z[i][:] = sum_{k: src = i} cs[k] y[k][:] + sum_{k: dst = i} ct[k] y[k][:]   (D.dot(y), :331)
+template <typename T>
+__global__ void k_div(const int* __restrict__ eoff, const int* __restrict__ toff,
+                      const int* __restrict__ tedge, const T* __restrict__ cs,
+                      const T* __restrict__ ct, const T* __restrict__ y, T* __restrict__ z, int N,
+                      int ld) {
+  const size_t total = (size_t)N * ld;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / (size_t)ld);
+    const int c = (int)(idx - (size_t)i * ld);
+    T acc = 0;
+    // the order of scipy's csc_matvec over D's rows does not matter for the value beyond rounding
+    for (int k = eoff[i]; k < eoff[i + 1]; ++k) acc += cs[k] * y[(size_t)k * ld + c];
+    for (int m = toff[i]; m < toff[i + 1]; ++m) {
+      const int k = tedge[m];
+      acc += ct[k] * y[(size_t)k * ld + c];
+    }
+    z[idx] = acc;
+  }
+}
+
+}  // namespace gspx

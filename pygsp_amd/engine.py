@@ -418,6 +418,144 @@ def _newton_methods():
 _newton_methods()
 
 
+def _ops_methods():
+    """Operators that reuse the device CSR next to the Chebyshev path (include/gspx.h, SURVEY 8(f)
+    row 3).  Host arrays in / out; the *_dev variants take device pointers."""
+
+    def _panel(self, x, rows, what):
+        x = np.asarray(x)
+        one_d = x.ndim == 1
+        x2 = np.ascontiguousarray(x.reshape(x.shape[0], -1), dtype=self.dtype)
+        if x2.shape[0] != rows:
+            raise ValueError("{}: first dimension must be {}, got {}".format(what, rows, x.shape))
+        return x2, one_d
+
+    def laplacian_apply_dev(self, x_ptr, y_ptr, nsig):
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_laplacian_apply_dev(
+            self._h, int(nsig), ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), ctypes.byref(ms)))
+        return ms.value
+
+    def laplacian_apply(self, x):
+        """L x for x of shape (N,) or (N, Nsig)."""
+        x2, one_d = _panel(self, x, self.N, "laplacian_apply")
+        bx, by = self.ctx.upload(x2), self.ctx.alloc(max(x2.nbytes, 16))
+        try:
+            laplacian_apply_dev(self, bx.ptr, by.ptr, x2.shape[1])
+            y = by.download(x2.shape, self.dtype)
+        finally:
+            bx.free()
+            by.free()
+        return y[:, 0] if one_d else y
+
+    def dirichlet_energy_dev(self, x_ptr, nsig):
+        gram = np.zeros((int(nsig), int(nsig)), dtype=np.float64)
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_dirichlet_energy_dev(
+            self._h, int(nsig), ctypes.c_void_p(x_ptr), _capi.ptr(gram), ctypes.byref(ms)))
+        return gram, ms.value
+
+    def dirichlet_energy(self, x):
+        """x^T L x: a float for one signal, the (Nsig, Nsig) matrix x.T @ (L @ x) for a panel
+        (what Graph.dirichlet_energy returns for 2-D input, graph.py:701-702)."""
+        x2, one_d = _panel(self, x, self.N, "dirichlet_energy")
+        bx = self.ctx.upload(x2)
+        try:
+            gram, _ = dirichlet_energy_dev(self, bx.ptr, x2.shape[1])
+        finally:
+            bx.free()
+        return float(gram[0, 0]) if one_d else gram
+
+    def tikhonov_cg_dev(self, tau, mask_ptr, y_ptr, x_ptr, nsig, rtol=1e-5, atol=0.0, maxiter=None):
+        maxiter = 10 * self.N if maxiter is None else int(maxiter)
+        iters = np.zeros(max(int(nsig), 1), dtype=np.int32)
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_tikhonov_cg_dev(
+            self._h, float(tau), ctypes.c_void_p(mask_ptr), int(nsig), ctypes.c_void_p(y_ptr),
+            ctypes.c_void_p(x_ptr), float(rtol), float(atol), maxiter, _capi.ptr(iters), ctypes.byref(ms)))
+        return iters[:int(nsig)], ms.value
+
+    def tikhonov_cg(self, tau, mask, y, rtol=1e-5, atol=0.0, maxiter=None):
+        """Solve (diag(mask) + tau L) x = mask * y per column by conjugate gradients (scipy's cg
+        recurrence and stopping rule).  Returns (x, iterations per column, device ms)."""
+        y2, one_d = _panel(self, y, self.N, "tikhonov_cg")
+        m = np.ascontiguousarray(np.asarray(mask).reshape(-1) != 0, dtype=self.dtype)
+        if m.size != self.N:
+            raise ValueError("M should be of size [G.n_vertices,]")
+        bm, by = self.ctx.upload(m), self.ctx.upload(y2)
+        bx = self.ctx.alloc(max(y2.nbytes, 16))
+        try:
+            iters, ms = tikhonov_cg_dev(self, tau, bm.ptr, by.ptr, bx.ptr, y2.shape[1], rtol, atol, maxiter)
+            x = bx.download(y2.shape, self.dtype)
+        finally:
+            bm.free()
+            by.free()
+            bx.free()
+        return (x[:, 0] if one_d else x), iters, ms
+
+    def n_edges(self):
+        v = ctypes.c_int64(0)
+        _capi.check(_capi.load().gspx_graph_n_edges(self._h, ctypes.byref(v)))
+        return v.value
+
+    def edge_list(self, with_d=False):
+        """(sources, targets, weights) in Graph.get_edge_list order; with_d adds D's two values per edge."""
+        E = n_edges(self)
+        src, dst = np.empty(E, dtype=np.int32), np.empty(E, dtype=np.int32)
+        w, ds, dt = (np.empty(E, dtype=self.dtype) for _ in range(3))
+        _capi.check(_capi.load().gspx_graph_download_edges(
+            self._h, _capi.ptr(src), _capi.ptr(dst), _capi.ptr(w), _capi.ptr(ds), _capi.ptr(dt)))
+        return (src, dst, w, ds, dt) if with_d else (src, dst, w)
+
+    def differential_operator(self):
+        """D as scipy csc (N x n_edges), assembled on the host from the device edge arrays."""
+        src, dst, _, ds, dt = edge_list(self, with_d=True)
+        E = src.size
+        rows = np.concatenate([src, dst])
+        cols = np.concatenate([np.arange(E), np.arange(E)])
+        return sparse.csc_matrix((np.concatenate([ds, dt]), (rows, cols)), shape=(self.N, E))
+
+    def grad_dev(self, x_ptr, y_ptr, nsig):
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_grad_dev(self._h, int(nsig), ctypes.c_void_p(x_ptr),
+                                               ctypes.c_void_p(y_ptr), ctypes.byref(ms)))
+        return ms.value
+
+    def div_dev(self, y_ptr, z_ptr, nsig):
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_div_dev(self._h, int(nsig), ctypes.c_void_p(y_ptr),
+                                              ctypes.c_void_p(z_ptr), ctypes.byref(ms)))
+        return ms.value
+
+    def _edge_op(self, x, rows_in, rows_out, fn, what):
+        x2, one_d = _panel(self, x, rows_in, what)
+        out_bytes = rows_out * x2.shape[1] * np.dtype(self.dtype).itemsize
+        bx, by = self.ctx.upload(x2), self.ctx.alloc(max(out_bytes, 16))
+        try:
+            fn(self, bx.ptr, by.ptr, x2.shape[1])
+            y = by.download((rows_out, x2.shape[1]), self.dtype)
+        finally:
+            bx.free()
+            by.free()
+        return y[:, 0] if one_d else y
+
+    def grad(self, x):
+        """D^T x: (N,) or (N, Nsig) -> (n_edges,) or (n_edges, Nsig)."""
+        return _edge_op(self, x, self.N, n_edges(self), grad_dev, "grad")
+
+    def div(self, y):
+        """D y: (n_edges,) or (n_edges, Nsig) -> (N,) or (N, Nsig)."""
+        return _edge_op(self, y, n_edges(self), self.N, div_dev, "div")
+
+    for f in (laplacian_apply_dev, laplacian_apply, dirichlet_energy_dev, dirichlet_energy,
+              tikhonov_cg_dev, tikhonov_cg, n_edges, edge_list, differential_operator, grad_dev,
+              div_dev, grad, div):
+        setattr(DeviceGraph, f.__name__, f)
+
+
+_ops_methods()
+
+
 def plan_describe(coeffs, ctx=None):
     """The engine's step schedule for these coefficients (host-only; for schedule tests)."""
     c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))

@@ -167,6 +167,60 @@ class Graph:
                              "G.N = {}, got {}.".format(self.N, s.shape))
         return s
 
+    # ---- operators on the device CSR ----------------------------------------
+    def dirichlet_energy(self, x):
+        """x^T L x (graph.py:642-702), computed on the device: one sparse product and one reduction."""
+        x = self._check_signal(x)
+        return self.device_graph().dirichlet_energy(x)
+
+    def get_edge_list(self):
+        """(sources, targets, weights), graph.py:934-1029: all stored entries of a directed graph,
+        the upper triangle (row-major) of an undirected one."""
+        if self.is_directed():
+            C = self.W.tocoo()
+        else:
+            C = sparse.triu(self.W, format="coo")
+        assert self.n_edges == C.row.size
+        return C.row, C.col, C.data
+
+    def _device_differential(self):
+        if self.is_directed():
+            raise NotImplementedError("the device differential operator covers undirected graphs; "
+                                      "this graph is directed")
+        if self.W.diagonal().any():
+            raise NotImplementedError("the device differential operator does not cover self-loops")
+        return self.device_graph()
+
+    def compute_differential_operator(self):
+        """difference.py:26-166.  D is assembled on the device (edge enumeration, sqrt of the
+        weights) and cached there; ``G.D`` is the scipy csc copy."""
+        dev = self._device_differential()
+        self._D = dev.differential_operator()
+        self._D_lap_type = self.lap_type
+
+    @property
+    def D(self):
+        """Differential operator (difference.py:15-24), N x n_edges, L = D D^T."""
+        if getattr(self, "_D", None) is None or getattr(self, "_D_lap_type", None) != self.lap_type:
+            self.logger.warning("The differential operator G.D is not available, we need to compute "
+                                "it. Explicitly call G.compute_differential_operator() once "
+                                "beforehand to suppress the warning.")
+            self.compute_differential_operator()
+        return self._D
+
+    def grad(self, x):
+        """Gradient D^T x of a vertex signal (difference.py:168-244), on the device."""
+        x = self._check_signal(x)
+        return self._device_differential().grad(x)
+
+    def div(self, y):
+        """Divergence D y of an edge signal (difference.py:246-331), on the device."""
+        y = np.asanyarray(y)
+        if y.shape[0] != self.Ne:
+            raise ValueError("First dimension must be the number of edges "
+                             "G.Ne = {}, got {}.".format(self.Ne, y.shape))
+        return self._device_differential().div(y)
+
     # ---- spectrum bounds (host; read-only input of the hot path) -------------------------------
     @property
     def lmax(self):

@@ -52,3 +52,8 @@ def golden_lap4():
 @pytest.fixture(scope="session")
 def golden_doctest():
     return load_golden("doctest_sensor30.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_ops():
+    return load_golden("ops_sensor123.npz")

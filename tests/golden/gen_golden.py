@@ -132,12 +132,64 @@ def laplacians4():
     np.savez_compressed(os.path.join(OUT, "laplacians4.npz"), **out)
 
 
+def ops_sensor123():
+    """SURVEY 8(f) row 3 on the same fixture graph: Dirichlet energy (graph.py:642-702), differential
+    operator / grad / div (difference.py), Tikhonov regression and classification (learning.py)."""
+    from pygsp import learning
+    out = {}
+    rng = np.random.default_rng(7)
+    G = graphs.Sensor(123, seed=42)
+    out.update(csr_parts(G.W, "W"))
+    x = rng.standard_normal(G.N)
+    X5 = rng.standard_normal((G.N, 5))
+    out["x"], out["X5"] = x, X5
+    for lt in ("combinatorial", "normalized"):
+        G.compute_laplacian(lt)
+        G.compute_differential_operator()
+        src, dst, w = G.get_edge_list()
+        out["edges_src"], out["edges_dst"], out["edges_w"] = src, dst, w
+        out["D_" + lt] = G.D.toarray()
+        out["energy_" + lt] = np.float64(G.dirichlet_energy(x))
+        out["energy5_" + lt] = G.dirichlet_energy(X5)
+        out["grad_" + lt] = G.grad(x)
+        out["grad5_" + lt] = G.grad(X5)
+        out["div_" + lt] = G.div(G.grad(x))
+        out["div5_" + lt] = G.div(G.grad(X5))
+        out["Lx_" + lt] = G.L.dot(X5)
+    # Tikhonov (the reference reads G.L: use the combinatorial Laplacian, as its doctests do)
+    G.compute_laplacian("combinatorial")
+    mask = rng.uniform(0, 1, G.N) > 0.5
+    out["mask"] = mask
+    meas = x.copy()
+    meas[~mask] = np.nan
+    out["measures"] = meas
+    m0 = np.nan_to_num(meas)
+    for tau in (0.5, 5.0):
+        out["reg_tau%g" % tau] = learning.regression_tikhonov(G, m0.copy(), mask, tau=tau)
+    M3 = np.nan_to_num(np.where(mask[:, None], X5[:, :3], np.nan))
+    out["reg3_in"] = M3
+    out["reg3_tau0.5"] = learning.regression_tikhonov(G, M3.copy(), mask, tau=0.5)
+    out["reg_tau0"] = learning.regression_tikhonov(G, m0.copy(), mask, tau=0)
+    labels = (G.coords[:, 0] > 0.5).astype(int) + (G.coords[:, 1] > 0.5).astype(int)
+    out["labels"] = labels
+    lab_meas = labels.astype(float)
+    lab_meas[~mask] = np.nan
+    out["class_tau0.1"] = learning.classification_tikhonov(G, lab_meas.copy(), mask, tau=0.1)
+    out["class_tau0"] = learning.classification_tikhonov(G, lab_meas.copy(), mask, tau=0)
+    np.savez_compressed(os.path.join(OUT, "ops_sensor123.npz"), **out)
+
+
 if __name__ == "__main__":
     print("pygsp", pygsp.__version__)
+    if len(sys.argv) > 1:  # e.g. `gen_golden.py ops_sensor123`: regenerate only the named fixtures
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     logo()
     sensor123()
     doctest_sensor30()
     laplacians4()
+    ops_sensor123()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

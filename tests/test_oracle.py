@@ -5,6 +5,7 @@ import pytest
 
 from conftest import csr_from, rel_err
 from oracle import cheby_oracle as orc
+from oracle import ops_oracle as ops
 
 
 def test_laplacians_4x4(golden_lap4):
@@ -117,3 +118,67 @@ def test_cheby_rect(golden_sensor123):
     L, lmax = csr_from(g, "Lcomb"), float(g["lmax"])
     assert rel_err(orc.cheby_rect(L, lmax, g["rect_bounds"], g["signal"], 30), g["rect_y"]) < 1e-14
     assert rel_err(orc.cheby_rect(L, lmax, g["rect_bounds"], g["signals5"], 25), g["rect_y5"]) < 1e-14
+
+
+# ---- the operators next to the path (oracle/ops_oracle.py) -------------------------
+def test_ops_doctest_values():
+    """graph.py:686-699: Path(5), signal [0, 2, 2, 4, 4]."""
+    from scipy import sparse
+    W = sparse.diags([np.ones(4), np.ones(4)], [1, -1]).tocsr()
+    x = np.array([0, 2, 2, 4, 4.0])
+    assert ops.dirichlet_energy(ops.laplacian(W), x) == 8.0
+    D = ops.differential_operator(W)
+    np.testing.assert_allclose(ops.grad(D, x), [2, 0, 2, 0])
+    Wd = sparse.diags([np.ones(4)], [1]).tocsr()  # directed path
+    assert abs(ops.dirichlet_energy(ops.laplacian(Wd), x) - 4.0) < 1e-15
+    np.testing.assert_allclose(ops.grad(ops.differential_operator(Wd), x),
+                               [1.41421356, 0, 1.41421356, 0], atol=1e-8)
+    # difference.py:104-118: the 3-vertex examples
+    W3 = np.array([[0, 2, 0], [2, 0, 1], [0, 1, 0.0]])
+    np.testing.assert_allclose(ops.differential_operator(W3).toarray(),
+                               [[-1.41421356, 0], [1.41421356, -1], [0, 1]], atol=1e-8)
+    np.testing.assert_allclose(ops.differential_operator(W3, "normalized").toarray(),
+                               [[-1, 0], [0.81649658, -0.57735027], [0, 1]], atol=1e-8)
+    W3d = np.array([[0, 2, 0], [2, 0, 1], [0, 0, 0.0]])
+    np.testing.assert_allclose(ops.differential_operator(W3d).toarray(),
+                               [[-1, 1, 0], [1, -1, -0.70710678], [0, 0, 0.70710678]], atol=1e-8)
+
+
+def test_ops_sensor123(golden_ops):
+    g = golden_ops
+    W = csr_from(g, "W")
+    x, X5 = g["x"], g["X5"]
+    src, dst, w = ops.get_edge_list(W)
+    np.testing.assert_array_equal(src, g["edges_src"])
+    np.testing.assert_array_equal(dst, g["edges_dst"])
+    np.testing.assert_array_equal(w, g["edges_w"])
+    for lt in ("combinatorial", "normalized"):
+        L = ops.laplacian(W, lt)
+        D = ops.differential_operator(W, lt)
+        np.testing.assert_allclose(D.toarray(), g["D_" + lt], rtol=0, atol=1e-15)
+        assert abs(ops.dirichlet_energy(L, x) - float(g["energy_" + lt])) <= 1e-13 * abs(float(g["energy_" + lt]))
+        assert rel_err(ops.dirichlet_energy(L, X5), g["energy5_" + lt]) < 1e-14
+        assert rel_err(ops.grad(D, x), g["grad_" + lt]) < 1e-15
+        assert rel_err(ops.grad(D, X5), g["grad5_" + lt]) < 1e-15
+        assert rel_err(ops.div(D, ops.grad(D, x)), g["div_" + lt]) < 1e-15
+        assert rel_err(ops.div(D, ops.grad(D, X5)), g["div5_" + lt]) < 1e-15
+        assert rel_err(L.dot(X5), g["Lx_" + lt]) < 1e-15
+        # L = D D^T (difference.py:31)
+        assert abs(D.dot(D.T) - L).max() < 1e-13
+
+
+def test_ops_tikhonov(golden_ops):
+    g = golden_ops
+    L = ops.laplacian(csr_from(g, "W"))
+    mask = g["mask"]
+    m0 = np.nan_to_num(g["measures"])
+    for tau in (0.5, 5.0):
+        assert rel_err(ops.regression_tikhonov(L, m0.copy(), mask, tau), g["reg_tau%g" % tau]) < 1e-13
+    assert rel_err(ops.regression_tikhonov(L, g["reg3_in"].copy(), mask, 0.5), g["reg3_tau0.5"]) < 1e-13
+    assert rel_err(ops.regression_tikhonov(L, m0.copy(), mask, 0), g["reg_tau0"]) < 1e-12
+    lab = g["labels"].astype(float)
+    lab[~mask] = np.nan
+    assert rel_err(ops.classification_tikhonov(L, lab.copy(), mask, 0.1), g["class_tau0.1"]) < 1e-13
+    assert rel_err(ops.classification_tikhonov(L, lab.copy(), mask, 0), g["class_tau0"]) < 1e-12
+    with pytest.raises(ValueError):
+        ops.regression_tikhonov(L, m0, mask[:-1], 0)
