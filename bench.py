@@ -106,6 +106,12 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
+    # the same matrix built by the device k-NN path, checked against the host one
+    t0 = time.perf_counter()
+    Wd, _, knn_info = engine.knn_graph(coords, a.knn, ctx=ctx)
+    t_gen_dev = time.perf_counter() - t0
+    knn_diff = float(abs(Wd - W).max()) if Wd.nnz == W.nnz else float("inf")
+    del Wd
     t0 = time.perf_counter()
     G = graphs.Graph(W, coords=coords, compute_dtype=dtype, device=local, reorder=a.reorder)
     t_graph = time.perf_counter() - t0
@@ -271,7 +277,9 @@ def main():
             "device_ms_per_step": dev_ms / a.steps,
             "device_ms_recurrence_per_step": steps_ms_max / a.steps,
             "gather_ms": gather_ms,
-            "setup_s": {"graph_generation_host": t_gen, "graph_object_incl_device_laplacian": t_graph,
+            "setup_s": {"graph_generation_host": t_gen, "graph_generation_device_knn": t_gen_dev,
+                        "device_knn_build_ms": knn_info["build_ms"], "device_knn_max_abs_diff_vs_host": knn_diff,
+                        "graph_object_incl_device_laplacian": t_graph,
                         "device_laplacian_build_ms": dev.build_ms},
         }
 

@@ -197,6 +197,25 @@ int gspx_graph_download_edges(gspx_graph* g, int32_t* sources, int32_t* targets,
 int gspx_grad_dev(gspx_graph* g, int64_t Nsig, const void* x_dev, void* y_dev, double* kernel_ms);
 int gspx_div_dev(gspx_graph* g, int64_t Nsig, const void* y_dev, void* z_dev, double* kernel_ms);
 
+/* ---- k-nearest-neighbour graph construction on the device ---------------
+ * Replaces, for NNtype='knn', dist_type='euclidean', symmetrize_type='average' and 1..3 dimensions,
+ * the KD-tree query, the Gaussian weights and the symmetrisation of NNGraph
+ * (pygsp/graphs/nngraphs/nngraph.py:213-226, 289-297):
+ *   D, NN = KDTree(X).query(X, k + 1);  sigma = mean(D[:, 1:]);  w = exp(-D^2 / sigma);
+ *   W = (W + W.T) / 2
+ * coords: N x d doubles on the HOST, already centred / rescaled by the caller (nngraph.py:129-137).
+ * sigma == 0 selects the mean neighbour distance.  Neighbours and distances equal scipy's KD-tree
+ * bit for bit (ties ordered by vertex index); a point is never its own neighbour. */
+typedef struct gspx_knn gspx_knn;
+int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, int k, double sigma,
+                   gspx_knn** out);
+int gspx_knn_destroy(gspx_knn* h);
+int gspx_knn_info(gspx_knn* h, int64_t* nnz, double* sigma, double* build_ms);
+/* symmetric W as CSR (sorted columns), float64 */
+int gspx_knn_download_w(gspx_knn* h, int32_t* indptr, int32_t* indices, double* data);
+/* NN[:, 1:] and D[:, 1:] of the reference: N x k, nearest first (either may be NULL) */
+int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist);
+
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
  *   out[0] total device time, out[1] time inside the recurrence-step launches only,
  *   out[2] number of step launches, out[3] permute-in/copy time, out[4] combine time */

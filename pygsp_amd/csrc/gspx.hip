@@ -1935,3 +1935,4 @@ extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double*
 }
 
 #include "gspx_ops.hip.h"
+#include "gspx_knn.hip.h"

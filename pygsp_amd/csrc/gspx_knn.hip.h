@@ -1,0 +1,458 @@
+// gspx_knn.hip.h - k-nearest-neighbour graph construction on the device.
+// Included at the end of gspx.hip.  gfx950 only.
+//
+// Replaces, for NNtype='knn', dist_type='euclidean', symmetrize_type='average', 1 <= d <= 3:
+//   pygsp/graphs/nngraphs/nngraph.py:213-216  kdt = spatial.KDTree(Xout); D, NN = kdt.query(Xout, k + 1)
+//   nngraph.py:218-226                        sigma = mean(D[:, 1:]);  w = exp(-D^2 / sigma)
+//   nngraph.py:289-297                        W = csc((w, (i, j)));  W = (W + W.T) / 2
+// Method: uniform grid (about 2.5 points per cell), counting sort of the points by cell, one thread
+// per query walking the Chebyshev rings of cells around its own until the k-th best distance is
+// below what any unvisited ring can offer.  Distances are formed exactly like the KD-tree's
+// (sum of squared differences in dimension order, no fused multiply-add, one correctly rounded
+// sqrt), so neighbour lists and distances equal scipy's bit for bit (ties, i.e. exactly equal
+// distances, are ordered by vertex index).
+#pragma once
+
+namespace gspx {
+
+struct KnnGrid {
+  double lo[3];
+  double inv_h[3];
+  double h_min;
+  int n[3];
+  int d;
+};
+
+__device__ __forceinline__ int knn_cell_of(const KnnGrid& g, const double* __restrict__ p, int c[3]) {
+  int id = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    c[j] = 0;
+    if (j < g.d) {
+      int v = (int)((p[j] - g.lo[j]) * g.inv_h[j]);
+      v = v < 0 ? 0 : (v >= g.n[j] ? g.n[j] - 1 : v);
+      c[j] = v;
+    }
+  }
+  id = (c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
+  return id;
+}
+
+__global__ void k_knn_cell_count(const double* __restrict__ x, int N, KnnGrid g, int* __restrict__ cell,
+                                 int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int c[3];
+  const int id = knn_cell_of(g, x + (size_t)i * g.d, c);
+  cell[i] = id;
+  atomicAdd(&count[id], 1);
+}
+__global__ void k_knn_scatter(const int* __restrict__ cell, int N, const int* __restrict__ start,
+                              int* __restrict__ cursor, int* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int id = cell[i];
+  order[start[id] + atomicAdd(&cursor[id], 1)] = i;
+}
+// the scatter's order inside a cell depends on atomics: sort every cell's points by index, and
+// gather the coordinates in that order (sorted[s] = x[order[s]])
+__global__ void k_knn_cell_sort(const int* __restrict__ start, int ncells, int* __restrict__ order,
+                                const double* __restrict__ x, int d, double* __restrict__ sorted) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  const int lo = start[c], hi = start[c + 1];
+  for (int a = lo + 1; a < hi; ++a) {
+    const int v = order[a];
+    int b = a - 1;
+    while (b >= lo && order[b] > v) {
+      order[b + 1] = order[b];
+      --b;
+    }
+    order[b + 1] = v;
+  }
+  for (int a = lo; a < hi; ++a)
+    for (int j = 0; j < d; ++j) sorted[(size_t)a * d + j] = x[(size_t)order[a] * d + j];
+}
+
+// KD-tree arithmetic (scipy ckdtree sqeuclidean_distance_double): differences squared and summed in
+// dimension order, every operation rounded on its own - hipcc contracts a*b+c into an fma by
+// default, which changes the last bit, so contraction is switched off here.
+__device__ __forceinline__ double knn_sqdist(const double* q, const double* __restrict__ p, int d) {
+#pragma clang fp contract(off)
+  double d2 = 0;
+  for (int j = 0; j < d; ++j) {
+    const double df = q[j] - p[j];
+    const double sq = df * df;
+    d2 = d2 + sq;
+  }
+  return d2;
+}
+// correctly rounded square root: the hardware-assisted sqrt is within an ulp; one exact residual
+// (fma) and a correction decide the last bit
+__device__ __forceinline__ double knn_sqrt(double x) {
+  if (!(x > 0.0)) return 0.0;
+  const double s = sqrt(x);
+  const double r = fma(-s, s, x);  // exact x - s*s
+  return s + r / (2.0 * s);
+}
+
+// one thread per query (in cell order: a wave's queries are neighbours in space).  best[] is kept
+// sorted by (distance, index) through a chain of conditional swaps - no dynamic register indexing.
+template <int KMAX>
+__global__ __launch_bounds__(128) void k_knn_query(const double* __restrict__ sorted,
+                                                   const int* __restrict__ order,
+                                                   const int* __restrict__ start, int N, KnnGrid g,
+                                                   int k, int* __restrict__ nn,
+                                                   double* __restrict__ dist) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const int self = order[s];
+  double q[3] = {0, 0, 0};
+  for (int j = 0; j < g.d; ++j) q[j] = sorted[(size_t)s * g.d + j];
+  int c[3];
+  knn_cell_of(g, q, c);
+  // distance from the query to the nearest wall of its own cell (>= 0 up to rounding)
+  double m = 1e300;
+  for (int j = 0; j < g.d; ++j) {
+    const double h = 1.0 / g.inv_h[j];
+    const double a = q[j] - (g.lo[j] + c[j] * h), b = (g.lo[j] + (c[j] + 1) * h) - q[j];
+    m = fmin(m, fmin(a, b));
+  }
+  m = fmax(m, 0.0);
+  double bd[KMAX];
+  int bi[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) {
+    bd[t] = 1e300;
+    bi[t] = 0x7fffffff;
+  }
+  const int rmax = max(g.n[0], max(g.n[1], g.n[2]));
+  const int r2 = g.d >= 2 ? 1 : 0, r3 = g.d >= 3 ? 1 : 0;
+  for (int r = 0; r <= rmax; ++r) {
+    for (int dz = -r * r3; dz <= r * r3; ++dz) {
+      const int cz = c[2] + dz;
+      if (cz < 0 || cz >= g.n[2]) continue;
+      for (int dy = -r * r2; dy <= r * r2; ++dy) {
+        const int cy = c[1] + dy;
+        if (cy < 0 || cy >= g.n[1]) continue;
+        const bool shell = (abs(dz) == r && r3) || (abs(dy) == r && r2);
+        // on the shell every dx counts; inside it only the two end cells dx = -r, +r
+        const int step = (shell || r == 0) ? 1 : 2 * r;
+        for (int dx = -r; dx <= r; dx += step) {
+          const int cx = c[0] + dx;
+          if (cx < 0 || cx >= g.n[0]) continue;
+          const int cid = (cz * g.n[1] + cy) * g.n[0] + cx;
+          for (int a = start[cid]; a < start[cid + 1]; ++a) {
+            const int idx = order[a];
+            if (idx == self) continue;
+            const double d2 = knn_sqdist(q, sorted + (size_t)a * g.d, g.d);
+            if (d2 < bd[KMAX - 1] || (d2 == bd[KMAX - 1] && idx < bi[KMAX - 1])) {
+              double cd = d2;
+              int ci = idx;
+#pragma unroll
+              for (int t = 0; t < KMAX; ++t) {
+                const bool lt = cd < bd[t] || (cd == bd[t] && ci < bi[t]);
+                const double td = bd[t];
+                const int ti = bi[t];
+                bd[t] = lt ? cd : td;
+                bi[t] = lt ? ci : ti;
+                cd = lt ? td : cd;
+                ci = lt ? ti : ci;
+              }
+            }
+          }
+        }
+      }
+    }
+    // every point not yet visited lies beyond r whole cells plus the way out of the own cell
+    double kth = 1e300;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+      if (t == k - 1) kth = bd[t];
+    const double lb = (r * g.h_min + m) * (1.0 - 1e-12);
+    if (kth < 1e300 && kth <= lb * lb) break;
+  }
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t)
+    if (t < k) {
+      nn[(size_t)self * k + t] = bi[t];
+      dist[(size_t)self * k + t] = knn_sqrt(bd[t]);
+    }
+}
+
+// sum of all distances (double, fixed order): partial sums per block, then one block
+__global__ __launch_bounds__(256) void k_knn_sum_partial(const double* __restrict__ v, size_t n,
+                                                         double* __restrict__ partial) {
+  __shared__ double ws[4];
+  double acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += v[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// w = exp(-d^2 / sigma) (nngraph.py:224-226: the distance is squared again after the sqrt); an edge
+// i -> j is mutual when i is among j's neighbours; non-mutual edges add one entry to row j
+__global__ void k_knn_weights(const int* __restrict__ nn, const double* __restrict__ dist, int N, int k,
+                              double sigma, double* __restrict__ w, unsigned char* __restrict__ mutual,
+                              int* __restrict__ extra) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N * k) return;
+  const int i = (int)(e / k);
+  const int j = nn[e];
+  const double d = dist[e];
+  w[e] = exp(-(d * d) / sigma);
+  bool mu = false;
+  for (int t = 0; t < k; ++t) mu |= nn[(size_t)j * k + t] == i;
+  mutual[e] = mu ? 1 : 0;
+  if (!mu) atomicAdd(&extra[j], 1);
+}
+__global__ void k_knn_rowlen(const int* __restrict__ extra, int N, int k, int* __restrict__ len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= N) len[i] = i < N ? k + extra[i] : 0;
+}
+// (W + W^T) / 2: a mutual pair keeps w (w/2 + w/2), a one-sided edge leaves w/2 in both rows
+__global__ void k_knn_fill(const int* __restrict__ nn, const double* __restrict__ w,
+                           const unsigned char* __restrict__ mutual, int N, int k,
+                           const int* __restrict__ rowptr, int* __restrict__ cursor,
+                           int* __restrict__ col, double* __restrict__ val) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N * k) return;
+  const int i = (int)(e / k), t = (int)(e - (size_t)i * k);
+  const int j = nn[e];
+  const double v = mutual[e] ? w[e] : w[e] * 0.5;
+  col[rowptr[i] + t] = j;
+  val[rowptr[i] + t] = v;
+  if (!mutual[e]) {
+    const int o = rowptr[j] + k + atomicAdd(&cursor[j], 1);
+    col[o] = i;
+    val[o] = v;
+  }
+}
+__global__ void k_knn_row_sort(const int* __restrict__ rowptr, int N, int* __restrict__ col,
+                               double* __restrict__ val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int lo = rowptr[i], hi = rowptr[i + 1];
+  for (int a = lo + 1; a < hi; ++a) {
+    const int c = col[a];
+    const double v = val[a];
+    int b = a - 1;
+    while (b >= lo && col[b] > c) {
+      col[b + 1] = col[b];
+      val[b + 1] = val[b];
+      --b;
+    }
+    col[b + 1] = c;
+    val[b + 1] = v;
+  }
+}
+
+}  // namespace gspx
+
+struct gspx_knn {
+  gspx_ctx* ctx = nullptr;
+  int64_t N = 0;
+  int d = 0, k = 0;
+  double sigma = 0.0;
+  int64_t nnz = 0;
+  double build_ms = 0.0;
+  DevMem nn, dist, rowptr, col, val;
+};
+
+template <int KMAX>
+static void launch_knn_query(const double* sorted, const int* order, const int* start, int N,
+                             const KnnGrid& g, int k, int* nn, double* dist, hipStream_t st) {
+  hipLaunchKernelGGL((k_knn_query<KMAX>), dim3((N + 127) / 128), dim3(128), 0, st, sorted, order, start, N,
+                     g, k, nn, dist);
+}
+
+extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, int k,
+                              double sigma, gspx_knn** out) {
+  if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null ctx or output");
+  *out = nullptr;
+  if (N < 2 || N >= ((int64_t)1 << 31) / 64) return set_err(GSPX_ERR_INVALID, "gspx_knn_build: bad N");
+  if (d < 1 || d > 3)
+    return set_err(GSPX_ERR_INVALID, "gspx_knn_build: the device k-NN search covers 1 to 3 dimensions (got %d)", d);
+  if (k < 1 || k > 64) return set_err(GSPX_ERR_INVALID, "gspx_knn_build: 1 <= k <= 64 (got %d)", k);
+  if (k >= N)  // nngraph.py:123-127
+    return set_err(GSPX_ERR_INVALID, "The number of neighbors (k=%d) must be smaller than the number of nodes (%lld).",
+                   k, (long long)N);
+  if (!coords) return set_err(GSPX_ERR_INVALID, "null coordinates");
+  if (!(sigma >= 0) || !std::isfinite(sigma)) return set_err(GSPX_ERR_INVALID, "sigma must be >= 0 (0: mean distance)");
+  KnnGrid g{};
+  g.d = d;
+  double hi[3] = {0, 0, 0};
+  for (int j = 0; j < 3; ++j) {
+    g.lo[j] = 0;
+    g.inv_h[j] = 1;
+    g.n[j] = 1;
+  }
+  for (int j = 0; j < d; ++j) {
+    g.lo[j] = coords[j];
+    hi[j] = coords[j];
+  }
+  for (int64_t i = 0; i < N; ++i)
+    for (int j = 0; j < d; ++j) {
+      const double v = coords[i * d + j];
+      if (!std::isfinite(v)) return set_err(GSPX_ERR_INVALID, "non-finite coordinate");
+      g.lo[j] = std::min(g.lo[j], v);
+      hi[j] = std::max(hi[j], v);
+    }
+  // about 2.5 points per cell over the bounding box; degenerate extents get one cell
+  const int cap = d == 1 ? (1 << 21) : (d == 2 ? 2048 : 128);
+  const int per_dim = std::max(1, std::min(cap, (int)std::floor(std::pow((double)N / 2.5, 1.0 / d))));
+  g.h_min = 1e300;
+  int64_t ncells = 1;
+  for (int j = 0; j < d; ++j) {
+    const double ext = hi[j] - g.lo[j];
+    g.n[j] = ext > 0 ? per_dim : 1;
+    const double h = ext > 0 ? ext / g.n[j] : 1.0;
+    g.inv_h[j] = 1.0 / h;
+    if (ext > 0) g.h_min = std::min(g.h_min, h);
+    ncells *= g.n[j];
+  }
+  if (g.h_min == 1e300) g.h_min = 1.0;  // all points coincide
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto t0 = std::chrono::steady_clock::now();
+  gspx_knn* h = new gspx_knn();
+  h->ctx = ctx;
+  h->N = N;
+  h->d = d;
+  h->k = k;
+  auto fail = [&](int rc) {
+    delete h;
+    return rc;
+  };
+#define KCHK(x)                      \
+  do {                               \
+    int rc__ = (x);                  \
+    if (rc__ != GSPX_OK) return fail(rc__); \
+  } while (0)
+#define KHIP(x)                                                                            \
+  do {                                                                                     \
+    hipError_t e__ = (x);                                                                  \
+    if (e__ != hipSuccess) return fail(set_err(GSPX_ERR_HIP, "%s: %s", #x, hipGetErrorString(e__))); \
+  } while (0)
+  const int n = (int)N;
+  const size_t nk = (size_t)N * k;
+  DevMem x, sorted, cell, count, start, cursor, order, w, mutual, extra, len, partial;
+  KCHK(x.alloc((size_t)N * d * sizeof(double)));
+  KCHK(sorted.alloc((size_t)N * d * sizeof(double)));
+  KCHK(cell.alloc((size_t)N * sizeof(int)));
+  KCHK(count.alloc(((size_t)ncells + 1) * sizeof(int)));
+  KCHK(start.alloc(((size_t)ncells + 1) * sizeof(int)));
+  KCHK(cursor.alloc(((size_t)std::max<int64_t>(ncells, N) + 1) * sizeof(int)));
+  KCHK(order.alloc((size_t)N * sizeof(int)));
+  KCHK(h->nn.alloc(nk * sizeof(int)));
+  KCHK(h->dist.alloc(nk * sizeof(double)));
+  KHIP(hipMemcpyAsync(x.p, coords, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, st));
+  KHIP(hipMemsetAsync(count.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
+  KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)std::max<int64_t>(ncells, N) + 1) * sizeof(int), st));
+  const int nbN = (n + 255) / 256;
+  hipLaunchKernelGGL(k_knn_cell_count, dim3(nbN), dim3(256), 0, st, x.as<double>(), n, g, cell.as<int>(),
+                     count.as<int>());
+  KCHK(scan_exclusive(ctx, count.as<int>(), start.as<int>(), (int)ncells + 1));
+  hipLaunchKernelGGL(k_knn_scatter, dim3(nbN), dim3(256), 0, st, cell.as<int>(), n, start.as<int>(),
+                     cursor.as<int>(), order.as<int>());
+  hipLaunchKernelGGL(k_knn_cell_sort, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st,
+                     start.as<int>(), (int)ncells, order.as<int>(), x.as<double>(), d, sorted.as<double>());
+  if (k <= 8)
+    launch_knn_query<8>(sorted.as<double>(), order.as<int>(), start.as<int>(), n, g, k, h->nn.as<int>(),
+                        h->dist.as<double>(), st);
+  else if (k <= 16)
+    launch_knn_query<16>(sorted.as<double>(), order.as<int>(), start.as<int>(), n, g, k, h->nn.as<int>(),
+                         h->dist.as<double>(), st);
+  else if (k <= 32)
+    launch_knn_query<32>(sorted.as<double>(), order.as<int>(), start.as<int>(), n, g, k, h->nn.as<int>(),
+                         h->dist.as<double>(), st);
+  else
+    launch_knn_query<64>(sorted.as<double>(), order.as<int>(), start.as<int>(), n, g, k, h->nn.as<int>(),
+                         h->dist.as<double>(), st);
+  KHIP(hipGetLastError());
+  // sigma = mean neighbour distance (nngraph.py:218-219) unless given
+  if (sigma == 0.0) {
+    const int nb = 1024;
+    KCHK(partial.alloc((size_t)nb * sizeof(double)));
+    hipLaunchKernelGGL(k_knn_sum_partial, dim3(nb), dim3(256), 0, st, h->dist.as<double>(), nk,
+                       partial.as<double>());
+    std::vector<double> hp(nb);
+    KHIP(hipMemcpyAsync(hp.data(), partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+    double s = 0;
+    for (double v : hp) s += v;
+    sigma = s / (double)nk;
+    if (!(sigma > 0)) return fail(set_err(GSPX_ERR_INVALID, "gspx_knn_build: all neighbour distances are zero"));
+  }
+  h->sigma = sigma;
+  KCHK(w.alloc(nk * sizeof(double)));
+  KCHK(mutual.alloc(nk));
+  KCHK(extra.alloc(((size_t)N + 1) * sizeof(int)));
+  KCHK(len.alloc(((size_t)N + 1) * sizeof(int)));
+  KCHK(h->rowptr.alloc(((size_t)N + 1) * sizeof(int)));
+  KHIP(hipMemsetAsync(extra.p, 0, ((size_t)N + 1) * sizeof(int), st));
+  const unsigned nbE = (unsigned)((nk + 255) / 256);
+  hipLaunchKernelGGL(k_knn_weights, dim3(nbE), dim3(256), 0, st, h->nn.as<int>(), h->dist.as<double>(), n, k,
+                     sigma, w.as<double>(), mutual.as<unsigned char>(), extra.as<int>());
+  hipLaunchKernelGGL(k_knn_rowlen, dim3((n + 1 + 255) / 256), dim3(256), 0, st, extra.as<int>(), n, k,
+                     len.as<int>());
+  KCHK(scan_exclusive(ctx, len.as<int>(), h->rowptr.as<int>(), n + 1));
+  int nnz = 0;
+  KHIP(hipMemcpyAsync(&nnz, h->rowptr.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+  KHIP(hipStreamSynchronize(st));
+  h->nnz = nnz;
+  KCHK(h->col.alloc((size_t)std::max(nnz, 1) * sizeof(int)));
+  KCHK(h->val.alloc((size_t)std::max(nnz, 1) * sizeof(double)));
+  KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)N + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(k_knn_fill, dim3(nbE), dim3(256), 0, st, h->nn.as<int>(), w.as<double>(),
+                     mutual.as<unsigned char>(), n, k, h->rowptr.as<int>(), cursor.as<int>(), h->col.as<int>(),
+                     h->val.as<double>());
+  hipLaunchKernelGGL(k_knn_row_sort, dim3(nbN), dim3(256), 0, st, h->rowptr.as<int>(), n, h->col.as<int>(),
+                     h->val.as<double>());
+  KHIP(hipGetLastError());
+  KHIP(hipStreamSynchronize(st));
+#undef KCHK
+#undef KHIP
+  h->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *out = h;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_knn_destroy(gspx_knn* h) {
+  if (!h) return GSPX_OK;
+  (void)hipSetDevice(h->ctx->device);
+  delete h;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_knn_info(gspx_knn* h, int64_t* nnz, double* sigma, double* build_ms) {
+  if (!h) return set_err(GSPX_ERR_INVALID, "null handle");
+  if (nnz) *nnz = h->nnz;
+  if (sigma) *sigma = h->sigma;
+  if (build_ms) *build_ms = h->build_ms;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_knn_download_w(gspx_knn* h, int32_t* indptr, int32_t* indices, double* data) {
+  if (!h || !indptr) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (h->nnz > 0 && (!indices || !data)) return set_err(GSPX_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->ctx->device));
+  HIPCHK(hipMemcpy(indptr, h->rowptr.p, ((size_t)h->N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (h->nnz > 0) {
+    HIPCHK(hipMemcpy(indices, h->col.p, (size_t)h->nnz * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(data, h->val.p, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return GSPX_OK;
+}
+
+extern "C" int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist) {
+  if (!h) return set_err(GSPX_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->ctx->device));
+  const size_t nk = (size_t)h->N * h->k;
+  if (nn) HIPCHK(hipMemcpy(nn, h->nn.p, nk * sizeof(int), hipMemcpyDeviceToHost));
+  if (dist) HIPCHK(hipMemcpy(dist, h->dist.p, nk * sizeof(double), hipMemcpyDeviceToHost));
+  return GSPX_OK;
+}

@@ -556,6 +556,38 @@ def _ops_methods():
 _ops_methods()
 
 
+def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False):
+    """k-nearest-neighbour weights on the device (gspx_knn_build): the KD-tree query, Gaussian weights
+    and symmetrisation of NNGraph (nngraph.py:213-226, 289-297) for euclidean distances in 1-3
+    dimensions.  coords: (N, d), already centred / rescaled.  Returns (W csr float64, sigma, info)
+    where info = {"build_ms": ...} plus "NN", "D" (N x k, nearest first) when neighbors=True."""
+    ctx = ctx or default_context()
+    X = np.ascontiguousarray(coords, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("coords must be (N, d)")
+    N, d = X.shape
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    _capi.check(lib.gspx_knn_build(ctx._h, N, d, _capi.ptr(X), int(k), float(sigma or 0.0), ctypes.byref(h)))
+    try:
+        nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))
+        indptr = np.empty(N + 1, dtype=np.int32)
+        indices = np.empty(nnz.value, dtype=np.int32)
+        data = np.empty(nnz.value, dtype=np.float64)
+        _capi.check(lib.gspx_knn_download_w(h, _capi.ptr(indptr), _capi.ptr(indices), _capi.ptr(data)))
+        info = {"build_ms": ms.value}
+        if neighbors:
+            NN = np.empty((N, int(k)), dtype=np.int32)
+            D = np.empty((N, int(k)), dtype=np.float64)
+            _capi.check(lib.gspx_knn_download_neighbors(h, _capi.ptr(NN), _capi.ptr(D)))
+            info["NN"], info["D"] = NN, D
+    finally:
+        lib.gspx_knn_destroy(h)
+    W = sparse.csr_matrix((data, indices, indptr), shape=(N, N))
+    return W, sg.value, info
+
+
 def plan_describe(coeffs, ctx=None):
     """The engine's step schedule for these coefficients (host-only; for schedule tests)."""
     c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))

@@ -316,12 +316,58 @@ def sensor_weights(N, k=6, seed=None, return_coords=True):
     return (W, coords) if return_coords else W
 
 
-class Sensor(Graph):
-    def __init__(self, N=64, k=6, seed=None, **kwargs):
-        self.k = k
+class NNGraph(Graph):
+    """Nearest-neighbour graph from a point cloud (nngraphs/nngraph.py:13-313), built on the device
+    for the case the reference's own models use: NNtype='knn', euclidean distance, 'average'
+    symmetrisation, 1-3 dimensions.  Other settings raise NotImplementedError (no host fallback)."""
+
+    def __init__(self, Xin, NNtype="knn", use_flann=False, center=True, rescale=True, k=10, sigma=None,
+                 epsilon=0.01, plotting={}, symmetrize_type="average", dist_type="euclidean", order=0,
+                 **kwargs):
+        self.Xin = np.asanyarray(Xin)
+        self.NNtype, self.use_flann, self.center, self.rescale = NNtype, use_flann, center, rescale
+        self.k, self.sigma, self.epsilon = k, sigma, epsilon
+        self.symmetrize_type, self.dist_type, self.order = symmetrize_type, dist_type, order
+        N, d = np.shape(self.Xin)
+        Xout = self.Xin
+        if k >= N:
+            raise ValueError("The number of neighbors (k={}) must be smaller "
+                             "than the number of nodes ({}).".format(k, N))
+        if NNtype != "knn" or dist_type != "euclidean" or symmetrize_type != "average":
+            raise NotImplementedError("the device builder covers NNtype='knn', dist_type='euclidean', "
+                                      "symmetrize_type='average'")
+        if self.center:  # nngraph.py:129-130
+            Xout = self.Xin - np.kron(np.ones((N, 1)), np.mean(self.Xin, axis=0))
+        if self.rescale:  # nngraph.py:132-137
+            bounding_radius = 0.5 * np.linalg.norm(np.amax(Xout, axis=0) - np.amin(Xout, axis=0), 2)
+            scale = np.power(N, 1.0 / float(min(d, 3))) / 10.0
+            Xout = Xout * (scale / bounding_radius)
+        ctx = engine.default_context(int(kwargs.get("device", 0)))
+        W, self.sigma, info = engine.knn_graph(Xout, k, sigma, ctx=ctx)
+        self.knn_build_ms = info["build_ms"]
+        super().__init__(W, plotting=plotting, coords=Xout, **kwargs)
+
+
+class Sensor(NNGraph):
+    """Random sensor graph (nngraphs/sensor.py:11-78): uniform points in the unit square, k nearest
+    neighbours; the neighbour search runs on the device.  ``sensor_weights`` is the host (KD-tree)
+    construction of the same matrix."""
+
+    def __init__(self, N=64, k=6, distributed=False, seed=None, **kwargs):
+        self.distributed = distributed
         self.seed = seed
-        W, coords = sensor_weights(N, k, seed)
-        super().__init__(W, coords=coords, **kwargs)
+        rng = np.random.default_rng(self.seed)
+        if distributed:
+            m = np.sqrt(N)
+            if not m.is_integer():
+                raise ValueError("The number of vertices must be a perfect square if they are to be "
+                                 "distributed on a grid.")
+            coords = np.mgrid[0:1:1 / m, 0:1:1 / m].reshape(2, -1).T
+            coords += rng.uniform(0, 1 / m, (N, 2))
+        else:
+            coords = rng.uniform(0, 1, (N, 2))
+        plotting = {"limits": np.array([0, 1, 0, 1])}
+        super().__init__(Xin=coords, k=k, rescale=False, center=False, plotting=plotting, **kwargs)
 
 
 def _sample_pairs_within(rng, n, p):

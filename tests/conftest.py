@@ -57,3 +57,8 @@ def golden_doctest():
 @pytest.fixture(scope="session")
 def golden_ops():
     return load_golden("ops_sensor123.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_knn():
+    return load_golden("knn.npz")

@@ -179,6 +179,30 @@ def ops_sensor123():
     np.savez_compressed(os.path.join(OUT, "ops_sensor123.npz"), **out)
 
 
+def knn():
+    """NNGraph (nngraph.py:113-297) on small point clouds, Sensor variants."""
+    out = {}
+    rng = np.random.default_rng(3)
+    X3 = rng.standard_normal((200, 3)) * np.array([1.0, 2.0, 0.5]) + 4.0
+    G = graphs.NNGraph(X3, k=5)  # center=True, rescale=True
+    out["X3"] = X3
+    out.update(csr_parts(G.W, "W3"))
+    out["X3_coords"] = G.coords
+    out["sigma3"] = np.float64(G.sigma)
+    X1 = rng.uniform(0, 10, (64, 1))
+    G = graphs.NNGraph(X1, k=3, center=False, rescale=False, sigma=0.7)
+    out["X1"] = X1
+    out.update(csr_parts(G.W, "W1"))
+    G = graphs.Sensor(123, seed=42)
+    out.update(csr_parts(G.W, "Wsensor"))
+    out["sensor_coords"] = G.coords
+    out["sensor_sigma"] = np.float64(G.sigma)
+    G = graphs.Sensor(144, k=4, distributed=True, seed=7)
+    out.update(csr_parts(G.W, "Wdist"))
+    out["dist_coords"] = G.coords
+    np.savez_compressed(os.path.join(OUT, "knn.npz"), **out)
+
+
 if __name__ == "__main__":
     print("pygsp", pygsp.__version__)
     if len(sys.argv) > 1:  # e.g. `gen_golden.py ops_sensor123`: regenerate only the named fixtures
@@ -190,6 +214,7 @@ if __name__ == "__main__":
     doctest_sensor30()
     laplacians4()
     ops_sensor123()
+    knn()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,98 @@
+"""Device nearest-neighbour graph construction against the reference's golden
+vectors (tests/golden/knn.npz) and the KD-tree oracle (oracle/knn_oracle.py).  Needs a real
+MI355X: `-m gpu`.
+
+The bar here is integer/bit work for the neighbour lists and distances (same arithmetic as the
+KD-tree: bit-exact), 1e-12 relative for the weights (the mean distance sigma is summed in a different order, and it sits
+in the exponent).
+"""
+import numpy as np
+import pytest
+
+from conftest import csr_from
+from oracle import knn_oracle as knn
+from pygsp_amd import engine, graphs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return engine.default_context(0)
+
+
+def check_against_oracle(ctx, X, k, sigma=None):
+    W, sg, info = engine.knn_graph(X, k, sigma, ctx=ctx, neighbors=True)
+    Wr, sr, NNr, Dr = knn.knn_weights(X, k, sigma)
+    np.testing.assert_array_equal(info["NN"], NNr)
+    np.testing.assert_array_equal(info["D"], Dr)           # bit for bit
+    assert abs(sg - sr) <= 1e-13 * sr                       # summation order of the mean
+    assert W.nnz == Wr.nnz
+    assert W.has_sorted_indices
+    np.testing.assert_array_equal(W.indptr, Wr.indptr)
+    np.testing.assert_array_equal(W.indices, Wr.indices)
+    assert np.max(np.abs(W.data - Wr.data) / Wr.data) < 1e-12
+    assert abs(W - W.T).max() == 0
+    return W
+
+
+def test_golden(ctx, golden_knn):
+    g = golden_knn
+    G = graphs.NNGraph(g["X3"], k=5)
+    np.testing.assert_allclose(G.coords, g["X3_coords"], rtol=0, atol=1e-14)
+    Wref = csr_from(g, "W3")
+    assert G.W.nnz == Wref.nnz and abs(G.W - Wref).max() < 1e-15
+    assert abs(G.sigma - float(g["sigma3"])) < 1e-15
+    G1 = graphs.NNGraph(g["X1"], k=3, center=False, rescale=False, sigma=0.7)
+    assert abs(G1.W - csr_from(g, "W1")).max() < 1e-15
+    Gs = graphs.Sensor(123, seed=42)
+    np.testing.assert_array_equal(Gs.coords, g["sensor_coords"])
+    assert Gs.W.nnz == csr_from(g, "Wsensor").nnz and abs(Gs.W - csr_from(g, "Wsensor")).max() < 1e-15
+    Gd = graphs.Sensor(144, k=4, distributed=True, seed=7)
+    assert abs(Gd.W - csr_from(g, "Wdist")).max() < 1e-15
+    with pytest.raises(ValueError):
+        graphs.Sensor(10, k=10)
+    with pytest.raises(ValueError):
+        graphs.Sensor(10, distributed=True)
+    with pytest.raises(NotImplementedError):
+        graphs.NNGraph(g["X3"], NNtype="radius")
+    with pytest.raises(ValueError):
+        engine.knn_graph(np.zeros((50, 4)), 3, ctx=ctx)      # 4 dimensions: not covered, says so
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_oracle_uniform(ctx, d):
+    rng = np.random.default_rng(10 + d)
+    for N, k in ((3000, 6), (50000, 8), (20000, 20), (5000, 40)):
+        check_against_oracle(ctx, rng.uniform(0, 1, (N, d)), k)
+
+
+def test_oracle_clustered_and_degenerate(ctx):
+    rng = np.random.default_rng(99)
+    # strongly non-uniform: most points in a small blob (many points per grid cell)
+    X = np.concatenate([rng.normal(0.5, 0.01, (4000, 2)), rng.uniform(0, 1, (1000, 2))])
+    check_against_oracle(ctx, X, 7)
+    # points on a line inside the plane (one extent is zero)
+    X = np.stack([rng.uniform(0, 1, 2000), np.full(2000, 0.25)], axis=1)
+    check_against_oracle(ctx, X, 4)
+    # tiny graphs, k = N - 1
+    check_against_oracle(ctx, rng.uniform(0, 1, (9, 2)), 8)
+    check_against_oracle(ctx, rng.uniform(0, 1, (2, 3)), 1)
+    # given sigma
+    check_against_oracle(ctx, rng.uniform(0, 1, (1000, 3)), 5, sigma=0.05)
+    # exact duplicates: every distance list still sorted, no self loops, symmetric
+    X = rng.uniform(0, 1, (500, 2))
+    X[100:110] = X[0]
+    W, _, info = engine.knn_graph(X, 5, ctx=ctx, neighbors=True)
+    assert (np.diff(info["D"], axis=1) >= 0).all() and W.diagonal().max() == 0
+    assert (info["NN"] != np.arange(500)[:, None]).all() and abs(W - W.T).max() == 0
+
+
+def test_sensor_headline_scale(ctx):
+    """The bench graph: 1M points, k = 8 - identical to the host construction."""
+    W, coords = graphs.sensor_weights(1000000, k=8, seed=42)
+    Wd, sigma, info = engine.knn_graph(coords, 8, ctx=ctx)
+    assert Wd.nnz == W.nnz
+    np.testing.assert_array_equal(Wd.indices, W.indices)
+    assert np.max(np.abs(Wd.data - W.data) / W.data) < 1e-12
+    assert info["build_ms"] < 2000

@@ -5,6 +5,7 @@ import pytest
 
 from conftest import csr_from, rel_err
 from oracle import cheby_oracle as orc
+from oracle import knn_oracle as knn
 from oracle import ops_oracle as ops
 
 
@@ -182,3 +183,25 @@ def test_ops_tikhonov(golden_ops):
     assert rel_err(ops.classification_tikhonov(L, lab.copy(), mask, 0), g["class_tau0"]) < 1e-12
     with pytest.raises(ValueError):
         ops.regression_tikhonov(L, m0, mask[:-1], 0)
+
+
+# ---- nearest-neighbour graph construction (oracle/knn_oracle.py) ----------------------
+def test_knn_golden(golden_knn):
+    g = golden_knn
+    X = knn.preprocess(g["X3"])
+    np.testing.assert_allclose(X, g["X3_coords"], rtol=0, atol=1e-14)
+    W, sigma, NN, D = knn.knn_weights(X, 5)
+    Wref = csr_from(g, "W3")
+    assert abs(sigma - float(g["sigma3"])) < 1e-15
+    assert W.nnz == Wref.nnz and abs(W - Wref).max() < 1e-16
+    assert NN.shape == (200, 5) and (np.diff(D, axis=1) >= 0).all()
+    W1, s1, _, _ = knn.knn_weights(knn.preprocess(g["X1"], False, False), 3, sigma=0.7)
+    assert s1 == 0.7 and abs(W1 - csr_from(g, "W1")).max() < 1e-16
+    Ws, sg, _, _ = knn.knn_weights(knn.sensor_coords(123, seed=42), 6)
+    np.testing.assert_array_equal(knn.sensor_coords(123, seed=42), g["sensor_coords"])
+    assert abs(Ws - csr_from(g, "Wsensor")).max() < 1e-16 and abs(sg - float(g["sensor_sigma"])) < 1e-16
+    cd = knn.sensor_coords(144, seed=7, distributed=True)
+    np.testing.assert_array_equal(cd, g["dist_coords"])
+    assert abs(knn.knn_weights(cd, 4)[0] - csr_from(g, "Wdist")).max() < 1e-16
+    with pytest.raises(ValueError):
+        knn.knn_weights(cd[:4], 4)
