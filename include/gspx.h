@@ -164,6 +164,16 @@ int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s
  * (0: no tiles set) */
 int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
 
+/* Optional acceleration structure for gspx_cheby_filter* with ONE filter: one-level row tiles
+ * (64-row blocks of the internal vertex order: per block the distinct rows it gathers, s1ptr /
+ * s1rows; per stored entry the 16-bit position of its column in that list, lidx, pads = 0;
+ * pygsp_amd/tiling.py builds them from gspx_graph_download_internal).  With tiles set (and option
+ * "tile_gather" = 1, the default) every recurrence step stages the gathered panel in LDS
+ * (k_step_tile).  block_rows == 0 drops the tiles.  stats (nullable): blocks, blocks on the
+ * plain-gather path (tile too large for LDS), dynamic LDS bytes per workgroup. */
+int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
+                                const int32_t* s1rows, const uint16_t* lidx, int64_t* stats);
+
 /* ---- operators on the same device CSR --------------------------------
  * Panels are DEVICE pointers (gspx_buf_ptr or any other device allocation), row-major N x Nsig,
  * compute dtype of the graph, caller's vertex order.

@@ -7,6 +7,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gspx.hip -o libgspx.so
 #include "gspx_kernels.hip.h"
+#include "gspx_tile_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -101,6 +102,8 @@ struct Options {
   int64_t interleave = 0;       // panel kernel: waves of a workgroup advance as one front
   int64_t newton_pair = 1;      // use the fused two-step kernel when the graph carries tiles
   int64_t pair_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
+  int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
+  int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
@@ -153,6 +156,10 @@ struct gspx_graph {
   int tile_rows = 0, tile_nb = 0, tile_max_n1 = 0, tile_max_n2 = 0;
   double fval_lmax = -1.0;
   double build_ms = 0.0;
+  // one-level row tiles of the LDS-staged recurrence step (optional; gspx_tile_kernels.hip.h)
+  DevMem gt_hdr, gt_s1rows, gt_lidx;
+  int gt_rows = 0, gt_nb = 0, gt_slow = 0;
+  size_t gt_lds = 0;
   // differential operator (built on first use; gspx_ops.hip.h)
   int lap_type = GSPX_LAP_COMBINATORIAL;
   bool edges_built = false;
@@ -247,6 +254,8 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "synthesis")) return &o.synthesis;
   if (!strcmp(key, "newton_pair")) return &o.newton_pair;
   if (!strcmp(key, "pair_workgroups")) return &o.pair_workgroups;
+  if (!strcmp(key, "tile_gather")) return &o.tile_gather;
+  if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
@@ -785,6 +794,62 @@ extern "C" int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]) {
   return GSPX_OK;
 }
 
+extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
+                                           const int32_t* s1rows, const uint16_t* lidx, int64_t* stats) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (block_rows == 0) {  // drop the tiles
+    g->gt_rows = 0;
+    return GSPX_OK;
+  }
+  if (block_rows != GSPX_TILE_BR)
+    return set_err(GSPX_ERR_INVALID, "gather tiles must use %d-row blocks", GSPX_TILE_BR);
+  if (!s1ptr || !s1rows || !lidx || nb < 1 || nb != (int)((g->N + block_rows - 1) / block_rows))
+    return set_err(GSPX_ERR_INVALID, "gspx_graph_set_gather_tiles: bad argument");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  std::vector<int> rp((size_t)g->N + 1);
+  HIPCHK(hipMemcpy(rp.data(), g->rptr.p, ((size_t)g->N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  for (auto& r : rp) r &= ~3;
+  // three workgroups per CU: 52 KB each (h tile + the block's slice of entries)
+  const size_t lds = (size_t)52 * 1024;
+  const size_t esz = elt_size(g->dtype);
+  std::vector<int> hdr((size_t)nb * 4);
+  int slow = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int lo = s1ptr[b], n1 = s1ptr[b + 1] - lo;
+    const int r0 = b * block_rows, r1 = (int)std::min<int64_t>((int64_t)r0 + block_rows, g->N);
+    const int ent = rp[r1] - rp[r0];
+    if (n1 < 0 || lo < 0) return set_err(GSPX_ERR_INVALID, "gspx_graph_set_gather_tiles: bad s1ptr");
+    for (int o = lo; o < lo + n1; ++o)
+      if (s1rows[o] < 0 || s1rows[o] >= g->N)
+        return set_err(GSPX_ERR_INVALID, "gspx_graph_set_gather_tiles: bad S1 row");
+    const size_t need = (size_t)n1 * 256 + (((size_t)ent * esz + 15) & ~(size_t)15) +
+                        (((size_t)ent * 2 + 15) & ~(size_t)15) + 32;
+    const bool fast = n1 <= GSPX_TILE_MAXN1 && n1 < 65535 && need <= lds;
+    slow += !fast;
+    hdr[(size_t)b * 4 + 0] = lo;
+    hdr[(size_t)b * 4 + 1] = fast ? n1 : -1;
+    hdr[(size_t)b * 4 + 2] = rp[r0];
+    hdr[(size_t)b * 4 + 3] = ent;
+  }
+  const int n_s1 = s1ptr[nb];
+  CHK(g->gt_hdr.alloc(hdr.size() * 4 + 64));
+  CHK(g->gt_s1rows.alloc((size_t)std::max(n_s1, 1) * 4 + 64));
+  CHK(g->gt_lidx.alloc((size_t)g->nnz_int * 2 + 128));
+  HIPCHK(hipMemcpy(g->gt_hdr.p, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->gt_s1rows.p, s1rows, (size_t)n_s1 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g->gt_lidx.p, lidx, (size_t)g->nnz_int * 2, hipMemcpyHostToDevice));
+  g->gt_rows = block_rows;
+  g->gt_nb = nb;
+  g->gt_slow = slow;
+  g->gt_lds = lds;
+  if (stats) {
+    stats[0] = nb;
+    stats[1] = slow;
+    stats[2] = (int64_t)lds;
+  }
+  return GSPX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // step schedule ("plan")
 // ------------------------------------------------------------------------------------------------
@@ -1208,8 +1273,57 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   a.y = y;
   a.ldy = ldy;
   a.perm = perm;
+  // LDS-staged gather (gspx_tile_kernels.hip.h): one filter, fused flush, 16-byte lanes everywhere
+  constexpr int TVEC = 16 / (int)sizeof(T);
+  const bool tile_ok = opt.tile_gather && g->gt_rows == GSPX_TILE_BR && nf == 1 && !deferred &&
+                       (ld % TVEC) == 0 && (ldy % TVEC) == 0 && (((uintptr_t)y / sizeof(T)) % TVEC) == 0 &&
+                       U * sizeof(T) < ((size_t)1 << 31) && (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31);
+  const int tile_ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
+  void (*tile_kernel)(const TileArgs<T>) = tile_ncol == 1 ? k_step_tile<T, 1> : k_step_tile<T, 0>;
+  if (tile_ok)
+    HIPCHK(hipFuncSetAttribute((const void*)tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)g->gt_lds));
   for (int k = 1; k <= K; ++k) {
     const PlanStep& ps = plan[(size_t)k - 1];
+    if (tile_ok) {
+      TileArgs<T> t{};
+      t.rowptr = g->rptr.as<int>();
+      t.col = g->rcol.as<int>();
+      t.val = g->fval.as<T>();
+      t.hdr = g->gt_hdr.as<int>();
+      t.s1rows = g->gt_s1rows.as<int>();
+      t.lidx = g->gt_lidx.as<unsigned short>();
+      t.cur = slots + (size_t)((k - 1) & 1) * U;
+      t.old = ps.gamma == 0.0 ? t.cur : slots + (size_t)(k & 1) * U;
+      t.out = slots + (size_t)(k & 1) * U;
+      t.racc = racc;
+      t.y = y;
+      t.perm = perm;
+      t.N = N;
+      t.ld = ld;
+      t.ldy = ldy;
+      t.panel_bytes = (unsigned)(U * sizeof(T));
+      t.val_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
+      t.lidx_bytes = (unsigned)((size_t)g->nnz_int * 2);
+      t.nb = g->gt_nb;
+      t.ncol = tile_ncol;
+      t.per_xcd = (t.nb + 7) / 8;
+      t.lds_bytes = (int)g->gt_lds;
+      t.scale = (T)ps.scale;
+      t.gamma = (T)ps.gamma;
+      t.flush = ps.flush;
+      t.final = ps.final;
+      if (ps.flush) {
+        t.wn = (T)ps.w[0];
+        t.wc = (T)ps.w[1];
+        t.wo = (T)ps.w[2];
+      }
+      unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)ctx->cu_count) / 8 * 8);
+      if (opt.tile_workgroups > 0)
+        nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
+      hipLaunchKernelGGL(tile_kernel, dim3(nwg), dim3(512), g->gt_lds, st, t);
+      continue;
+    }
     if (deferred) {
       a.cur = slots + (size_t)(k - 1) * U;
       a.old = k >= 2 ? slots + (size_t)(k - 2) * U : slots;

@@ -1,0 +1,236 @@
+// gspx_tile_kernels.hip.h - the recurrence step with the gathered panel staged in LDS ("x tile").
+//
+//   T_k = scale * (F T_{k-1}) + gamma * T_{k-2}   (+ the fused flush of one filter)
+//   approximations.py:107-109, same arithmetic as k_step_panel / k_step_lds (gspx_kernels.hip.h)
+//
+// The internal vertex order is cut into 64-row blocks.  The host (pygsp_amd/tiling.py) lists, per
+// block, the distinct rows its entries touch (S1: 123 rows on average on the headline graph) and,
+// for every stored entry, the 16-bit position of its column inside that list.  A workgroup
+//   1. loads the S1 rows of T_{k-1} straight into LDS (buffer_load ... lds: 1 KiB per wave
+//      instruction, no VGPRs), one 256-byte column chunk at a time;
+//   2. copies the block's contiguous slice of matrix entries (value + 16-bit position) into LDS,
+//      coalesced, once for all column chunks of the block;
+//   3. computes its rows from LDS (ds_read_b128 gathers, broadcast reads of the entries).
+// Against the plain gather kernels this turns 11 gathers per row (a third of which miss the L1 and
+// re-fetch from L2) into 1.9 coalesced row fetches per row, and shrinks the streamed matrix from
+// (elt + 4) to (elt + 2) bytes per entry.  Workgroups are persistent; XCD x walks a contiguous
+// eighth of the blocks, its workgroups interleaved, so the halo rows of concurrently staged blocks
+// meet in that XCD's L2.  Block headers are prefetched two blocks ahead, row lists one block ahead.
+// Blocks whose tile does not fit (n1 > 160 rows or rows longer than the LDS slice) take a plain
+// global-gather path inside the same kernel.
+#pragma once
+
+#include "gspx_kernels.hip.h"
+
+namespace gspx {
+
+template <typename T> struct TileArgs {
+  const int* rowptr;   // internal padded CSR
+  const int* col;      // global columns (slow path only)
+  const T* val;        // factor values F
+  const int* hdr;      // [nb][4]: s1lo, n1 (-1: slow path), rp0 (first entry of the block), ent (entries)
+  const int* s1rows;   // concatenated S1 lists
+  const u16* lidx;     // [nnz_int] position of each entry's column in its block's S1 (pads: 0)
+  const T* cur;
+  const T* old;
+  T* out;
+  T* racc;
+  T* y;
+  const int* perm;
+  int N;
+  u32 ld, ldy;
+  u32 panel_bytes, val_bytes, lidx_bytes;
+  int nb, ncol, per_xcd;
+  int lds_bytes;
+  T scale, gamma;
+  T wn, wc, wo;  // flush weights of the single filter
+  int flush;     // 0 none, 1 write, 2 accumulate
+  int final;     // 1: the flush result goes to y (caller's order)
+};
+
+constexpr int GSPX_TILE_BR = 64;      // rows per block
+constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group)
+
+template <typename T, int NCOL>  // NCOL = 1: one column chunk per row; 0: a.ncol chunks
+__global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef typename VT<T, VEC>::t V;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gspx_smem[];
+
+  const int tid = threadIdx.x;
+  const int lane16 = tid & 15;
+  const int grp = tid >> 4;  // 0..31: two rows of the block each
+  const int wave = tid >> 6;
+  const int nwx = (int)(gridDim.x >> 3);
+  const int xlo = (int)(blockIdx.x & 7) * a.per_xcd;
+  int k1 = xlo + a.per_xcd;
+  if (k1 > a.nb) k1 = a.nb;
+  const int k0 = xlo + (int)(blockIdx.x >> 3);
+  if (k0 >= k1) return;
+
+  constexpr u32 POISON = 0x80000000u;
+  const rsrc_t rcur = __builtin_amdgcn_make_buffer_rsrc((void*)a.cur, 0, a.panel_bytes, 0x00020000);
+  const rsrc_t rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.panel_bytes, 0x00020000);
+  const rsrc_t rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.panel_bytes, 0x00020000);
+  const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.val, 0, a.val_bytes, 0x00020000);
+  const rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)a.lidx, 0, a.lidx_bytes, 0x00020000);
+  const u32 ldb = a.ld * (u32)sizeof(T);
+
+  struct Meta { int rows[5]; int rp[3]; };
+  auto load_hdr = [&](int k) { return *(const int4*)(a.hdr + (size_t)k * 4); };
+  auto uniform = [](int4 h) {
+    int4 u;
+    u.x = __builtin_amdgcn_readfirstlane(h.x); u.y = __builtin_amdgcn_readfirstlane(h.y);
+    u.z = __builtin_amdgcn_readfirstlane(h.z); u.w = __builtin_amdgcn_readfirstlane(h.w);
+    return u;
+  };
+  auto load_meta = [&](int k, const int4& h) {
+    Meta m;
+    const int n1 = h.y;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int u = grp + 32 * t;
+      m.rows[t] = a.s1rows[h.x + (u < n1 ? u : 0)];
+    }
+    int r = k * GSPX_TILE_BR + grp * 2;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) m.rp[t] = a.rowptr[(r + t) <= a.N ? (r + t) : a.N];
+    return m;
+  };
+  V* const tile = (V*)gspx_smem;
+  auto stage = [&](const Meta& m, int n1, u32 cb) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      if (grp + 32 * t < n1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rcur, (lds_ptr)(gspx_smem + (wave * 4 + 32 * t) * 256), 16,
+                                                 (u32)m.rows[t] * ldb + cb, 0, 0, 0);
+    }
+  };
+  auto chunk_off = [&](int c) {
+    const u32 col0 = (c * 16 + lane16) * VEC;
+    return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
+  };
+
+  int4 H = uniform(load_hdr(k0));
+  Meta M = load_meta(k0, H);
+  int4 Hn = uniform(load_hdr(k0 + nwx < k1 ? k0 + nwx : k0));
+  int k = k0;
+  if (H.y >= 0) stage(M, H.y, chunk_off(0));
+
+  // one pass = column chunk c of block k; returns false after the workgroup's last pass
+  auto pass = [&](const int c, const bool first, const bool last) __attribute__((always_inline)) {
+    const int n1 = H.y, rp0 = H.z, ent = H.w;
+    const bool fast = n1 >= 0;
+    T* const mval = (T*)(tile + (fast ? n1 : 0) * 16);
+    u16* const midx = (u16*)(mval + ent);
+    const int row0 = k * GSPX_TILE_BR + grp * 2;
+    const int s0 = M.rp[0] & ~3, s1 = M.rp[1] & ~3, s2 = M.rp[2] & ~3;
+    const u32 col0 = (c * 16 + lane16) * VEC;
+    const bool on = col0 < a.ld;
+    const u32 cb = on ? col0 * (u32)sizeof(T) : POISON;
+    // T_{k-2} (and the accumulator) of the group's two rows
+    V ov[2], ra[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
+      ov[t] = VT<T, VEC>::bload(rold, a.gamma != T(0) ? off : POISON);
+      ra[t] = VT<T, VEC>::bload(rra, a.flush == 2 ? off : POISON);
+    }
+    // the block's slice of matrix entries, coalesced (values: 16-byte pieces, positions likewise)
+    u32x4 ev = 0, ei = 0;
+    const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent * 2 + 15) >> 4;
+    if (first && fast) {
+      ev = __builtin_amdgcn_raw_buffer_load_b128(rv, tid < nv16 ? (u32)rp0 * (u32)sizeof(T) + tid * 16u : POISON, 0, 0);
+      ei = __builtin_amdgcn_raw_buffer_load_b128(ri, tid < ni16 ? (u32)rp0 * 2u + tid * 16u : POISON, 0, 0);
+    }
+    int4 Hv = Hn;
+    if (last) {  // the next block's row lists, the header after that
+      M = load_meta(k + nwx < k1 ? k + nwx : k, Hn);
+      Hv = load_hdr(k + 2 * nwx < k1 ? k + 2 * nwx : k);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (first && fast) {
+      if (tid < nv16) *(u32x4*)((unsigned char*)mval + tid * 16) = ev;
+      if (tid < ni16) *(u32x4*)((unsigned char*)midx + tid * 16) = ei;
+      for (int i = tid + 512; i < nv16; i += 512)  // slices longer than 8 KiB of values: rare
+        *(u32x4*)((unsigned char*)mval + i * 16) =
+            __builtin_amdgcn_raw_buffer_load_b128(rv, (u32)rp0 * (u32)sizeof(T) + i * 16u, 0, 0);
+      for (int i = tid + 512; i < ni16; i += 512)
+        *(u32x4*)((unsigned char*)midx + i * 16) =
+            __builtin_amdgcn_raw_buffer_load_b128(ri, (u32)rp0 * 2u + i * 16u, 0, 0);
+    }
+    __syncthreads();  // tile and entries in place
+    int4 Hnn = Hn;
+    if (last) Hnn = uniform(Hv);  // youngest load of the pass: everything prefetched has landed
+    V nv[2], cv[2];
+    if (fast) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int s = t == 0 ? s0 : s1, e = t == 0 ? s1 : s2;
+        V self;
+        const V acc = lds_row_dot<T, V>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
+                                        lane16, self);
+        nv[t] = a.scale * acc + a.gamma * ov[t];
+        cv[t] = self;
+      }
+    } else {
+      // plain gathers from global memory (tile too large for LDS)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int s = t == 0 ? s0 : s1, e = t == 0 ? s1 : s2;
+        V acc = 0, self = 0;
+        if (row0 + t < a.N) {
+          for (int j = s; j < e; ++j) {
+            const int cc = a.col[j];
+            const V xv = VT<T, VEC>::bload(rcur, cc < a.N ? (u32)cc * ldb + cb : POISON);
+            if (j == s) self = xv;  // entry 0 is the diagonal slot
+            acc += a.val[j] * xv;
+          }
+        }
+        nv[t] = a.scale * acc + a.gamma * ov[t];
+        cv[t] = self;
+      }
+    }
+    __syncthreads();  // everybody is done with the tile
+    bool more = true;
+    if (last) {
+      H = Hn;
+      Hn = Hnn;
+      more = k + nwx < k1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // next pass's tile: the next chunk of this block, or chunk 0 of the next block
+    if (more && H.y >= 0) stage(M, H.y, chunk_off(last ? 0 : c + 1));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = row0 + t;
+      if (row < a.N && on) {
+        *(V*)(a.out + (size_t)row * a.ld + col0) = nv[t];
+        if (a.flush) {
+          V res = a.wn * nv[t] + a.wc * cv[t] + a.wo * ov[t];
+          if (a.flush == 2) res += ra[t];
+          if (a.final) {
+            const size_t orow = a.perm ? (size_t)a.perm[row] : (size_t)row;
+            *(V*)(a.y + orow * a.ldy + col0) = res;
+          } else {
+            *(V*)(a.racc + (size_t)row * a.ld + col0) = res;
+          }
+        }
+      }
+    }
+    if (last) k += nwx;
+    return more;
+  };
+  for (;;) {
+    if constexpr (NCOL == 1) {
+      if (!pass(0, true, true)) break;
+    } else {
+      bool more = true;
+      for (int c = 0; c < a.ncol; ++c) more = pass(c, c == 0, c == a.ncol - 1);
+      if (!more) break;
+    }
+  }
+}
+
+}  // namespace gspx

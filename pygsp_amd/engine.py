@@ -404,6 +404,27 @@ def _newton_methods():
         st["unstaged_blocks"], st["fallback_lds_bytes"] = int(out[1]), int(out[2])
         return st
 
+    def enable_gather_tiles(self):
+        """Build (numpy) and upload the one-level row tiles of the LDS-staged recurrence step
+        (k_step_tile): per 64-row block the distinct rows it gathers, per entry a 16-bit position in
+        that list.  With them (and option "tile_gather" = 1, the default) single-filter Chebyshev
+        filtering stages the gathered panel in LDS.  Returns tile statistics."""
+        from . import tiling
+        rp, col = self.download_internal()
+        t = tiling.build_tiles(rp, col, self.N, 64, levels=1)
+        lidx = t["lidx1"].copy()
+        lidx[lidx == tiling.PAD] = 0  # pads carry the value 0: any valid position will do
+        c = np.ascontiguousarray
+        stats = np.zeros(3, dtype=np.int64)
+        _capi.check(_capi.load().gspx_graph_set_gather_tiles(
+            self._h, 64, t["nb"], _capi.ptr(c(t["s1ptr"])), _capi.ptr(c(t["s1rows"])), _capi.ptr(c(lidx)),
+            _capi.ptr(stats)))
+        return {"nb": t["nb"], "max_n1": t["max_n1"], "mean_n1": t["mean_n1"],
+                "slow_blocks": int(stats[1]), "lds_bytes": int(stats[2])}
+
+    def disable_gather_tiles(self):
+        _capi.check(_capi.load().gspx_graph_set_gather_tiles(self._h, 0, 0, None, None, None, None))
+
     def disable_pair_tiles(self):
         _capi.check(_capi.load().gspx_graph_set_tiles(self._h, 0, 0, None, None, None, None, None,
                                                       None, 0, None, 0, 0))
@@ -412,6 +433,8 @@ def _newton_methods():
     DeviceGraph.newton_filter_dev = newton_filter_dev
     DeviceGraph.download_internal = download_internal
     DeviceGraph.enable_pair_tiles = enable_pair_tiles
+    DeviceGraph.enable_gather_tiles = enable_gather_tiles
+    DeviceGraph.disable_gather_tiles = disable_gather_tiles
     DeviceGraph.disable_pair_tiles = disable_pair_tiles
 
 

@@ -23,9 +23,10 @@ import numpy as np
 PAD = 0xFFFF
 
 
-def build_tiles(rptr, rcol, N, block_rows=64):
+def build_tiles(rptr, rcol, N, block_rows=64, levels=2):
     """rptr: int32[N+1] internal row starts (low 2 bits may carry pad counts), rcol: int32[nnz_int]
-    internal columns (pads == N).  Returns a dict of the arrays above plus max_n1 / max_n2."""
+    internal columns (pads == N).  Returns a dict of the arrays above plus max_n1 / max_n2.
+    levels=1 stops after S1 / lidx1 (the LDS-staged recurrence step needs no more)."""
     rptr = (np.asarray(rptr, dtype=np.int64) & ~3)
     rcol = np.asarray(rcol, dtype=np.int64)
     BR = int(block_rows)
@@ -49,6 +50,11 @@ def build_tiles(rptr, rcol, N, block_rows=64):
     if loc.size and loc.max() >= PAD:
         raise ValueError("tile too large for 16-bit local indices")
     lidx1[real] = loc.astype(np.uint16)
+
+    if levels == 1:
+        n1 = np.diff(s1ptr)
+        return {"block_rows": BR, "nb": nb, "s1ptr": s1ptr, "s1rows": s1rows, "lidx1": lidx1,
+                "max_n1": int(n1.max()) if nb else 0, "mean_n1": float(n1.mean()) if nb else 0.0}
 
     # ---- level 2: every (block, row in S1) occurrence expands to that row's entries --------------
     occ_rows = s1rows.astype(np.int64)
