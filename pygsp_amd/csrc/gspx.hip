@@ -1195,6 +1195,45 @@ static hipEvent_t pool_event(gspx_ctx* ctx, size_t& i_ref) {
 
 // One (sub)problem: nf filters applied to one batch of `ld` signals whose first column is
 // x/y column c0.  x: [N][ldx] (+c0), y: [nf][N][ldy] (+c0).
+// LDS-staged gather step (gspx_tile_kernels.hip.h): usable when the graph carries gather tiles and
+// every panel the kernel touches is made of 16-byte lane pieces
+template <typename T>
+static bool tile_usable(const gspx_graph* g, const Options& opt, unsigned ld, const T* y, unsigned ldy) {
+  constexpr int TVEC = 16 / (int)sizeof(T);
+  const size_t U = (size_t)g->N * ld;
+  return opt.tile_gather && g->gt_rows == GSPX_TILE_BR && (ld % TVEC) == 0 && (ldy % TVEC) == 0 &&
+         (((uintptr_t)y / sizeof(T)) % TVEC) == 0 && U * sizeof(T) < ((size_t)1 << 31) &&
+         (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31);
+}
+// fills the graph / geometry fields of t and launches; the caller sets cur, old, out, racc, y,
+// ldy, perm, scale, gamma, beta, flush, final, wn, wc, wo
+template <typename T>
+static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, unsigned ld, hipStream_t st) {
+  const int ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
+  void (*kern)(const TileArgs<T>) = ncol == 1 ? k_step_tile<T, 1> : ncol == 2 ? k_step_tile<T, 2> : k_step_tile<T, 0>;
+  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gt_lds));
+  t.rowptr = g->rptr.as<int>();
+  t.col = g->rcol.as<int>();
+  t.val = g->fval.as<T>();
+  t.hdr = g->gt_hdr.as<int>();
+  t.s1rows = g->gt_s1rows.as<int>();
+  t.lidx = g->gt_lidx.as<unsigned short>();
+  t.N = (int)g->N;
+  t.ld = ld;
+  t.panel_bytes = (unsigned)((size_t)g->N * ld * sizeof(T));
+  t.val_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
+  t.lidx_bytes = (unsigned)((size_t)g->nnz_int * 2);
+  t.nb = g->gt_nb;
+  t.ncol = ncol;
+  t.per_xcd = (t.nb + 7) / 8;
+  t.lds_bytes = (int)g->gt_lds;
+  unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)g->ctx->cu_count) / 8 * 8);
+  if (opt.tile_workgroups > 0)
+    nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), g->gt_lds, st, t);
+  return GSPX_OK;
+}
+
 template <typename T>
 static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp, const T* x,
                      unsigned ldx, T* y, unsigned ldy, unsigned ld, bool deferred,
@@ -1273,44 +1312,22 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   a.y = y;
   a.ldy = ldy;
   a.perm = perm;
-  // LDS-staged gather (gspx_tile_kernels.hip.h): one filter, fused flush, 16-byte lanes everywhere
-  constexpr int TVEC = 16 / (int)sizeof(T);
-  const bool tile_ok = opt.tile_gather && g->gt_rows == GSPX_TILE_BR && nf == 1 && !deferred &&
-                       (ld % TVEC) == 0 && (ldy % TVEC) == 0 && (((uintptr_t)y / sizeof(T)) % TVEC) == 0 &&
-                       U * sizeof(T) < ((size_t)1 << 31) && (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31);
-  const int tile_ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
-  void (*tile_kernel)(const TileArgs<T>) = tile_ncol == 1 ? k_step_tile<T, 1> : k_step_tile<T, 0>;
-  if (tile_ok)
-    HIPCHK(hipFuncSetAttribute((const void*)tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)g->gt_lds));
+  // LDS-staged gather: one filter with the fused flush
+  const bool tile_ok = nf == 1 && !deferred && tile_usable<T>(g, opt, ld, y, ldy);
   for (int k = 1; k <= K; ++k) {
     const PlanStep& ps = plan[(size_t)k - 1];
     if (tile_ok) {
       TileArgs<T> t{};
-      t.rowptr = g->rptr.as<int>();
-      t.col = g->rcol.as<int>();
-      t.val = g->fval.as<T>();
-      t.hdr = g->gt_hdr.as<int>();
-      t.s1rows = g->gt_s1rows.as<int>();
-      t.lidx = g->gt_lidx.as<unsigned short>();
       t.cur = slots + (size_t)((k - 1) & 1) * U;
       t.old = ps.gamma == 0.0 ? t.cur : slots + (size_t)(k & 1) * U;
       t.out = slots + (size_t)(k & 1) * U;
       t.racc = racc;
       t.y = y;
-      t.perm = perm;
-      t.N = N;
-      t.ld = ld;
       t.ldy = ldy;
-      t.panel_bytes = (unsigned)(U * sizeof(T));
-      t.val_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
-      t.lidx_bytes = (unsigned)((size_t)g->nnz_int * 2);
-      t.nb = g->gt_nb;
-      t.ncol = tile_ncol;
-      t.per_xcd = (t.nb + 7) / 8;
-      t.lds_bytes = (int)g->gt_lds;
+      t.perm = perm;
       t.scale = (T)ps.scale;
       t.gamma = (T)ps.gamma;
+      t.beta = T(0);
       t.flush = ps.flush;
       t.final = ps.final;
       if (ps.flush) {
@@ -1318,10 +1335,7 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
         t.wc = (T)ps.w[1];
         t.wo = (T)ps.w[2];
       }
-      unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)ctx->cu_count) / 8 * 8);
-      if (opt.tile_workgroups > 0)
-        nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
-      hipLaunchKernelGGL(tile_kernel, dim3(nwg), dim3(512), g->gt_lds, st, t);
+      CHK(launch_step_tile<T>(g, opt, t, ld, st));
       continue;
     }
     if (deferred) {
@@ -1634,6 +1648,7 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   // (one chunk: straight-line build; more: the runtime-count build, which measured faster than an
   // unrolled two-chunk build - that one spills)
   void (*pair_kernel)(const PairArgs<T>) = pair_ncol == 1 ? k_newton_pair<T, 1> : k_newton_pair<T, 0>;
+  const bool tile_ok = tile_usable<T>(g, opt, ld, y, ldy);
   int s_first_pair = K;  // steps >= this index run as fused pairs
   if (pair_ok) s_first_pair = K & 1;
   int pair_cur = (pair_ok && (K & 1)) ? 0 : -1;  // panel holding h before the next pair (-1 = X)
@@ -1691,6 +1706,21 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       continue;
     }
     const int j = K - 1 - s;
+    if (tile_ok) {
+      TileArgs<T> t{};
+      t.cur = (s == 0) ? X : H[(s - 1) & 1];
+      t.old = X;
+      t.out = H[s & 1];
+      t.racc = H[0];  // never read or written (flush == 0)
+      t.y = y;
+      t.ldy = ldy;
+      t.perm = perm;
+      step_params(s, t.scale, t.beta, t.gamma);
+      t.flush = 0;
+      t.final = (j == 0) ? 1 : 0;
+      CHK(launch_step_tile<T>(g, opt, t, ld, st));
+      continue;
+    }
     a.cur = (s == 0) ? X : H[(s - 1) & 1];
     a.out = H[s & 1];
     if (s == 0) {

@@ -43,6 +43,7 @@ template <typename T> struct TileArgs {
   int nb, ncol, per_xcd;
   int lds_bytes;
   T scale, gamma;
+  T beta;        // coefficient of T_{k-1}'s own row (Newton-form steps; 0 for the recurrence)
   T wn, wc, wo;  // flush weights of the single filter
   int flush;     // 0 none, 1 write, 2 accumulate
   int final;     // 1: the flush result goes to y (caller's order)
@@ -51,7 +52,7 @@ template <typename T> struct TileArgs {
 constexpr int GSPX_TILE_BR = 64;      // rows per block
 constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group)
 
-template <typename T, int NCOL>  // NCOL = 1: one column chunk per row; 0: a.ncol chunks
+template <typename T, int NCOL>  // NCOL = 1, 2: that many 256-byte column chunks per row; 0: a.ncol chunks
 __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   constexpr int VEC = 16 / (int)sizeof(T);
   typedef typename VT<T, VEC>::t V;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
         V self;
         const V acc = lds_row_dot<T, V>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
                                         lane16, self);
-        nv[t] = a.scale * acc + a.gamma * ov[t];
+        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self;
         cv[t] = self;
       }
     } else {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
             acc += a.val[j] * xv;
           }
         }
-        nv[t] = a.scale * acc + a.gamma * ov[t];
+        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self;
         cv[t] = self;
       }
     }
@@ -206,6 +207,11 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     for (int t = 0; t < 2; ++t) {
       const int row = row0 + t;
       if (row < a.N && on) {
+        if (a.final && !a.flush) {  // Newton form: the last step's result is the output
+          const size_t orow = a.perm ? (size_t)a.perm[row] : (size_t)row;
+          *(V*)(a.y + orow * a.ldy + col0) = nv[t];
+          continue;
+        }
         *(V*)(a.out + (size_t)row * a.ld + col0) = nv[t];
         if (a.flush) {
           V res = a.wn * nv[t] + a.wc * cv[t] + a.wo * ov[t];
@@ -225,6 +231,9 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   for (;;) {
     if constexpr (NCOL == 1) {
       if (!pass(0, true, true)) break;
+    } else if constexpr (NCOL == 2) {
+      pass(0, true, false);
+      if (!pass(1, false, true)) break;
     } else {
       bool more = true;
       for (int c = 0; c < a.ncol; ++c) more = pass(c, c == 0, c == a.ncol - 1);

@@ -772,3 +772,60 @@ def test_newton_pair_kernel(ctx, dtype):
     y, _ = dev.newton_filter(nodes, d, x, lm)
     assert rel_err(y, orc.cheby_op(Lr, lm, c, x.astype(dtype).astype(np.float64))) < tol
     dev.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# LDS-staged recurrence step (k_step_tile): gathered panel in LDS, 16-bit tile positions
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tile_gather_kernel(ctx, dtype):
+    tol = TOL[np.dtype(dtype)] * 10
+    rng = np.random.default_rng(23)
+    W, coords = graphs.sensor_weights(20000, k=8, seed=9)
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    for perm in (engine.locality_order(W, coords), None):
+        dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+        stats = dev.enable_gather_tiles()
+        if perm is not None:  # locality order: (nearly) every block stages its tile in LDS
+            assert stats["slow_blocks"] * 20 < stats["nb"], stats
+        else:                 # vertex order of the generator: no locality, the plain-gather path
+            assert stats["slow_blocks"] > stats["nb"] // 2, stats
+        for nsig in (4, 8, 32, 64, 100, 128):
+            x = rng.standard_normal((W.shape[0], nsig))
+            x64 = x.astype(dtype).astype(np.float64)
+            for order in (30, 7, 3, 2, 1):
+                c = orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, order)
+                ref = orc.cheby_op(L, lmax, c, x64)
+                ctx.set_option("tile_gather", 1)
+                y1, _ = dev.cheby_filter(c, x, lmax)
+                ctx.set_option("tile_gather", 0)
+                y0, _ = dev.cheby_filter(c, x, lmax)
+                ctx.set_option("tile_gather", 1)
+                assert rel_err(y0[0], ref) < tol, (nsig, order, "plain")
+                assert rel_err(y1[0], ref) < tol, (nsig, order, "tile")
+                if order in (30, 2):
+                    nodes, d = filters.cheb_to_newton(c)
+                    yn, _ = dev.newton_filter(nodes, d, x, lmax)
+                    assert rel_err(yn, ref) < tol, (nsig, order, "newton on tiles")
+        # filterbanks and synthesis never take the tile path; they must be unaffected by the tiles
+        cb = np.stack([orc.compute_cheby_coeff(k, lmax, 12) for k in orc.mexican_hat_kernels(lmax, 3)])
+        x = rng.standard_normal((W.shape[0], 8))
+        yb, _ = dev.cheby_filter(cb, x, lmax)
+        refb = orc.cheby_op(L, lmax, cb, x.astype(dtype).astype(np.float64)).reshape(3, -1, 8)
+        assert rel_err(yb, refb) < tol
+        dev.disable_gather_tiles()
+        dev.destroy()
+    # a graph with isolated vertices, a hub and ragged rows; normalized Laplacian
+    Wr = random_graph(5000, 7, seed=33, hub=True, isolated=5)
+    for lt in ("combinatorial", "normalized"):
+        Lr = orc.laplacian(Wr, lt)
+        lm = upper_lmax(Wr) if lt == "combinatorial" else 2.0
+        dev = engine.DeviceGraph.from_w(Wr, lt, dtype=dtype, perm=engine.locality_order(Wr, None), ctx=ctx)
+        st = dev.enable_gather_tiles()
+        assert st["slow_blocks"] >= 1  # the hub's block does not fit
+        x = rng.standard_normal((5000, 16))
+        c = orc.compute_cheby_coeff(orc.heat_kernel(9, lm), lm, 12)
+        y, _ = dev.cheby_filter(c, x, lm)
+        assert rel_err(y[0], orc.cheby_op(Lr, lm, c, x.astype(dtype).astype(np.float64))) < tol
+        dev.destroy()

@@ -21,6 +21,15 @@ for dtype in (np.float32,np.float64):
         for _ in range(3):
             dev.cheby_filter_dev(c,bx.ptr,(by if tg else bz).ptr,64,lmax); t=ctx.last_timing(); best=min(best,t["steps_ms"]/30)
         print(np.dtype(dtype).name,"tile_gather",tg,"workgroups",wg,"ms per order %.4f"%best,flush=True)
+    nodes,d=filters.cheb_to_newton(c[0])
+    for tg in (0,1):
+        ctx.set_option("tile_gather",tg); ctx.set_option("tile_workgroups",0)
+        best=1e9
+        for _ in range(3):
+            dev.newton_filter_dev(nodes,d,bx.ptr,by.ptr,64,lmax); t=ctx.last_timing(); best=min(best,t["steps_ms"]/30)
+        print(np.dtype(dtype).name,"NEWTON tile_gather",tg,"ms per order %.4f"%best,flush=True)
+    ctx.set_option("tile_gather",1)
+    dev.cheby_filter_dev(c,bx.ptr,by.ptr,64,lmax)
     y1=by.download((N,64),dtype); y0=bz.download((N,64),dtype)
     print("max rel diff tile vs plain %.2e"%(np.max(abs(y1-y0))/np.max(abs(y0))),flush=True)
     ctx.set_option("tile_gather",1); ctx.set_option("tile_workgroups",0)
