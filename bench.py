@@ -64,6 +64,9 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
+    p.add_argument("--tiles", choices=["auto", "off"], default="auto",
+                   help="auto = the product default (LDS-staged recurrence step when the graph's order "
+                        "is local); off = the plain gather kernels")
     p.add_argument("--opt", action="append", default=[], help="engine option key=value")
     p.add_argument("--reorder", default="auto")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -113,7 +116,8 @@ def main():
     knn_diff = float(abs(Wd - W).max()) if Wd.nnz == W.nnz else float("inf")
     del Wd
     t0 = time.perf_counter()
-    G = graphs.Graph(W, coords=coords, compute_dtype=dtype, device=local, reorder=a.reorder)
+    G = graphs.Graph(W, coords=coords, compute_dtype=dtype, device=local, reorder=a.reorder,
+                     tiles="auto" if a.tiles == "auto" else False)
     t_graph = time.perf_counter() - t0
     dev = G.device_graph()
     G.estimate_lmax("bounds")
@@ -205,6 +209,8 @@ def main():
             assert len(blocks) == world
         del blocks
 
+    tiled = bool(G.tile_stats and G.tile_stats.get("enabled"))
+
     def newton_report(r, pair):
         ms_order = r[1] / (K * a.steps)
         out = {"note": ("same polynomial in Newton form, two orders per launch with the h panel staged in "
@@ -230,7 +236,7 @@ def main():
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic_{}.json".format(a.dtype))
     # the committed PMC measurement is of the default workload only
-    default_workload = (N, nsig, K, a.knn, a.evaluation) == (1000000, 64, 30, 8, "recurrence")
+    default_workload = (N, nsig, K, a.knn, a.evaluation, a.tiles) == (1000000, 64, 30, 8, "recurrence", "auto")
     if default_workload and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
@@ -262,13 +268,14 @@ def main():
                 "parallelism": "graph-parallel x{} (independent graphs, no data-path collective)".format(world),
                 "internal_order": "morton" if G._perm is not None else "none",
                 "evaluation": a.evaluation,
-                "engine_options": a.opt,
+                "engine_options": a.opt, "gather_tiles": G.tile_stats,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
                 "traffic": traffic,
-                "kernel": "k_step_panel (one recurrence order per launch)",
+                "kernel": ("k_step_tile (one recurrence order per launch, gathered panel staged in LDS)"
+                           if tiled else "k_step_panel / k_step_lds (one recurrence order per launch)"),
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "avg_launch_ms": avg_launch_ms, "launches_timed": launches,
             },

@@ -422,6 +422,24 @@ def _newton_methods():
         return {"nb": t["nb"], "max_n1": t["max_n1"], "mean_n1": t["mean_n1"],
                 "slow_blocks": int(stats[1]), "lds_bytes": int(stats[2])}
 
+    def auto_gather_tiles(self, min_vertices=32768):
+        """enable_gather_tiles() when it pays: a large graph whose internal order is local (nearly
+        every 64-row block's gather set fits its LDS tile).  Returns the statistics (with
+        "enabled") or None when the graph is too small to bother."""
+        if self.N < min_vertices:
+            return None
+        rp, col = self.download_internal()
+        rows = np.repeat(np.arange(self.N, dtype=np.int64), np.diff(rp.astype(np.int64) & ~3))
+        real = col[:rows.size] < self.N
+        near = np.abs(rows[real] - col[:rows.size][real]) <= 8192
+        if near.size and near.mean() < 0.5:  # no locality: the tiles would not fit, skip the build
+            return {"enabled": False, "near_fraction": float(near.mean())}
+        st = enable_gather_tiles(self)
+        st["enabled"] = st["slow_blocks"] * 50 <= st["nb"]
+        if not st["enabled"]:
+            disable_gather_tiles(self)
+        return st
+
     def disable_gather_tiles(self):
         _capi.check(_capi.load().gspx_graph_set_gather_tiles(self._h, 0, 0, None, None, None, None))
 
@@ -435,6 +453,7 @@ def _newton_methods():
     DeviceGraph.enable_pair_tiles = enable_pair_tiles
     DeviceGraph.enable_gather_tiles = enable_gather_tiles
     DeviceGraph.disable_gather_tiles = disable_gather_tiles
+    DeviceGraph.auto_gather_tiles = auto_gather_tiles
     DeviceGraph.disable_pair_tiles = disable_pair_tiles
 
 

@@ -30,7 +30,7 @@ _logger = logging.getLogger(__name__)
 
 class Graph:
     def __init__(self, adjacency, lap_type="combinatorial", coords=None, plotting={}, *,
-                 compute_dtype=np.float64, device=0, reorder="auto"):
+                 compute_dtype=np.float64, device=0, reorder="auto", tiles="auto"):
         self.logger = _logger
         if not sparse.issparse(adjacency):
             adjacency = np.asanyarray(adjacency)
@@ -64,6 +64,8 @@ class Graph:
         self.compute_dtype = np.dtype(compute_dtype)
         self.device = int(device)
         self.reorder = reorder
+        self.tiles = tiles  # "auto" | True | False: gather tiles of the LDS-staged recurrence step
+        self.tile_stats = None
         self._perm = None
         self._perm_done = False
 
@@ -125,6 +127,10 @@ class Graph:
             ctx = engine.default_context(self.device)
             g = engine.DeviceGraph.from_w(self._symmetric_w(), self.lap_type, dtype=dt,
                                           perm=self._internal_order(), ctx=ctx)
+            if self.tiles == "auto":  # LDS tiles for the recurrence step, when the order is local
+                self.tile_stats = g.auto_gather_tiles()
+            elif self.tiles:
+                self.tile_stats = g.enable_gather_tiles()
             self._dev[dt] = g
         return g
 

@@ -15,7 +15,7 @@ from scipy import sparse
 from . import engine, filters as _filters
 
 _saved = {}
-_config = {"laplacian": "device", "dtype": np.float64, "device": 0, "reorder": "auto"}
+_config = {"laplacian": "device", "dtype": np.float64, "device": 0, "reorder": "auto", "tiles": "auto"}
 
 
 def device_graph_for(G):
@@ -37,18 +37,22 @@ def device_graph_for(G):
         dev = engine.DeviceGraph.from_w(W, G.lap_type, dtype=_config["dtype"], perm=perm, ctx=ctx)
     else:  # bit-parity mode: upload the Laplacian the reference built
         dev = engine.DeviceGraph.from_l(G.L, dtype=_config["dtype"], perm=perm, ctx=ctx)
+    if _config.get("tiles", "auto"):
+        dev.auto_gather_tiles()
     G._gspx_dev = (key, dev)
     return dev
 
 
-def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, reorder="auto"):
+def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, reorder="auto",
+            tiles="auto"):
     """Patch the real pygsp in place.  `laplacian`: 'device' (L assembled by HIP kernels from
     G.W) or 'host' (upload the reference's G.L)."""
     if laplacian not in ("device", "host"):
         raise ValueError("laplacian must be 'device' or 'host'")
     if pygsp_module is None:
         import pygsp as pygsp_module
-    _config.update(laplacian=laplacian, dtype=np.dtype(dtype), device=int(device), reorder=reorder)
+    _config.update(laplacian=laplacian, dtype=np.dtype(dtype), device=int(device), reorder=reorder,
+                   tiles=tiles)
     approx = pygsp_module.filters.approximations
     if "cheby_op" not in _saved:
         _saved["cheby_op"] = approx.cheby_op
