@@ -1313,14 +1313,21 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   a.ldy = ldy;
   a.perm = perm;
   // LDS-staged gather: one filter with the fused flush
-  const bool tile_ok = nf == 1 && !deferred && tile_usable<T>(g, opt, ld, y, ldy);
+  // (or a filterbank's deferred combine, whose steps are plain recurrence steps into kept slots)
+  const bool tile_ok = (deferred || nf == 1) && tile_usable<T>(g, opt, ld, y, ldy);
   for (int k = 1; k <= K; ++k) {
     const PlanStep& ps = plan[(size_t)k - 1];
     if (tile_ok) {
       TileArgs<T> t{};
-      t.cur = slots + (size_t)((k - 1) & 1) * U;
-      t.old = ps.gamma == 0.0 ? t.cur : slots + (size_t)(k & 1) * U;
-      t.out = slots + (size_t)(k & 1) * U;
+      if (deferred) {
+        t.cur = slots + (size_t)(k - 1) * U;
+        t.old = (k >= 2 && ps.gamma != 0.0) ? slots + (size_t)(k - 2) * U : t.cur;
+        t.out = slots + (size_t)k * U;
+      } else {
+        t.cur = slots + (size_t)((k - 1) & 1) * U;
+        t.old = ps.gamma == 0.0 ? t.cur : slots + (size_t)(k & 1) * U;
+        t.out = slots + (size_t)(k & 1) * U;
+      }
       t.racc = racc;
       t.y = y;
       t.ldy = ldy;

@@ -808,7 +808,7 @@ def test_tile_gather_kernel(ctx, dtype):
                     nodes, d = filters.cheb_to_newton(c)
                     yn, _ = dev.newton_filter(nodes, d, x, lmax)
                     assert rel_err(yn, ref) < tol, (nsig, order, "newton on tiles")
-        # filterbanks and synthesis never take the tile path; they must be unaffected by the tiles
+        # filterbank (deferred combine): its recurrence steps run on the tile kernel too; synthesis does not
         cb = np.stack([orc.compute_cheby_coeff(k, lmax, 12) for k in orc.mexican_hat_kernels(lmax, 3)])
         x = rng.standard_normal((W.shape[0], 8))
         yb, _ = dev.cheby_filter(cb, x, lmax)
