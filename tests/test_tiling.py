@@ -73,3 +73,35 @@ def test_tiles_reproduce_two_steps(block_rows):
     ref = B[0] * F.dot(g) + B[1] * g + B[2] * x
     out = tiling.emulate_pair(t, rptr, rcol, fval, N, h, x, A, B)
     np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_gather_tiles_level1_reproduce_one_step():
+    """levels=1 (the LDS-staged recurrence step): a numpy model of k_step_tile's fast path - stage the
+    S1 rows, gather by 16-bit position - equals the sparse product; level-1 arrays equal the
+    two-level build's."""
+    W, coords = graphs.sensor_weights(900, k=7, seed=6)
+    L = orc.laplacian(W)
+    N = L.shape[0]
+    perm = engine.locality_order(W, coords)
+    rptr, rcol, rval = host_internal_csr(L, perm)
+    t1 = tiling.build_tiles(rptr, rcol, N, 64, levels=1)
+    t2 = tiling.build_tiles(rptr, rcol, N, 64)
+    for key in ("s1ptr", "s1rows", "lidx1"):
+        np.testing.assert_array_equal(t1[key], t2[key])
+    assert t1["max_n1"] == t2["max_n1"] and "s2rows" not in t1
+    x = np.random.default_rng(0).standard_normal((N, 3))
+    xi = x[perm]
+    out = np.zeros_like(xi)
+    lidx = t1["lidx1"].astype(np.int64)
+    lidx[lidx == tiling.PAD] = 0  # what DeviceGraph.enable_gather_tiles uploads
+    for b in range(t1["nb"]):
+        s1 = t1["s1rows"][t1["s1ptr"][b]:t1["s1ptr"][b + 1]]
+        assert (np.diff(s1) > 0).all() and s1.size <= 65535
+        tile = xi[s1]
+        for i in range(b * 64, min((b + 1) * 64, N)):
+            s, e = rptr[i], rptr[i + 1]
+            out[i] = (rval[s:e, None] * tile[lidx[s:e]]).sum(axis=0)
+            assert s1[lidx[s]] == i  # entry 0 is the diagonal slot: the row itself
+    ref = np.empty_like(out)
+    ref[:] = L.dot(x)[perm]
+    assert np.max(np.abs(out - ref)) < 1e-12
