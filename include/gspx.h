@@ -73,6 +73,13 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "waves_per_block" 4 (default), 8 or 16 waves per workgroup (kernel 1)
  *   "ws_limit_mb" / "max_batch"  workspace budget / cap on signals per batch
  *   "combine"     0 auto, 1 fused flush every 3rd step, 2 deferred combine (keep all T_k)
+ *   "graph_launch" 2 (default) an analysis call that repeats the previous one exactly (same graph,
+ *                 lmax, coefficients, pointers, options) is recorded once as a hipGraph and replayed
+ *                 when its panel is at most 32 MB (launch-bound); 1 always; 0 never.  A replayed call
+ *                 reports one total time (gspx_last_timing out[0] == out[1])
+ *   "tile_gather" 1 (default) recurrence steps stage the gathered panel in LDS when the graph
+ *                 carries gather tiles (gspx_graph_set_gather_tiles); 0 plain gather kernels
+ *   "tile_workgroups" persistent workgroups of that kernel (0 = two per CU)
  *   "newton_pair" 1 (default) Newton-form filtering runs two orders per launch when the graph
  *                 carries tiles (gspx_graph_set_tiles); 0 one order per launch
  *   "pair_workgroups" persistent workgroups of the fused pair kernel (0 = two per CU)

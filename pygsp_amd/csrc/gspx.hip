@@ -102,6 +102,7 @@ struct Options {
   int64_t interleave = 0;       // panel kernel: waves of a workgroup advance as one front
   int64_t newton_pair = 1;      // use the fused two-step kernel when the graph carries tiles
   int64_t pair_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
+  int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
@@ -125,7 +126,24 @@ struct gspx_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev_pool;
   double timing[5] = {0, 0, 0, 0, 0};
+  // hipGraph replay of a repeated identical filter call (launch-bound small graphs)
+  bool capturing = false;     // run_batch is being recorded: no copies, syncs or events inside
+  uint64_t seen_key = 0;      // key of the last eager call
+  uint64_t graph_key = 0;     // key the instantiated graph was captured for
+  hipGraphExec_t graph_exec = nullptr;
 };
+
+// any other work on the context invalidates a recorded replay (it may have rewritten the weights,
+// the cached gather offsets or the workspace the graph refers to)
+static void replay_reset(gspx_ctx* ctx) {
+  if (!ctx) return;
+  ctx->seen_key = 0;
+  ctx->graph_key = 0;
+  if (ctx->graph_exec) {
+    (void)hipGraphExecDestroy(ctx->graph_exec);
+    ctx->graph_exec = nullptr;
+  }
+}
 
 struct gspx_buf {
   gspx_ctx* ctx = nullptr;
@@ -219,7 +237,12 @@ extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
 }
 
 extern "C" int gspx_ctx_destroy(gspx_ctx* ctx) {
+  replay_reset(ctx);
   if (!ctx) return GSPX_OK;
+  if (ctx->graph_exec) {
+    (void)hipGraphExecDestroy(ctx->graph_exec);
+    ctx->graph_exec = nullptr;
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 4; ++i)
@@ -255,6 +278,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "newton_pair")) return &o.newton_pair;
   if (!strcmp(key, "pair_workgroups")) return &o.pair_workgroups;
   if (!strcmp(key, "tile_gather")) return &o.tile_gather;
+  if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
@@ -264,6 +288,7 @@ static int64_t* option_slot(Options& o, const char* key) {
 }
 
 extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value) {
+  replay_reset(ctx);
   if (!ctx) return set_err(GSPX_ERR_INVALID, "null ctx");
   int64_t* s = option_slot(ctx->opt, key);
   if (!s) return set_err(GSPX_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
@@ -609,6 +634,7 @@ extern "C" int gspx_graph_create_from_l(gspx_ctx* ctx, int64_t N, int64_t nnz,
 }
 
 extern "C" int gspx_graph_destroy(gspx_graph* g) {
+  if (g) replay_reset(g->ctx);
   if (!g) return GSPX_OK;
   (void)hipSetDevice(g->ctx->device);
   (void)hipStreamSynchronize(g->ctx->stream);
@@ -675,6 +701,7 @@ extern "C" int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const
                                     const int32_t* s2rows, const uint16_t* lidx1,
                                     const uint32_t* occ_off, int64_t n_lidx2, const uint16_t* lidx2,
                                     int max_n1, int max_n2) {
+  if (g) replay_reset(g->ctx);
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
   if (block_rows == 0) {  // drop the tiles
     g->tile_rows = 0;
@@ -796,6 +823,7 @@ extern "C" int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]) {
 
 extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
                                            const int32_t* s1rows, const uint16_t* lidx, int64_t* stats) {
+  if (g) replay_reset(g->ctx);
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
   if (block_rows == 0) {  // drop the tiles
     g->gt_rows = 0;
@@ -1267,9 +1295,12 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
     for (int k = 0; k < K; ++k)
       for (int j = 0; j < nf * 3; ++j) hw[(size_t)k * nf * 3 + j] = (T)plan[(size_t)k].w[(size_t)j];
   }
-  CHK(ctx->ws_w.ensure(hw.size() * sizeof(T) + 64));
-  HIPCHK(hipMemcpyAsync(ctx->ws_w.p, hw.data(), hw.size() * sizeof(T), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // hw is a stack-owned staging buffer
+  const bool cap = ctx->capturing;  // replay recording: the previous eager call left the same weights
+  if (!cap) {                       // and workspace in place
+    CHK(ctx->ws_w.ensure(hw.size() * sizeof(T) + 64));
+    HIPCHK(hipMemcpyAsync(ctx->ws_w.p, hw.data(), hw.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // hw is a stack-owned staging buffer
+  }
 
   const size_t nslots = deferred ? (size_t)M : 2;
   CHK(ctx->ws_t.ensure(nslots * U * sizeof(T) + 256));
@@ -1277,16 +1308,20 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   T* slots = ctx->ws_t.as<T>();
   T* racc = ctx->ws_r.as<T>();
 
-  hipEvent_t e0 = pool_event(ctx, ++ev_idx), e1 = pool_event(ctx, ++ev_idx),
-             e2 = pool_event(ctx, ++ev_idx), e3 = pool_event(ctx, ++ev_idx);
-  if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
-
-  HIPCHK(hipEventRecord(e0, st));
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+  if (!cap) {
+    e0 = pool_event(ctx, ++ev_idx);
+    e1 = pool_event(ctx, ++ev_idx);
+    e2 = pool_event(ctx, ++ev_idx);
+    e3 = pool_event(ctx, ++ev_idx);
+    if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
+    HIPCHK(hipEventRecord(e0, st));
+  }
   // permute-in vector width: x rows must be aligned too
   int pvec = shape.vec;
   while (pvec > 1 && ((ldx % pvec) != 0 || (((uintptr_t)x / sizeof(T)) % pvec) != 0)) pvec /= 2;
   launch_permute_in<T>(x, ldx, slots, ld, N, perm, pvec, st);
-  HIPCHK(hipEventRecord(e1, st));
+  if (!cap) HIPCHK(hipEventRecord(e1, st));
 
   const int pad_self = (shape.kernel == 3 || shape.kernel == 4) ? 1 : 0;
   if (shape.kernel >= 3 &&
@@ -1363,15 +1398,17 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
     a.wts = ctx->ws_w.as<T>() + (size_t)(k - 1) * nf * 3;
     launch_step<T>(a, shape, opt, st, g->coff.as<unsigned>());
   }
-  HIPCHK(hipEventRecord(e2, st));
+  if (!cap) HIPCHK(hipEventRecord(e2, st));
   if (deferred) {
     int cvec = shape.vec;
     while (cvec > 1 && ((ldy % cvec) != 0 || (((uintptr_t)y / sizeof(T)) % cvec) != 0)) cvec /= 2;
     launch_combine<T>(slots, M, U, ctx->ws_w.as<T>(), M, nf, N, ld, y, ldy, (size_t)N * ldy, perm,
                       cvec, st);
   }
-  HIPCHK(hipEventRecord(e3, st));
-  HIPCHK(hipGetLastError());
+  if (!cap) {
+    HIPCHK(hipEventRecord(e3, st));
+    HIPCHK(hipGetLastError());
+  }
   return GSPX_OK;
 }
 
@@ -1411,6 +1448,73 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
   max_ld = std::min<int64_t>(max_ld, std::max<int64_t>(1, (int64_t)(budget / ws_per_col(deferred))));
   if (opt.max_batch > 0) max_ld = std::min<int64_t>(max_ld, opt.max_batch);
   if (max_ld < Nsig && max_ld >= 4) max_ld &= ~(int64_t)3;  // keep batch starts 16-byte friendly
+
+  // ---- hipGraph replay: an analysis call that repeats the previous one exactly (same graph, lmax,
+  // coefficients, pointers, options) is recorded once and replayed as one graph launch - K + 1
+  // kernel launches cost ~5 us each, which is the whole call on cache-resident graphs
+  uint64_t key = 0;
+  const bool graph_mode =
+      analysis && Nsig <= max_ld &&
+      (opt.graph_launch == 1 || (opt.graph_launch == 2 && (size_t)N * Nsig * sizeof(T) <= ((size_t)32 << 20)));
+  if (graph_mode) {
+    auto mix = [&](const void* p, size_t n) {
+      const unsigned char* b = (const unsigned char*)p;
+      for (size_t i = 0; i < n; ++i) key = (key ^ b[i]) * 1099511628211ull;
+    };
+    key = 1469598103934665603ull;
+    const void* ptrs[] = {g, x, y, ctx->ws_t.p, ctx->ws_r.p, ctx->ws_w.p, g->coff.p, g->gt_hdr.p, g->fval.p};
+    mix(ptrs, sizeof(ptrs));
+    mix(&lmax, sizeof(lmax));
+    mix(&Nf, sizeof(Nf));
+    mix(&M, sizeof(M));
+    mix(&Nsig, sizeof(Nsig));
+    mix(cp.data(), cp.size() * sizeof(double));
+    mix(&opt, sizeof(opt));
+    mix(&g->gt_rows, sizeof(g->gt_rows));
+    if (key == 0) key = 1;
+    if (ctx->graph_exec && ctx->graph_key == key) {
+      HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+      HIPCHK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+      HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      float gms = 0;
+      HIPCHK(hipEventElapsedTime(&gms, ctx->ev[0], ctx->ev[1]));
+      ctx->timing[0] = gms;
+      ctx->timing[1] = gms;  // one graph: no per-phase split
+      ctx->timing[2] = (double)K;
+      return GSPX_OK;
+    }
+    if (ctx->seen_key == key) {  // second identical call: record it
+      if (ctx->graph_exec) {
+        (void)hipGraphExecDestroy(ctx->graph_exec);
+        ctx->graph_exec = nullptr;
+      }
+      hipGraph_t graph = nullptr;
+      size_t dummy = 0;
+      HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      ctx->capturing = true;
+      const int rc = run_batch<T>(g, Nf, M, cp, x, (unsigned)Nsig, y, (unsigned)Nsig, (unsigned)Nsig,
+                                  deferred, false, true, dummy);
+      ctx->capturing = false;
+      const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+      if (rc != GSPX_OK || ce != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        ctx->seen_key = 0;  // fall through to the eager path below
+      } else {
+        const hipError_t ie = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie == hipSuccess) {
+          ctx->graph_key = key;
+          return filter_dev_t<T>(g, lmax, Nf, M, coeffs, Nsig, x, y, mode);  // replays
+        }
+        ctx->graph_exec = nullptr;
+        (void)hipGetLastError();
+      }
+    }
+  }
+  if (ctx->graph_exec && ctx->graph_key != key) replay_reset(ctx);
+  ctx->seen_key = key;  // 0 when graph mode is off
 
   size_t ev_idx = 0;
   HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -1796,6 +1900,7 @@ static int newton_dev_t(gspx_graph* g, double lmax, int K, const double* nodes, 
 extern "C" int gspx_newton_filter_dev(gspx_graph* g, double lmax, int K, const double* nodes,
                                       const double* dcoef, int64_t Nsig, const void* x_dev,
                                       void* y_dev, double* kernel_ms) {
+  if (g) replay_reset(g->ctx);
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
   if (K < 1) return set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape");
   if (!nodes || !dcoef) return set_err(GSPX_ERR_INVALID, "null nodes / coefficients");
@@ -2023,6 +2128,7 @@ static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* 
 
 extern "C" int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax,
                                  int* iterations) {
+  if (g) replay_reset(g->ctx);
   if (!g || !lmax) return set_err(GSPX_ERR_INVALID, "null argument");
   if (max_iter < 1 || !(tol > 0)) return set_err(GSPX_ERR_INVALID, "max_iter >= 1 and tol > 0");
   HIPCHK(hipSetDevice(g->ctx->device));

@@ -111,6 +111,7 @@ static int lap_apply_t(gspx_graph* g, int64_t Nsig, const T* x, T* y, double* ms
 
 extern "C" int gspx_laplacian_apply_dev(gspx_graph* g, int64_t Nsig, const void* x_dev, void* y_dev,
                                         double* kernel_ms) {
+  if (g) replay_reset(g->ctx);
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
   if (Nsig < 0) return set_err(GSPX_ERR_INVALID, "negative number of signals");
   if (Nsig > 0 && g->N > 0 && (!x_dev || !y_dev)) return set_err(GSPX_ERR_INVALID, "null signal pointer");
@@ -170,6 +171,7 @@ static int dirichlet_t(gspx_graph* g, int64_t Nsig, const T* x, double* gram, do
 
 extern "C" int gspx_dirichlet_energy_dev(gspx_graph* g, int64_t Nsig, const void* x_dev,
                                          double* gram_host, double* kernel_ms) {
+  if (g) replay_reset(g->ctx);
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
   if (Nsig < 0 || Nsig > 4096) return set_err(GSPX_ERR_INVALID, "dirichlet_energy: 0 <= Nsig <= 4096");
   if (Nsig > 0 && (!gram_host || (g->N > 0 && !x_dev))) return set_err(GSPX_ERR_INVALID, "null pointer");
@@ -275,6 +277,7 @@ static int tikhonov_t(gspx_graph* g, double tau, const T* mask, int64_t Nsig, co
 extern "C" int gspx_tikhonov_cg_dev(gspx_graph* g, double tau, const void* mask_dev, int64_t Nsig,
                                     const void* y_dev, void* x_dev, double rtol, double atol,
                                     int64_t maxiter, int32_t* iterations, double* kernel_ms) {
+  if (g) replay_reset(g->ctx);
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
   if (!(tau > 0) || !std::isfinite(tau)) return set_err(GSPX_ERR_INVALID, "tau must be positive and finite");
   if (Nsig < 0 || maxiter < 0 || !(rtol >= 0) || !(atol >= 0))

@@ -829,3 +829,56 @@ def test_tile_gather_kernel(ctx, dtype):
         y, _ = dev.cheby_filter(c, x, lm)
         assert rel_err(y[0], orc.cheby_op(Lr, lm, c, x.astype(dtype).astype(np.float64))) < tol
         dev.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# hipGraph replay of a repeated identical call (option "graph_launch")
+# ---------------------------------------------------------------------------------------------
+def test_graph_replay(ctx):
+    rng = np.random.default_rng(77)
+    W, coords = graphs.sensor_weights(30000, k=6, seed=12)
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    dev = engine.DeviceGraph.from_w(W, perm=engine.locality_order(W, coords), ctx=ctx)
+    c1 = orc.compute_cheby_coeff(orc.heat_kernel(10, lmax), lmax, 20)
+    c2 = orc.compute_cheby_coeff(orc.heat_kernel(3, lmax), lmax, 20)
+    cb = np.stack([orc.compute_cheby_coeff(k, lmax, 15) for k in orc.mexican_hat_kernels(lmax, 3)])
+    for nsig in (1, 8):
+        x = rng.standard_normal((30000, nsig))
+        bx, by = ctx.upload(x), ctx.alloc(3 * x.nbytes)
+        ref1, ref2 = orc.cheby_op(L, lmax, c1, x), orc.cheby_op(L, lmax, c2, x)
+        refb = orc.cheby_op(L, lmax, cb, x).reshape(3, -1, nsig)
+        ctx.set_option("graph_launch", 1)
+        for rep in range(5):   # eager, eager (pointers settled), record + replay, replay, replay
+            dev.cheby_filter_dev(c1, bx.ptr, by.ptr, nsig, lmax)
+            assert rel_err(by.download((30000, nsig), np.float64), ref1.reshape(30000, nsig)) < 1e-11, rep
+        t = ctx.last_timing()
+        assert t["total_ms"] == t["steps_ms"] > 0  # a replayed call reports one time
+        # other coefficients: the recorded graph must not be reused
+        dev.cheby_filter_dev(c2, bx.ptr, by.ptr, nsig, lmax)
+        assert rel_err(by.download((30000, nsig), np.float64), ref2.reshape(30000, nsig)) < 1e-11
+        # new input in the same buffer: a replay reads the buffer, not a snapshot
+        for rep in range(4):
+            x2 = rng.standard_normal((30000, nsig))
+            bx.upload(x2)
+            dev.cheby_filter_dev(c2, bx.ptr, by.ptr, nsig, lmax)
+            assert rel_err(by.download((30000, nsig), np.float64),
+                           orc.cheby_op(L, lmax, c2, x2).reshape(30000, nsig)) < 1e-11, rep
+        bx.upload(x)
+        # interleaved with calls that rewrite the workspace / weights
+        for rep in range(4):
+            dev.cheby_filter_dev(c1, bx.ptr, by.ptr, nsig, lmax)
+            assert rel_err(by.download((30000, nsig), np.float64), ref1.reshape(30000, nsig)) < 1e-11
+            if rep % 2:
+                dev.laplacian_apply(x)
+            else:
+                nodes, d = filters.cheb_to_newton(c2)
+                dev.newton_filter(nodes, d, x, lmax)
+        # filterbank (deferred combine) replays too
+        for rep in range(4):
+            dev.cheby_filter_dev(cb, bx.ptr, by.ptr, nsig, lmax)
+            assert rel_err(by.download((3, 30000, nsig), np.float64), refb) < 1e-11, rep
+        ctx.set_option("graph_launch", 2)
+        bx.free()
+        by.free()
+    dev.destroy()
