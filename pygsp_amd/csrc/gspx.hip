@@ -1637,7 +1637,30 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
   a.ldy = ldy;
   a.perm = perm;
   a.beta = T(0);
+  // (nf input panels: the buffer window of the tile kernel spans all of them)
+  const bool tile_ok = tile_usable<T>(g, opt, ld, y, ldy) && (size_t)nf * U * sizeof(T) < ((size_t)1 << 31);
   for (int k = K; k >= 0; --k) {
+    if (tile_ok) {
+      TileArgs<T> t{};
+      const bool has_b2 = (k + 2 <= K);
+      t.cur = (k == K) ? S : B[(k + 1) & 1];
+      t.old = (k < K && has_b2) ? B[k & 1] : t.cur;
+      t.out = B[k & 1];
+      t.racc = B[0];  // unused (flush == 0)
+      t.y = y;
+      t.ldy = ldy;
+      t.perm = perm;
+      t.scale = (k == K) ? T(0) : (k == 0 ? T(0.5) : T(1));
+      t.gamma = (k < K && has_b2) ? T(-1) : T(0);
+      t.beta = T(0);
+      t.inp = S;
+      t.wts = ctx->ws_w.as<T>() + (size_t)k * nf;
+      t.nin = nf;
+      t.flush = 0;
+      t.final = (k == 0) ? 1 : 0;
+      CHK(launch_step_tile<T>(g, opt, t, ld, st));
+      continue;
+    }
     a.wts = ctx->ws_w.as<T>() + (size_t)k * nf;
     a.final = (k == 0) ? 1 : 0;
     a.flush = 0;

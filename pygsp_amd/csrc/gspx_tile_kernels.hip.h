@@ -45,6 +45,10 @@ template <typename T> struct TileArgs {
   T scale, gamma;
   T beta;        // coefficient of T_{k-1}'s own row (Newton-form steps; 0 for the recurrence)
   T wn, wc, wo;  // flush weights of the single filter
+  // extra input panels summed into the row: out += sum_f wts[f] * inp[f][row] (synthesis by Clenshaw)
+  const T* inp;  // [nin][N][ld]
+  const T* wts;  // device, [nin]
+  int nin;
   int flush;     // 0 none, 1 write, 2 accumulate
   int final;     // 1: the flush result goes to y (caller's order)
 };
@@ -138,6 +142,20 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
       ov[t] = VT<T, VEC>::bload(rold, a.gamma != T(0) ? off : POISON);
       ra[t] = VT<T, VEC>::bload(rra, a.flush == 2 ? off : POISON);
     }
+    V ins[2];
+    ins[0] = 0;
+    ins[1] = 0;
+    if (a.nin > 0) {
+      const rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.inp, 0, a.panel_bytes * (u32)a.nin, 0x00020000);
+      for (int f = 0; f < a.nin; ++f) {
+        const T w = a.wts[f];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
+          ins[t] += w * VT<T, VEC>::bload(rin, off == POISON ? POISON : off + (u32)f * a.panel_bytes);
+        }
+      }
+    }
     // the block's slice of matrix entries, coalesced (values: 16-byte pieces, positions likewise)
     u32x4 ev = 0, ei = 0;
     const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent * 2 + 15) >> 4;
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
         V self;
         const V acc = lds_row_dot<T, V>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
                                         lane16, self);
-        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self;
+        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
         cv[t] = self;
       }
     } else {
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
             acc += a.val[j] * xv;
           }
         }
-        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self;
+        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
         cv[t] = self;
       }
     }

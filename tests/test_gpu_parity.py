@@ -814,6 +814,11 @@ def test_tile_gather_kernel(ctx, dtype):
         yb, _ = dev.cheby_filter(cb, x, lmax)
         refb = orc.cheby_op(L, lmax, cb, x.astype(dtype).astype(np.float64)).reshape(3, -1, 8)
         assert rel_err(yb, refb) < tol
+        # synthesis (vector-coefficient Clenshaw): the extra input panels are summed in the tile kernel
+        s3 = rng.standard_normal((3, W.shape[0], 8))
+        refs = sum(orc.cheby_op(L, lmax, cb[f], s3[f].astype(dtype).astype(np.float64)) for f in range(3))
+        ys, _ = dev.cheby_filter(cb, s3, lmax, mode=_capi.SYNTHESIS)
+        assert rel_err(ys, refs) < tol
         dev.disable_gather_tiles()
         dev.destroy()
     # a graph with isolated vertices, a hub and ragged rows; normalized Laplacian
