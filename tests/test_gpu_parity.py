@@ -848,7 +848,9 @@ def test_graph_replay(ctx):
     c1 = orc.compute_cheby_coeff(orc.heat_kernel(10, lmax), lmax, 20)
     c2 = orc.compute_cheby_coeff(orc.heat_kernel(3, lmax), lmax, 20)
     cb = np.stack([orc.compute_cheby_coeff(k, lmax, 15) for k in orc.mexican_hat_kernels(lmax, 3)])
-    for nsig in (1, 8):
+    for nsig in (1, 8, 16):
+        if nsig == 16:  # the recorded launches are those of the LDS-staged step kernel
+            assert dev.enable_gather_tiles()["slow_blocks"] == 0
         x = rng.standard_normal((30000, nsig))
         bx, by = ctx.upload(x), ctx.alloc(3 * x.nbytes)
         ref1, ref2 = orc.cheby_op(L, lmax, c1, x), orc.cheby_op(L, lmax, c2, x)
