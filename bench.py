@@ -266,7 +266,8 @@ def main():
                 "N": N, "Nsig": nsig, "order": K, "Nf": 1, "nnz_W": int(W.nnz), "nnz_L": int(nnz_l),
                 "n_edges": int(G.n_edges), "lmax": lmax, "lmax_method": "bounds",
                 "parallelism": "graph-parallel x{} (independent graphs, no data-path collective)".format(world),
-                "internal_order": "morton" if G._perm is not None else "none",
+                "internal_order": ("hilbert (2-D coordinates)" if coords.shape[1] == 2 else "morton")
+                                  if G._perm is not None else "none",
                 "evaluation": a.evaluation,
                 "engine_options": a.opt, "gather_tiles": G.tile_stats,
             },

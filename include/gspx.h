@@ -233,6 +233,11 @@ int gspx_knn_download_w(gspx_knn* h, int32_t* indptr, int32_t* indices, double* 
 /* NN[:, 1:] and D[:, 1:] of the reference: N x k, nearest first (either may be NULL) */
 int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist);
 
+/* Space-filling-curve keys of N points (coords: N x d doubles on the HOST, d >= 2; the first two /
+ * three axes are used): curve 0 = Morton, 1 = Hilbert (2-D).  The engine's internal vertex order
+ * for graphs with coordinates is the stable argsort of these keys (pygsp_amd.engine.locality_order). */
+int gspx_curve_keys(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve, uint64_t* keys);
+
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
  *   out[0] total device time, out[1] time inside the recurrence-step launches only,
  *   out[2] number of step launches, out[3] permute-in/copy time, out[4] combine time */

@@ -250,7 +250,86 @@ __global__ void k_knn_row_sort(const int* __restrict__ rowptr, int N, int* __res
   }
 }
 
+// space-filling-curve key of every point (internal vertex order = argsort of the keys):
+// curve 0 = Morton (bit interleave, 31 bits per axis in 2-D, 21 in 3-D), 1 = Hilbert (2-D, 16 bits
+// per axis; the classic xy -> d walk)
+__global__ void k_curve_keys(const double* __restrict__ x, int N, int d, double lo0, double lo1, double lo2,
+                             double inv0, double inv1, double inv2, int curve,
+                             unsigned long long* __restrict__ key) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double lo[3] = {lo0, lo1, lo2}, inv[3] = {inv0, inv1, inv2};
+  if (curve == 1) {
+    const unsigned long long top = (1ull << 16) - 1;
+    long long q[2];
+    for (int j = 0; j < 2; ++j) {
+      long long v = (long long)((x[(size_t)i * d + j] - lo[j]) * inv[j] * 65536.0);
+      q[j] = v < 0 ? 0 : (v > (long long)top ? (long long)top : v);
+    }
+    long long px = q[0], py = q[1];
+    unsigned long long dd = 0;
+    for (long long s = 1ll << 15; s > 0; s >>= 1) {
+      const long long rx = (px & s) ? 1 : 0, ry = (py & s) ? 1 : 0;
+      dd += (unsigned long long)(s * s) * (unsigned long long)((3 * rx) ^ ry);
+      if (ry == 0) {
+        if (rx == 1) {
+          px = s - 1 - px;
+          py = s - 1 - py;
+        }
+        const long long t = px;
+        px = py;
+        py = t;
+      }
+    }
+    key[i] = dd;
+    return;
+  }
+  const int dm = d >= 3 ? 3 : 2;
+  const int bits = dm == 3 ? 21 : 31;
+  const double scale = (double)((1ull << bits) - 1);
+  unsigned long long code = 0;
+  unsigned long long q[3] = {0, 0, 0};
+  for (int j = 0; j < dm; ++j) {
+    double v = (x[(size_t)i * d + j] - lo[j]) * inv[j] * scale;
+    v = v < 0 ? 0 : (v > scale ? scale : v);
+    q[j] = (unsigned long long)v;
+  }
+  for (int b = 0; b < bits; ++b)
+    for (int j = 0; j < dm; ++j) code |= ((q[j] >> b) & 1ull) << (b * dm + j);
+  key[i] = code;
+}
+
 }  // namespace gspx
+
+extern "C" int gspx_curve_keys(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve,
+                               uint64_t* keys) {
+  if (!ctx || !coords || !keys) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (N < 1 || N >= ((int64_t)1 << 31) || d < 2) return set_err(GSPX_ERR_INVALID, "gspx_curve_keys: bad N or d");
+  if (curve != 0 && curve != 1) return set_err(GSPX_ERR_INVALID, "curve: 0 Morton, 1 Hilbert");
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, inv[3] = {1, 1, 1};
+  const int dm = std::min(d, 3);
+  for (int j = 0; j < dm; ++j) lo[j] = hi[j] = coords[j];
+  for (int64_t i = 0; i < N; ++i)
+    for (int j = 0; j < dm; ++j) {
+      const double v = coords[i * d + j];
+      if (!std::isfinite(v)) return set_err(GSPX_ERR_INVALID, "non-finite coordinate");
+      lo[j] = std::min(lo[j], v);
+      hi[j] = std::max(hi[j], v);
+    }
+  for (int j = 0; j < dm; ++j) inv[j] = hi[j] > lo[j] ? 1.0 / (hi[j] - lo[j]) : 1.0;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevMem x, k;
+  CHK(x.alloc((size_t)N * d * sizeof(double)));
+  CHK(k.alloc((size_t)N * sizeof(uint64_t)));
+  HIPCHK(hipMemcpyAsync(x.p, coords, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_curve_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, x.as<double>(),
+                     (int)N, d, lo[0], lo[1], lo[2], inv[0], inv[1], inv[2], curve,
+                     (unsigned long long*)k.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(keys, k.p, (size_t)N * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GSPX_OK;
+}
 
 struct gspx_knn {
   gspx_ctx* ctx = nullptr;
