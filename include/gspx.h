@@ -253,8 +253,9 @@ int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, doubl
 
 /* Largest eigenvalue of L by Lanczos on the device (replaces the ARPACK call of
  * pygsp/graphs/graph.py:911-917).  Deterministic (fixed start vector).  Returns the largest Ritz
- * value (<= lambda_max); stops when it changes by less than `tol` (relative; the reference uses
- * 5e-3) or after `max_iter` steps.  The caller applies the reference's 1 % margin (graph.py:920). */
+ * value (<= lambda_max); stops when the residual of the Ritz pair is below `tol` * value (an
+ * eigenvalue of L lies within that distance; the reference asks ARPACK for 5e-3) or after
+ * `max_iter` steps.  The caller applies the reference's 1 % margin (graph.py:920). */
 int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int* iterations);
 
 /* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two

@@ -2036,8 +2036,9 @@ extern "C" int gspx_last_timing(gspx_ctx* ctx, double out[5]) {
 // lambda_max by Lanczos ON DEVICE (replaces the ARPACK call of
 // graph.py:911-917, 3.3 s on the host at N = 1M).  Plain three-term Lanczos on L with a fixed
 // start vector (deterministic, unlike ARPACK's random start); the largest Ritz value of the
-// tridiagonal matrix is found by bisection on the host.  Stops when it moves by less than `tol`
-// (relative) or after max_iter steps.  Returns the Ritz value itself (<= lambda_max); the caller
+// tridiagonal matrix is found by bisection on the host.  Stops when the residual of the Ritz pair,
+// beta_j |s_j|, is below `tol` * theta (an eigenvalue of L lies within that distance) or after
+// max_iter steps.  Returns the Ritz value itself (<= lambda_max); the caller
 // applies the reference's 1 % safety factor (graph.py:920).
 // ------------------------------------------------------------------------------------------------
 static double tridiag_max_eig(const std::vector<double>& al, const std::vector<double>& be) {
@@ -2112,7 +2113,7 @@ static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* 
   a.gamma = T(0);
   a.beta = T(1);
   std::vector<double> al, be;
-  double theta_prev = 0, theta = 0, beta_prev = 0;
+  double theta = 0, beta_prev = 0;
   int cur = 0, prev = 2;
   for (int j = 0; j < max_iter && j < N; ++j) {
     const int nxt = 3 - cur - prev;  // the third buffer
@@ -2133,9 +2134,31 @@ static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* 
     theta = tridiag_max_eig(al, be);
     if (iters) *iters = j + 1;
     const double beta = std::sqrt(std::max(b2, 0.0));
-    if (j >= 4 && std::fabs(theta - theta_prev) <= tol * std::fabs(theta)) break;
     if (!(beta > 1e-300 * std::max(1.0, std::fabs(theta)))) break;  // invariant subspace
-    theta_prev = theta;
+    // residual of the Ritz pair: ||L y - theta y|| = beta_j |s_j|, s = unit eigenvector of the
+    // tridiagonal matrix for theta; its components come from the backward recurrence (the stable
+    // direction for the extreme eigenvalue).  There is an eigenvalue of L within that distance of
+    // theta - a bound, unlike "theta stopped moving", which stalls on plateaus.
+    {
+      const int m = (int)al.size();
+      double w_next = 0.0, w_cur = 1.0, w_last = 1.0, nrm2w = 1.0;  // w_m = 1
+      for (int i = m - 1; i >= 1; --i) {
+        // row i (0-based) of (T - theta) w = 0:  be[i-1] w_{i-1} + (al[i] - theta) w_i + be[i] w_{i+1} = 0
+        const double up = (i < m - 1) ? be[(size_t)i] * w_next : 0.0;
+        const double w_prev = ((theta - al[(size_t)i]) * w_cur - up) / be[(size_t)i - 1];
+        w_next = w_cur;
+        w_cur = w_prev;
+        nrm2w += w_cur * w_cur;
+        if (nrm2w > 1e200) {  // rescale everything, the last component included
+          w_next *= 1e-100;
+          w_cur *= 1e-100;
+          w_last *= 1e-100;
+          nrm2w *= 1e-200;
+        }
+      }
+      const double s_last = w_last / std::sqrt(nrm2w);
+      if (j >= 2 && beta * std::fabs(s_last) <= tol * std::fabs(theta)) break;
+    }
     be.push_back(beta);
     hipLaunchKernelGGL((k_axpby<T>), dim3(nb), dim3(256), 0, st, T(0), v[nxt], (T)(1.0 / beta),
                        v[nxt], (size_t)N);
