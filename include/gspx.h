@@ -181,6 +181,11 @@ int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
 int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
                                 const int32_t* s1rows, const uint16_t* lidx, int64_t* stats);
 
+/* The same tiles computed on the device from the internal CSR (per-block sort / unique in LDS).
+ * stats (nullable, 4 values): blocks, blocks on the plain-gather path, LDS bytes per workgroup,
+ * total rows in the gather lists. */
+int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats);
+
 /* ---- operators on the same device CSR --------------------------------
  * Panels are DEVICE pointers (gspx_buf_ptr or any other device allocation), row-major N x Nsig,
  * compute dtype of the graph, caller's vertex order.

@@ -878,6 +878,56 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
   return GSPX_OK;
 }
 
+// the same tiles, computed on the device from the internal CSR (no host arrays)
+extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  replay_reset(g->ctx);
+  gspx_ctx* ctx = g->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int N = (int)g->N;
+  if (N < 1) return set_err(GSPX_ERR_INVALID, "empty graph");
+  const int nb = (N + GSPX_TILE_BR - 1) / GSPX_TILE_BR;
+  const size_t lds = (size_t)52 * 1024;
+  DevMem tmp, n1, keep, s1lo, nslow;
+  CHK(tmp.alloc((size_t)nb * GSPX_TILE_TMPCAP * sizeof(int)));
+  CHK(n1.alloc(((size_t)nb + 1) * sizeof(int)));
+  CHK(keep.alloc(((size_t)nb + 1) * sizeof(int)));
+  CHK(s1lo.alloc(((size_t)nb + 1) * sizeof(int)));
+  CHK(nslow.alloc(sizeof(int)));
+  HIPCHK(hipMemsetAsync(nslow.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_tiles_unique, dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
+                     tmp.as<int>(), n1.as<int>());
+  hipLaunchKernelGGL(k_tiles_keep, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, n1.as<int>(), nb,
+                     keep.as<int>());
+  CHK(scan_exclusive(ctx, keep.as<int>(), s1lo.as<int>(), nb + 1));
+  int n_s1 = 0;
+  HIPCHK(hipMemcpyAsync(&n_s1, s1lo.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  CHK(g->gt_hdr.alloc((size_t)nb * 4 * sizeof(int) + 64));
+  CHK(g->gt_s1rows.alloc((size_t)std::max(n_s1, 1) * 4 + 64));
+  CHK(g->gt_lidx.alloc((size_t)g->nnz_int * 2 + 128));
+  hipLaunchKernelGGL(k_tiles_fill, dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
+                     tmp.as<int>(), n1.as<int>(), s1lo.as<int>(), (int)elt_size(g->dtype), (int)lds,
+                     g->gt_s1rows.as<int>(), g->gt_lidx.as<unsigned short>(), g->gt_hdr.as<int>(),
+                     nslow.as<int>());
+  int slow = 0;
+  HIPCHK(hipMemcpyAsync(&slow, nslow.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  g->gt_rows = GSPX_TILE_BR;
+  g->gt_nb = nb;
+  g->gt_slow = slow;
+  g->gt_lds = lds;
+  if (stats) {
+    stats[0] = nb;
+    stats[1] = slow;
+    stats[2] = (int64_t)lds;
+    stats[3] = n_s1;
+  }
+  return GSPX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // step schedule ("plan")
 // ------------------------------------------------------------------------------------------------

@@ -261,3 +261,119 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
 }
 
 }  // namespace gspx
+
+// ---------------------------------------------------------------------------------------------
+// Gather tiles built on the device (what pygsp_amd/tiling.py computes with numpy):
+// pass A: per 64-row block, the sorted distinct columns of its entries -> tmp[b][0..n1), n1[b]
+// pass B: (after a scan of n1) s1rows, per-entry 16-bit positions, block headers
+// ---------------------------------------------------------------------------------------------
+namespace gspx {
+
+constexpr int GSPX_TILE_SORTCAP = 4096;  // entries of a block the LDS sort holds
+constexpr int GSPX_TILE_TMPCAP = 256;    // distinct rows kept per block (more: the block is "slow")
+
+__global__ __launch_bounds__(256) void k_tiles_unique(const int* __restrict__ rowptr,
+                                                      const int* __restrict__ col, int N, int nb,
+                                                      int* __restrict__ tmp, int* __restrict__ n1) {
+  __shared__ unsigned keys[GSPX_TILE_SORTCAP];
+  __shared__ int wsum[4];
+  const int b = blockIdx.x;
+  const int r0 = b * GSPX_TILE_BR, r1 = min(r0 + GSPX_TILE_BR, N);
+  const int e0 = rowptr[r0] & ~3, e1 = rowptr[r1] & ~3;
+  const int ent = e1 - e0;
+  if (ent > GSPX_TILE_SORTCAP) {  // a hub: no tile for this block
+    if (threadIdx.x == 0) n1[b] = GSPX_TILE_TMPCAP + 1;
+    return;
+  }
+  int n = 1;
+  while (n < ent) n <<= 1;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    unsigned v = 0xFFFFFFFFu;
+    if (i < ent) {
+      const int c = col[e0 + i];
+      if (c < N) v = (unsigned)c;  // pads (col == N) sort to the end with the filler
+    }
+    keys[i] = v;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned a = keys[i], c = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) {
+            keys[i] = c;
+            keys[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // distinct values, in order: position = number of "first occurrences" before it
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const bool first = i < n && keys[i] != 0xFFFFFFFFu && (i == 0 || keys[i] != keys[i - 1]);
+    // block-wide exclusive scan of `first`
+    const unsigned long long m = __ballot(first);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int before = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wv; ++w) off += wsum[w];
+    if (first && off + before < GSPX_TILE_TMPCAP) tmp[(size_t)b * GSPX_TILE_TMPCAP + off + before] = (int)keys[i];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    base += total;
+  }
+  if (threadIdx.x == 0) n1[b] = base;
+}
+
+__global__ __launch_bounds__(256) void k_tiles_fill(const int* __restrict__ rowptr,
+                                                    const int* __restrict__ col, int N, int nb,
+                                                    const int* __restrict__ tmp, const int* __restrict__ n1,
+                                                    const int* __restrict__ s1lo, int esz, int lds_bytes,
+                                                    int* __restrict__ s1rows, u16* __restrict__ lidx,
+                                                    int* __restrict__ hdr, int* __restrict__ nslow) {
+  const int b = blockIdx.x;
+  const int r0 = b * GSPX_TILE_BR, r1 = min(r0 + GSPX_TILE_BR, N);
+  const int e0 = rowptr[r0] & ~3, e1 = rowptr[r1] & ~3;
+  const int ent = e1 - e0;
+  const int n = n1[b];
+  const long need = (long)n * 256 + (((long)ent * esz + 15) & ~15L) + (((long)ent * 2 + 15) & ~15L) + 32;
+  const bool fast = n <= GSPX_TILE_MAXN1 && need <= lds_bytes;
+  const int lo = s1lo[b];
+  if (threadIdx.x == 0) {
+    hdr[(size_t)b * 4 + 0] = lo;
+    hdr[(size_t)b * 4 + 1] = fast ? n : -1;
+    hdr[(size_t)b * 4 + 2] = e0;
+    hdr[(size_t)b * 4 + 3] = ent;
+    if (!fast) atomicAdd(nslow, 1);
+  }
+  const int* list = tmp + (size_t)b * GSPX_TILE_TMPCAP;
+  const int keep = n <= GSPX_TILE_TMPCAP ? n : 0;  // slow blocks beyond the cap keep no list
+  for (int i = threadIdx.x; i < keep; i += 256) s1rows[lo + i] = list[i];
+  for (int i = threadIdx.x; i < ent; i += 256) {
+    const int c = col[e0 + i];
+    int pos = 0;
+    if (c < N && fast) {
+      int a = 0, z = n;
+      while (a < z) {
+        const int mid = (a + z) >> 1;
+        if (list[mid] < c) a = mid + 1; else z = mid;
+      }
+      pos = a;
+    }
+    lidx[e0 + i] = (u16)pos;
+  }
+}
+// kept rows per block for the scan (a slow block beyond the cap contributes none)
+__global__ void k_tiles_keep(const int* __restrict__ n1, int nb, int* __restrict__ keep) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= nb) keep[b] = (b < nb && n1[b] <= GSPX_TILE_TMPCAP) ? n1[b] : 0;
+}
+
+}  // namespace gspx

@@ -808,6 +808,15 @@ def test_tile_gather_kernel(ctx, dtype):
                     nodes, d = filters.cheb_to_newton(c)
                     yn, _ = dev.newton_filter(nodes, d, x, lmax)
                     assert rel_err(yn, ref) < tol, (nsig, order, "newton on tiles")
+        # the same tiles built on the device (per-block sort / unique in LDS) instead of numpy
+        st_dev = dev.build_gather_tiles()
+        assert st_dev["slow_blocks"] == stats["slow_blocks"] and st_dev["nb"] == stats["nb"]
+        if perm is not None:
+            assert abs(st_dev["mean_n1"] - stats["mean_n1"]) < 1e-9
+        c = orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, 9)
+        x = rng.standard_normal((W.shape[0], 12))
+        yd, _ = dev.cheby_filter(c, x, lmax)
+        assert rel_err(yd[0], orc.cheby_op(L, lmax, c, x.astype(dtype).astype(np.float64))) < tol
         # filterbank (deferred combine): its recurrence steps run on the tile kernel too; synthesis does not
         cb = np.stack([orc.compute_cheby_coeff(k, lmax, 12) for k in orc.mexican_hat_kernels(lmax, 3)])
         x = rng.standard_normal((W.shape[0], 8))
@@ -829,6 +838,7 @@ def test_tile_gather_kernel(ctx, dtype):
         dev = engine.DeviceGraph.from_w(Wr, lt, dtype=dtype, perm=engine.locality_order(Wr, None), ctx=ctx)
         st = dev.enable_gather_tiles()
         assert st["slow_blocks"] >= 1  # the hub's block does not fit
+        assert dev.build_gather_tiles()["slow_blocks"] == st["slow_blocks"]
         x = rng.standard_normal((5000, 16))
         c = orc.compute_cheby_coeff(orc.heat_kernel(9, lm), lm, 12)
         y, _ = dev.cheby_filter(c, x, lm)
