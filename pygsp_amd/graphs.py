@@ -110,9 +110,10 @@ class Graph:
                 # Cuthill-McKee on the pattern (0.25 s at N = 1M; within 6 % of Morton on kNN
                 # graphs) - kept only if it improves locality over the graph's own order
                 big = self.n_vertices >= 4096
-                self._perm = engine.auto_order(self.W, getattr(self, "coords", None)) if big else None
+                self._perm = engine.auto_order(self.W, getattr(self, "coords", None), self.device) if big else None
             elif mode in ("morton", "hilbert"):
-                self._perm = engine.locality_order(self.W, getattr(self, "coords", None), curve=mode)
+                self._perm = engine.locality_order(self.W, getattr(self, "coords", None), curve=mode,
+                                                   device=self.device)
             elif mode == "rcm":
                 self._perm = engine.locality_order(self.W, None)
             else:

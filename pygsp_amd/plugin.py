@@ -29,7 +29,7 @@ def device_graph_for(G):
     perm = None
     coords = getattr(G, "coords", None)
     if _config["reorder"] == "auto" and G.N >= 4096:
-        perm = engine.auto_order(G.W, coords)
+        perm = engine.auto_order(G.W, coords, _config["device"])
     elif _config["reorder"] == "rcm":
         perm = engine.locality_order(G.W, None)
     if _config["laplacian"] == "device":
