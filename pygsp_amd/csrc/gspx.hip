@@ -1287,8 +1287,13 @@ static bool tile_usable(const gspx_graph* g, const Options& opt, unsigned ld, co
 // ldy, perm, scale, gamma, beta, flush, final, wn, wc, wo
 template <typename T>
 static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, unsigned ld, hipStream_t st) {
-  const int ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
-  void (*kern)(const TileArgs<T>) = ncol == 1 ? k_step_tile<T, 1> : ncol == 2 ? k_step_tile<T, 2> : k_step_tile<T, 0>;
+  // narrow panels (rows of at most 128 bytes): 8-lane row groups, or half of every 16-lane group idles
+  const bool narrow = (size_t)ld * sizeof(T) <= 128;
+  const int ncol = narrow ? 1 : (int)(((size_t)ld * sizeof(T) + 255) / 256);
+  void (*kern)(const TileArgs<T>) = narrow      ? k_step_tile<T, 1, 8>
+                                    : ncol == 1 ? k_step_tile<T, 1>
+                                    : ncol == 2 ? k_step_tile<T, 2>
+                                                : k_step_tile<T, 0>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gt_lds));
   t.rowptr = g->rptr.as<int>();
   t.col = g->rcol.as<int>();

@@ -1118,7 +1118,7 @@ __device__ __forceinline__ V tile_row_dot(const T* __restrict__ val, const u16* 
 
 // The same dot product with the entries already in LDS (pads resolved), one 4-entry chunk per trip:
 // small register footprint, the staged kernel keeps a prefetched block's row lists live across it.
-template <typename T, typename V>
+template <typename T, typename V, int LG = 16>  // LG: lanes (16-byte pieces) per tile row
 __device__ __forceinline__ V lds_row_dot(const T* val, const u16* idx, int len, const V* tile, int lane16,
                                          V& self) {
   typedef T T4 __attribute__((ext_vector_type(4)));
@@ -1127,10 +1127,10 @@ __device__ __forceinline__ V lds_row_dot(const T* val, const u16* idx, int len, 
   for (int j = 0; j < len; j += 4) {
     const u16x4 ia = *(const u16x4*)(idx + j);
     const T4 va = *(const T4*)(val + j);
-    const V t0 = tile[ia.x * 16 + lane16];
-    const V t1 = tile[ia.y * 16 + lane16];
-    const V t2 = tile[ia.z * 16 + lane16];
-    const V t3 = tile[ia.w * 16 + lane16];
+    const V t0 = tile[ia.x * LG + lane16];
+    const V t1 = tile[ia.y * LG + lane16];
+    const V t2 = tile[ia.z * LG + lane16];
+    const V t3 = tile[ia.w * LG + lane16];
     if (j == 0) self = t0;
     acc += va.x * t0;
     acc += va.y * t1;

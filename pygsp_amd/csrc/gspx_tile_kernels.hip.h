@@ -56,7 +56,9 @@ template <typename T> struct TileArgs {
 constexpr int GSPX_TILE_BR = 64;      // rows per block
 constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group)
 
-template <typename T, int NCOL>  // NCOL = 1, 2: that many 256-byte column chunks per row; 0: a.ncol chunks
+// LG = lanes per row group: 16 (256-byte column chunks; 32 groups x 2 rows) or 8 (128-byte chunks for
+// narrow panels; 64 groups x 1 row).  NCOL = 1, 2: that many column chunks per row; 0: a.ncol chunks
+template <typename T, int NCOL, int LG = 16>
 __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   constexpr int VEC = 16 / (int)sizeof(T);
   typedef typename VT<T, VEC>::t V;
@@ -64,8 +66,12 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gspx_smem[];
 
   const int tid = threadIdx.x;
-  const int lane16 = tid & 15;
-  const int grp = tid >> 4;  // 0..31: two rows of the block each
+  constexpr int NG = 512 / LG;             // row groups per workgroup
+  constexpr int RPG = GSPX_TILE_BR / NG;   // rows of the block per group
+  constexpr int ST = (GSPX_TILE_MAXN1 + NG - 1) / NG;  // tile rows a group stages
+  constexpr int RB = LG * 16;              // bytes of a tile row
+  const int lane16 = tid & (LG - 1);
+  const int grp = tid / LG;
   const int wave = tid >> 6;
   const int nwx = (int)(gridDim.x >> 3);
   const int xlo = (int)(blockIdx.x & 7) * a.per_xcd;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   const rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)a.lidx, 0, a.lidx_bytes, 0x00020000);
   const u32 ldb = a.ld * (u32)sizeof(T);
 
-  struct Meta { int rows[5]; int rp[3]; };
+  struct Meta { int rows[ST]; int rp[RPG + 1]; };
   auto load_hdr = [&](int k) { return *(const int4*)(a.hdr + (size_t)k * 4); };
   auto uniform = [](int4 h) {
     int4 u;
@@ -94,26 +100,26 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     Meta m;
     const int n1 = h.y;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int u = grp + 32 * t;
+    for (int t = 0; t < ST; ++t) {
+      const int u = grp + NG * t;
       m.rows[t] = a.s1rows[h.x + (u < n1 ? u : 0)];
     }
-    int r = k * GSPX_TILE_BR + grp * 2;
+    int r = k * GSPX_TILE_BR + grp * RPG;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) m.rp[t] = a.rowptr[(r + t) <= a.N ? (r + t) : a.N];
+    for (int t = 0; t < RPG + 1; ++t) m.rp[t] = a.rowptr[(r + t) <= a.N ? (r + t) : a.N];
     return m;
   };
   V* const tile = (V*)gspx_smem;
   auto stage = [&](const Meta& m, int n1, u32 cb) {
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      if (grp + 32 * t < n1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rcur, (lds_ptr)(gspx_smem + (wave * 4 + 32 * t) * 256), 16,
+    for (int t = 0; t < ST; ++t) {
+      if (grp + NG * t < n1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rcur, (lds_ptr)(gspx_smem + (wave * (64 / LG) + NG * t) * RB), 16,
                                                  (u32)m.rows[t] * ldb + cb, 0, 0, 0);
     }
   };
   auto chunk_off = [&](int c) {
-    const u32 col0 = (c * 16 + lane16) * VEC;
+    const u32 col0 = (c * LG + lane16) * VEC;
     return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
   };
 
@@ -127,30 +133,32 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   auto pass = [&](const int c, const bool first, const bool last) __attribute__((always_inline)) {
     const int n1 = H.y, rp0 = H.z, ent = H.w;
     const bool fast = n1 >= 0;
-    T* const mval = (T*)(tile + (fast ? n1 : 0) * 16);
+    T* const mval = (T*)(tile + (fast ? n1 : 0) * LG);
     u16* const midx = (u16*)(mval + ent);
-    const int row0 = k * GSPX_TILE_BR + grp * 2;
-    const int s0 = M.rp[0] & ~3, s1 = M.rp[1] & ~3, s2 = M.rp[2] & ~3;
-    const u32 col0 = (c * 16 + lane16) * VEC;
+    const int row0 = k * GSPX_TILE_BR + grp * RPG;
+    int rs[RPG + 1];
+#pragma unroll
+    for (int t = 0; t < RPG + 1; ++t) rs[t] = M.rp[t] & ~3;
+    const u32 col0 = (c * LG + lane16) * VEC;
     const bool on = col0 < a.ld;
     const u32 cb = on ? col0 * (u32)sizeof(T) : POISON;
     // T_{k-2} (and the accumulator) of the group's two rows
-    V ov[2], ra[2];
+    V ov[RPG], ra[RPG];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < RPG; ++t) {
       const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
       ov[t] = VT<T, VEC>::bload(rold, a.gamma != T(0) ? off : POISON);
       ra[t] = VT<T, VEC>::bload(rra, a.flush == 2 ? off : POISON);
     }
-    V ins[2];
-    ins[0] = 0;
-    ins[1] = 0;
+    V ins[RPG];
+#pragma unroll
+    for (int t = 0; t < RPG; ++t) ins[t] = 0;
     if (a.nin > 0) {
       const rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.inp, 0, a.panel_bytes * (u32)a.nin, 0x00020000);
       for (int f = 0; f < a.nin; ++f) {
         const T w = a.wts[f];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < RPG; ++t) {
           const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
           ins[t] += w * VT<T, VEC>::bload(rin, off == POISON ? POISON : off + (u32)f * a.panel_bytes);
         }
@@ -182,13 +190,13 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     __syncthreads();  // tile and entries in place
     int4 Hnn = Hn;
     if (last) Hnn = uniform(Hv);  // youngest load of the pass: everything prefetched has landed
-    V nv[2], cv[2];
+    V nv[RPG], cv[RPG];
     if (fast) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int s = t == 0 ? s0 : s1, e = t == 0 ? s1 : s2;
+      for (int t = 0; t < RPG; ++t) {
+        const int s = rs[t], e = rs[t + 1];
         V self;
-        const V acc = lds_row_dot<T, V>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
+        const V acc = lds_row_dot<T, V, LG>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
                                         lane16, self);
         nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
         cv[t] = self;
@@ -196,8 +204,8 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     } else {
       // plain gathers from global memory (tile too large for LDS)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int s = t == 0 ? s0 : s1, e = t == 0 ? s1 : s2;
+      for (int t = 0; t < RPG; ++t) {
+        const int s = rs[t], e = rs[t + 1];
         V acc = 0, self = 0;
         if (row0 + t < a.N) {
           for (int j = s; j < e; ++j) {
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     // next pass's tile: the next chunk of this block, or chunk 0 of the next block
     if (more && H.y >= 0) stage(M, H.y, chunk_off(last ? 0 : c + 1));
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < RPG; ++t) {
       const int row = row0 + t;
       if (row < a.N && on) {
         if (a.final && !a.flush) {  // Newton form: the last step's result is the output
