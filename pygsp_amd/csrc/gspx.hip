@@ -1286,7 +1286,8 @@ static bool tile_usable(const gspx_graph* g, const Options& opt, unsigned ld, co
 // fills the graph / geometry fields of t and launches; the caller sets cur, old, out, racc, y,
 // ldy, perm, scale, gamma, beta, flush, final, wn, wc, wo
 template <typename T>
-static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, unsigned ld, hipStream_t st) {
+static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, unsigned ld, hipStream_t st,
+                            const T* vals = nullptr) {
   // narrow panels (rows of at most 128 bytes): 8-lane row groups, or half of every 16-lane group idles
   const bool narrow = (size_t)ld * sizeof(T) <= 128;
   const int ncol = narrow ? 1 : (int)(((size_t)ld * sizeof(T) + 255) / 256);
@@ -1297,7 +1298,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gt_lds));
   t.rowptr = g->rptr.as<int>();
   t.col = g->rcol.as<int>();
-  t.val = g->fval.as<T>();
+  t.val = vals ? vals : g->fval.as<T>();  // any values array on the internal pattern
   t.hdr = g->gt_hdr.as<int>();
   t.s1rows = g->gt_s1rows.as<int>();
   t.lidx = g->gt_lidx.as<unsigned short>();

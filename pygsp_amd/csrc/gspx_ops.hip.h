@@ -29,6 +29,22 @@ static int spmm_internal(gspx_graph* g, const T* vals, T scale, T beta, const T*
                          unsigned ld, T* y, unsigned ldy) {
   gspx_ctx* ctx = g->ctx;
   Options opt = ctx->opt;
+  if (tile_usable<T>(g, opt, ld, y ? y : out, y ? ldy : ld)) {  // LDS-staged gather, as the filter steps
+    TileArgs<T> t{};
+    t.cur = cur;
+    t.old = cur;
+    t.out = out;
+    t.racc = const_cast<T*>(cur);  // unused (flush == 0)
+    t.y = y;
+    t.ldy = ldy;
+    t.perm = g->has_perm ? g->perm.as<int>() : nullptr;
+    t.scale = scale;
+    t.gamma = T(0);
+    t.beta = beta;
+    t.flush = 0;
+    t.final = y ? 1 : 0;
+    return launch_step_tile<T>(g, opt, t, ld, ctx->stream, vals);
+  }
   if (opt.kernel == 3 || opt.kernel == 4) opt.kernel = 0;  // wave-row kernels have no beta term
   int veccap = 4;
   if (y)
@@ -138,10 +154,12 @@ static int dirichlet_t(gspx_graph* g, int64_t Nsig, const T* x, double* gram, do
   CHK(ctx->ws_t.ensure((size_t)2 * N * ld * sizeof(T) + 256));
   T* P0 = ctx->ws_t.as<T>();
   T* P1 = P0 + (size_t)N * ld;
-  const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, (N + 63) / 64));
-  DevMem partial;
-  CHK(partial.alloc((size_t)nb * 256 * sizeof(double)));
-  std::vector<double> hp((size_t)nb * 256);
+  // per-block partial Gram matrices, reduced on the device (at most 512 MB of them)
+  const int64_t nb_cap = std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)ld * ld * 8));
+  const int nb = (int)std::min<int64_t>(std::min<int64_t>(256, nb_cap), std::max<int64_t>(1, (N + 63) / 64));
+  DevMem partial, gsum;
+  CHK(partial.alloc((size_t)nb * ld * ld * sizeof(double)));
+  CHK(gsum.alloc((size_t)ld * ld * sizeof(double)));
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   CHK(permute_panel<T>(g, x, ld, P0, ld, g->has_perm ? g->perm.as<int>() : nullptr));
   CHK(spmm_internal<T>(g, g->rval.as<T>(), T(1), T(0), P0, P1, ld, nullptr, 0));
@@ -151,15 +169,10 @@ static int dirichlet_t(gspx_graph* g, int64_t Nsig, const T* x, double* gram, do
       const int na = std::min(16, (int)ld - a0), nc = std::min(16, (int)ld - c0);
       hipLaunchKernelGGL((k_gram_partial<T>), dim3(nb), dim3(256), 0, st, P0, P1, (int)N, (int)ld, a0,
                          na, c0, nc, partial.as<double>());
-      HIPCHK(hipMemcpyAsync(hp.data(), partial.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      for (int a = 0; a < na; ++a)
-        for (int c = 0; c < nc; ++c) {
-          double s = 0;
-          for (int b = 0; b < nb; ++b) s += hp[(size_t)b * 256 + a * 16 + c];
-          gram[(size_t)(a0 + a) * ld + (c0 + c)] = s;
-        }
     }
+  hipLaunchKernelGGL(k_colsum, dim3(ld * ld), dim3(64), 0, st, partial.as<double>(), nb, (int)(ld * ld),
+                     gsum.as<double>());
+  HIPCHK(hipMemcpyAsync(gram, gsum.p, (size_t)ld * ld * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
@@ -173,7 +186,7 @@ extern "C" int gspx_dirichlet_energy_dev(gspx_graph* g, int64_t Nsig, const void
                                          double* gram_host, double* kernel_ms) {
   if (g) replay_reset(g->ctx);
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
-  if (Nsig < 0 || Nsig > 4096) return set_err(GSPX_ERR_INVALID, "dirichlet_energy: 0 <= Nsig <= 4096");
+  if (Nsig < 0 || Nsig > 2048) return set_err(GSPX_ERR_INVALID, "dirichlet_energy: 0 <= Nsig <= 2048");
   if (Nsig > 0 && (!gram_host || (g->N > 0 && !x_dev))) return set_err(GSPX_ERR_INVALID, "null pointer");
   HIPCHK(hipSetDevice(g->ctx->device));
   return g->dtype == GSPX_F32 ? dirichlet_t<float>(g, Nsig, (const float*)x_dev, gram_host, kernel_ms)
@@ -207,7 +220,7 @@ static int tikhonov_t(gspx_graph* g, double tau, const T* mask, int64_t Nsig, co
   CHK(permute_panel<T>(g, mask, 1, mint.as<T>(), 1, perm));
   hipLaunchKernelGGL((k_affine_values<T>), dim3(nbN), dim3(256), 0, st, g->rptr.as<int>(),
                      g->rcol.as<int>(), g->rval.as<T>(), (int)N, (T)tau, mint.as<T>(), aval.as<T>());
-  const int nred = (int)std::min<int64_t>(1024, std::max<int64_t>(1, N / 64));
+  const int nred = (int)std::min<int64_t>(4096, std::max<int64_t>(1, N / 64));
   for (int64_t c0 = 0; c0 < Nsig; c0 += max_ld) {
     const unsigned ld = (unsigned)std::min<int64_t>(max_ld, Nsig - c0);
     int ldp = 1;
@@ -234,7 +247,7 @@ static int tikhonov_t(gspx_graph* g, double tau, const T* mask, int64_t Nsig, co
     auto coldot = [&](const T* a_, const T* b_, double* out) {
       hipLaunchKernelGGL((k_coldot_partial<T>), dim3(nred), dim3(256), 0, st, a_, b_, (int)N, (int)ld,
                          ldp, partial.as<double>());
-      hipLaunchKernelGGL(k_colsum, dim3(nbl), dim3(64), 0, st, partial.as<double>(), nred, (int)ld, out);
+      hipLaunchKernelGGL(k_colsum, dim3(ld), dim3(64), 0, st, partial.as<double>(), nred, (int)ld, out);
     };
     // b = M y (learning.py:325-326 zeroes the unmeasured entries), r = b, x = 0
     CHK(permute_panel<T>(g, y + c0, (unsigned)Nsig, B, ld, perm));
@@ -371,17 +384,19 @@ static int grad_div_t(gspx_graph* g, bool is_div, int64_t Nsig, const T* in, T* 
   gspx_ctx* ctx = g->ctx;
   hipStream_t st = ctx->stream;
   if (ms) *ms = 0;
-  const size_t total = (size_t)(is_div ? g->N : g->n_edges) * (size_t)Nsig;
-  if (total == 0) return GSPX_OK;
-  const unsigned nb = (unsigned)std::min<size_t>((total + 255) / 256, 1 << 20);
+  const size_t rows = (size_t)(is_div ? g->N : g->n_edges);
+  if (rows == 0 || Nsig == 0) return GSPX_OK;
+  int cw = 1;  // lanes across the signals of one row: a power of two up to 64
+  while (cw < 64 && cw < Nsig) cw <<= 1;
+  const unsigned nb = (unsigned)std::min<size_t>((rows + (256 / cw) - 1) / (256 / cw), 1 << 20);
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   if (is_div)
     hipLaunchKernelGGL((k_div<T>), dim3(nb), dim3(256), 0, st, g->e_off.as<int>(), g->e_toff.as<int>(),
                        g->e_tedge.as<int>(), g->e_cs.as<T>(), g->e_ct.as<T>(), in, out, (int)g->N,
-                       (int)Nsig);
+                       (int)Nsig, cw);
   else
     hipLaunchKernelGGL((k_grad<T>), dim3(nb), dim3(256), 0, st, g->e_src.as<int>(), g->e_dst.as<int>(),
-                       g->e_cs.as<T>(), g->e_ct.as<T>(), in, out, (size_t)g->n_edges, (int)Nsig);
+                       g->e_cs.as<T>(), g->e_ct.as<T>(), in, out, (size_t)g->n_edges, (int)Nsig, cw);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));

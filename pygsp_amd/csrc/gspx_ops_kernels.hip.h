@@ -43,8 +43,17 @@ __global__ __launch_bounds__(256) void k_coldot_partial(const T* __restrict__ A,
   const int rstep = 256 / ldp;
   double acc = 0;
   if (c < ld) {
-    for (size_t i = (size_t)blockIdx.x * rstep + r0; i < (size_t)N; i += (size_t)gridDim.x * rstep)
-      acc += (double)A[i * ld + c] * (double)B[i * ld + c];
+    const size_t stride = (size_t)gridDim.x * rstep;
+    size_t i = (size_t)blockIdx.x * rstep + r0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // four rows in flight per thread
+    for (; i + 3 * stride < (size_t)N; i += 4 * stride) {
+      a0 += (double)A[i * ld + c] * (double)B[i * ld + c];
+      a1 += (double)A[(i + stride) * ld + c] * (double)B[(i + stride) * ld + c];
+      a2 += (double)A[(i + 2 * stride) * ld + c] * (double)B[(i + 2 * stride) * ld + c];
+      a3 += (double)A[(i + 3 * stride) * ld + c] * (double)B[(i + 3 * stride) * ld + c];
+    }
+    for (; i < (size_t)N; i += stride) a0 += (double)A[i * ld + c] * (double)B[i * ld + c];
+    acc = (a0 + a1) + (a2 + a3);
   }
   ws[threadIdx.x] = acc;
   __syncthreads();
@@ -54,16 +63,19 @@ __global__ __launch_bounds__(256) void k_coldot_partial(const T* __restrict__ A,
     if (threadIdx.x < ld) partial[(size_t)blockIdx.x * ld + threadIdx.x] = s;
   }
 }
-// out[c] = sum_b partial[b][c], fixed order
-__global__ void k_colsum(const double* __restrict__ partial, int nb, int ld, double* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// out[c] = sum_b partial[b][c]: one 64-lane wave per column, fixed summation tree (deterministic)
+__global__ __launch_bounds__(64) void k_colsum(const double* __restrict__ partial, int nb, int ld,
+                                               double* __restrict__ out) {
+  const int c = blockIdx.x;
   if (c >= ld) return;
   double s = 0;
-  for (int b = 0; b < nb; ++b) s += partial[(size_t)b * ld + c];
-  out[c] = s;
+  for (int b = threadIdx.x; b < nb; b += 64) s += partial[(size_t)b * ld + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (threadIdx.x == 0) out[c] = s;
 }
 
-// Gram block: partial[b][a][c] = sum over the block's rows of X[i][a0 + a] * Y[i][c0 + c]
+// Gram block: partial[b][a0 + a][c0 + c] (ld x ld per block) = sum over the block's rows of X[i][a0 + a] * Y[i][c0 + c]
 // (na, nc <= 16; one thread per (a, c) pair, rows staged through LDS 64 at a time)
 template <typename T>
 __global__ __launch_bounds__(256) void k_gram_partial(const T* __restrict__ X, const T* __restrict__ Y,
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256) void k_gram_partial(const T* __restrict__ X, c
     for (int r = 0; r < 64; ++r) acc += xs[r][ta] * ys[r][tc];
     __syncthreads();
   }
-  partial[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+  if (ta < na && tc < nc) partial[(size_t)blockIdx.x * ld * ld + (size_t)(a0 + ta) * ld + (c0 + tc)] = acc;
 }
 
 // ---- conjugate gradient, one independent system per column (scipy.sparse.linalg.cg's recurrence) ---
@@ -116,11 +128,12 @@ __global__ void k_cg_pre(CgScalars s, const double* __restrict__ rr, int ld, int
   }
 }
 // p = r + beta p on the active columns
+// (element indices fit 32 bits: a panel is below 2 GiB; the column comes from a 32-bit modulo)
 template <typename T>
 __global__ void k_cg_p(const T* __restrict__ r, T* __restrict__ p, size_t total, int ld, CgScalars s) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % (size_t)ld);
+  const unsigned n = (unsigned)total, step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const int c = (int)(i % (unsigned)ld);
     if (s.active[c]) p[i] = r[i] + (T)s.beta[c] * p[i];
   }
 }
@@ -136,9 +149,9 @@ __global__ void k_cg_post(CgScalars s, const double* __restrict__ pq, int ld) {
 template <typename T>
 __global__ void k_cg_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
                         const T* __restrict__ q, size_t total, int ld, CgScalars s) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % (size_t)ld);
+  const unsigned n = (unsigned)total, step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const int c = (int)(i % (unsigned)ld);
     if (s.active[c]) {
       const T al = (T)s.alpha[c];
       x[i] += al * p[i];
@@ -159,9 +172,9 @@ __global__ void k_cg_init(CgScalars s, const double* __restrict__ bb, int ld, do
 template <typename T>
 __global__ void k_rowscale(const T* __restrict__ m, const T* __restrict__ y, T* __restrict__ out,
                            size_t total, int ld) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x)
-    out[i] = m[i / (size_t)ld] * y[i];
+  const unsigned n = (unsigned)total, step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+    out[i] = m[i / (unsigned)ld] * y[i];
 }
 
 // ---- differential operator of an undirected graph (difference.py:140-166) --------------------------
@@ -229,37 +242,39 @@ __global__ void k_edge_fill(const int* __restrict__ lptr, const int* __restrict_
   }
 }
 // grad: y[k][:] = cs[k] * x[src[k]][:] + ct[k] * x[dst[k]][:]      (D.T.dot(x), difference.py:244)
+// 2-D thread blocks (cw columns x 256/cw edges): consecutive lanes walk the signals of one edge, no
+// index division anywhere
 template <typename T>
-__global__ void k_grad(const int* __restrict__ esrc, const int* __restrict__ edst,
-                       const T* __restrict__ cs, const T* __restrict__ ct, const T* __restrict__ x,
-                       T* __restrict__ y, size_t E, int ld) {
-  const size_t total = E * (size_t)ld;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t k = idx / (size_t)ld;
-    const int c = (int)(idx - k * (size_t)ld);
-    y[idx] = cs[k] * x[(size_t)esrc[k] * ld + c] + ct[k] * x[(size_t)edst[k] * ld + c];
+__global__ __launch_bounds__(256) void k_grad(const int* __restrict__ esrc, const int* __restrict__ edst,
+                                              const T* __restrict__ cs, const T* __restrict__ ct,
+                                              const T* __restrict__ x, T* __restrict__ y, size_t E, int ld,
+                                              int cw) {
+  const int cx = threadIdx.x % cw, ry = threadIdx.x / cw, rpb = 256 / cw;
+  for (size_t k = (size_t)blockIdx.x * rpb + ry; k < E; k += (size_t)gridDim.x * rpb) {
+    const size_t s = (size_t)esrc[k] * ld, d = (size_t)edst[k] * ld;
+    const T a = cs[k], b = ct[k];
+    for (int c = cx; c < ld; c += cw) y[k * ld + c] = a * x[s + c] + b * x[d + c];
   }
 }
 // div: z[i][:] = sum_{k: src = i} cs[k] y[k][:] + sum_{k: dst = i} ct[k] y[k][:]   (D.dot(y), :331)
 template <typename T>
-__global__ void k_div(const int* __restrict__ eoff, const int* __restrict__ toff,
-                      const int* __restrict__ tedge, const T* __restrict__ cs,
-                      const T* __restrict__ ct, const T* __restrict__ y, T* __restrict__ z, int N,
-                      int ld) {
-  const size_t total = (size_t)N * ld;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx / (size_t)ld);
-    const int c = (int)(idx - (size_t)i * ld);
-    T acc = 0;
-    // the order of scipy's csc_matvec over D's rows does not matter for the value beyond rounding
-    for (int k = eoff[i]; k < eoff[i + 1]; ++k) acc += cs[k] * y[(size_t)k * ld + c];
-    for (int m = toff[i]; m < toff[i + 1]; ++m) {
-      const int k = tedge[m];
-      acc += ct[k] * y[(size_t)k * ld + c];
+__global__ __launch_bounds__(256) void k_div(const int* __restrict__ eoff, const int* __restrict__ toff,
+                                             const int* __restrict__ tedge, const T* __restrict__ cs,
+                                             const T* __restrict__ ct, const T* __restrict__ y,
+                                             T* __restrict__ z, int N, int ld, int cw) {
+  const int cx = threadIdx.x % cw, ry = threadIdx.x / cw, rpb = 256 / cw;
+  for (size_t i = (size_t)blockIdx.x * rpb + ry; i < (size_t)N; i += (size_t)gridDim.x * rpb) {
+    const int e0 = eoff[i], e1 = eoff[i + 1], t0 = toff[i], t1 = toff[i + 1];
+    for (int c = cx; c < ld; c += cw) {
+      T acc = 0;
+      // the order of scipy's csc_matvec over D's rows does not matter for the value beyond rounding
+      for (int k = e0; k < e1; ++k) acc += cs[k] * y[(size_t)k * ld + c];
+      for (int m = t0; m < t1; ++m) {
+        const int k = tedge[m];
+        acc += ct[k] * y[(size_t)k * ld + c];
+      }
+      z[i * ld + c] = acc;
     }
-    z[idx] = acc;
   }
 }
 

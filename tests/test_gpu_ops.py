@@ -102,6 +102,8 @@ def test_oracle_sensor20k(ctx, dtype, lap_type):
     D = ops.differential_operator(W, lap_type)
     for perm in (engine.locality_order(W, coords), None):
         dev = engine.DeviceGraph.from_w(W, lap_type, dtype=dtype, perm=perm, ctx=ctx)
+        if perm is not None:  # with gather tiles the products run on the LDS-staged kernel
+            assert dev.build_gather_tiles()["slow_blocks"] == 0
         for nsig in (1, 3, 16, 64):
             X = rng.standard_normal((N, nsig)).astype(dtype)
             X64 = X.astype(np.float64)
@@ -131,6 +133,8 @@ def test_oracle_tikhonov(ctx, dtype):
     y = np.where(mask[:, None], smooth, 0.0)
     for perm in (engine.locality_order(W, coords), None):
         dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+        if perm is not None:
+            dev.build_gather_tiles()
         for tau in (0.3, 3.0):
             ref = ops.regression_tikhonov(L, y.astype(dtype).astype(np.float64), mask, tau)
             x, iters, _ = dev.tikhonov_cg(tau, mask, y)

@@ -26,6 +26,7 @@ for dtype in (np.float64, np.float32):
     tag = np.dtype(dtype).name
     elt = np.dtype(dtype).itemsize
     dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+    dev.build_gather_tiles()  # what graphs.Graph does for a graph of this size
     X = rng.standard_normal((N, nsig)).astype(dtype)
     bx, by = ctx.upload(X), ctx.alloc(X.nbytes)
     res = {}
