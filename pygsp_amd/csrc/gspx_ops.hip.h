@@ -154,23 +154,24 @@ static int dirichlet_t(gspx_graph* g, int64_t Nsig, const T* x, double* gram, do
   CHK(ctx->ws_t.ensure((size_t)2 * N * ld * sizeof(T) + 256));
   T* P0 = ctx->ws_t.as<T>();
   T* P1 = P0 + (size_t)N * ld;
-  // per-block partial Gram matrices, reduced on the device (at most 512 MB of them)
-  const int64_t nb_cap = std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)ld * ld * 8));
-  const int nb = (int)std::min<int64_t>(std::min<int64_t>(256, nb_cap), std::max<int64_t>(1, (N + 63) / 64));
+  // per-wave partial Gram matrices, reduced on the device (at most 512 MB of them)
+  const int64_t nw_cap = std::max<int64_t>(4, ((int64_t)512 << 20) / ((int64_t)ld * ld * 8));
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(512, nw_cap / 4), (N + 255) / 256));
+  const int nwaves = nb * 4;
   DevMem partial, gsum;
-  CHK(partial.alloc((size_t)nb * ld * ld * sizeof(double)));
+  CHK(partial.alloc((size_t)nwaves * ld * ld * sizeof(double)));
   CHK(gsum.alloc((size_t)ld * ld * sizeof(double)));
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   CHK(permute_panel<T>(g, x, ld, P0, ld, g->has_perm ? g->perm.as<int>() : nullptr));
   CHK(spmm_internal<T>(g, g->rval.as<T>(), T(1), T(0), P0, P1, ld, nullptr, 0));
   // the sums do not depend on the vertex order: both panels stay in the internal order
-  for (int a0 = 0; a0 < (int)ld; a0 += 16)
-    for (int c0 = 0; c0 < (int)ld; c0 += 16) {
-      const int na = std::min(16, (int)ld - a0), nc = std::min(16, (int)ld - c0);
-      hipLaunchKernelGGL((k_gram_partial<T>), dim3(nb), dim3(256), 0, st, P0, P1, (int)N, (int)ld, a0,
-                         na, c0, nc, partial.as<double>());
+  for (int a0 = 0; a0 < (int)ld; a0 += 64)
+    for (int c0 = 0; c0 < (int)ld; c0 += 64) {
+      const int na = std::min(64, (int)ld - a0), nc = std::min(64, (int)ld - c0);
+      hipLaunchKernelGGL((k_gram_mfma<T>), dim3(nb), dim3(256), 0, st, P0, P1, (int)N, (int)ld, a0, na, c0,
+                         nc, partial.as<double>());
     }
-  hipLaunchKernelGGL(k_colsum, dim3(ld * ld), dim3(64), 0, st, partial.as<double>(), nb, (int)(ld * ld),
+  hipLaunchKernelGGL(k_colsum, dim3(ld * ld), dim3(64), 0, st, partial.as<double>(), nwaves, (int)(ld * ld),
                      gsum.as<double>());
   HIPCHK(hipMemcpyAsync(gram, gsum.p, (size_t)ld * ld * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[1], st));

@@ -75,28 +75,53 @@ __global__ __launch_bounds__(64) void k_colsum(const double* __restrict__ partia
   if (threadIdx.x == 0) out[c] = s;
 }
 
-// Gram block: partial[b][a0 + a][c0 + c] (ld x ld per block) = sum over the block's rows of X[i][a0 + a] * Y[i][c0 + c]
-// (na, nc <= 16; one thread per (a, c) pair, rows staged through LDS 64 at a time)
+// Gram block on the matrix cores: G[a0 + a][c0 + c] += sum_i X[i][a0 + a] * Y[i][c0 + c] for a 64 x 64 block
+// of the Gram matrix (na, nc <= 64 valid columns).  This IS a dense panel contraction (8 flop/byte at 64
+// signals), so it runs on MFMA: v_mfma_f64_16x16x4f64 takes A = X^T (16 signals x 4 rows) and B = Y
+// (4 rows x 16 signals) straight from coalesced row loads - lane l holds row l / 16, column l % 16 of
+// both - and accumulates a 16 x 16 tile; a wave keeps the 4 x 4 tiles of its block in registers and
+// walks the rows four at a time.  fp32 panels are converted on load: the sums are double either way.
+// partial[w][a][c] (ld x ld per wave, only this block's entries written).
 template <typename T>
-__global__ __launch_bounds__(256) void k_gram_partial(const T* __restrict__ X, const T* __restrict__ Y,
-                                                      int N, int ld, int a0, int na, int c0, int nc,
-                                                      double* __restrict__ partial) {
-  __shared__ double xs[64][16], ys[64][16];
-  const int ta = threadIdx.x >> 4, tc = threadIdx.x & 15;
-  double acc = 0;
-  for (size_t base = (size_t)blockIdx.x * 64; base < (size_t)N; base += (size_t)gridDim.x * 64) {
-    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-      const int r = e >> 4, q = e & 15;
-      const size_t row = base + r;
-      xs[r][q] = (row < (size_t)N && q < na) ? (double)X[row * ld + a0 + q] : 0.0;
-      ys[r][q] = (row < (size_t)N && q < nc) ? (double)Y[row * ld + c0 + q] : 0.0;
+__global__ __launch_bounds__(256) void k_gram_mfma(const T* __restrict__ X, const T* __restrict__ Y, int N,
+                                                   int ld, int a0, int na, int c0, int nc,
+                                                   double* __restrict__ partial) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int kq = lane >> 4, cq = lane & 15;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+  for (long r4 = gw; r4 * 4 < (long)N; r4 += nw) {
+    const long row = r4 * 4 + kq;
+    const bool rok = row < (long)N;
+    double xa[4], yb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ca = t * 16 + cq;
+      xa[t] = (rok && ca < na) ? (double)X[(size_t)row * ld + a0 + ca] : 0.0;
+      yb[t] = (rok && ca < nc) ? (double)Y[(size_t)row * ld + c0 + ca] : 0.0;
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < 64; ++r) acc += xs[r][ta] * ys[r][tc];
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
   }
-  if (ta < na && tc < nc) partial[(size_t)blockIdx.x * ld * ld + (size_t)(a0 + ta) * ld + (c0 + tc)] = acc;
+  // D layout of the f64 16x16x4 instruction: lane l holds rows (l / 16) + 4 e (e = 0..3), column l % 16
+  double* out = partial + (size_t)gw * ld * ld;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int aa = i * 16 + kq + 4 * e, cc = j * 16 + cq;
+        if (aa < na && cc < nc) out[(size_t)(a0 + aa) * ld + (c0 + cc)] = acc[i][j][e];
+      }
 }
 
 // ---- conjugate gradient, one independent system per column (scipy.sparse.linalg.cg's recurrence) ---
