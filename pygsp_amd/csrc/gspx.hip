@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1295,7 +1296,17 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
                                     : ncol == 1 ? k_step_tile<T, 1>
                                     : ncol == 2 ? k_step_tile<T, 2>
                                                 : k_step_tile<T, 0>;
-  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gt_lds));
+  {  // once per kernel build and device (a driver call per launch would cost microseconds each)
+    static std::map<std::pair<const void*, int>, size_t> lds_set;
+    static std::mutex lds_mu;
+    std::lock_guard<std::mutex> lock(lds_mu);
+    const auto key = std::make_pair((const void*)kern, g->ctx->device);
+    auto it = lds_set.find(key);
+    if (it == lds_set.end() || it->second != g->gt_lds) {
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gt_lds));
+      lds_set[key] = g->gt_lds;
+    }
+  }
   t.rowptr = g->rptr.as<int>();
   t.col = g->rcol.as<int>();
   t.val = vals ? vals : g->fval.as<T>();  // any values array on the internal pattern
