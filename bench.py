@@ -291,6 +291,23 @@ def main():
                         "device_laplacian_build_ms": dev.build_ms},
         }
 
+    # ---- end to end through the mirrored API: numpy in -> Filter.filter -> numpy out (PCIe both ways,
+    # coefficient quadrature, shape handling); reported beside the device-resident rate, never as `value`
+    if rank == 0 and world == 1:
+        flt = filters.Heat(G, a.scale)
+        flt.filter(x[:, :4], method="chebyshev", order=K)  # warm-up (allocations)
+        te = time.perf_counter()
+        y_host = flt.filter(x, method="chebyshev", order=K)
+        t_e2e = time.perf_counter() - te
+        out["end_to_end_host_arrays"] = {
+            "ms": t_e2e * 1e3, "value": N * nsig * K / t_e2e,
+            "note": "pygsp_amd.filters.Heat(G, scale).filter(x_host, method='chebyshev', order=K): "
+                    "host-to-device copy of x, kernels, device-to-host copy of y"}
+        assert y_host.shape == (N, nsig)
+        del y_host
+        step()  # leave the timed path's result in the output buffer for the parity check below
+        fence()
+
     # ---- CPU baseline beside it (rank 0, N=1 only): the oracle on a bounded column sample --------
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle import cheby_oracle as orc
