@@ -64,6 +64,7 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
+    p.add_argument("--no-e2e", action="store_true", help="skip the numpy-in/numpy-out leg (profiling passes)")
     p.add_argument("--tiles", choices=["auto", "off"], default="auto",
                    help="auto = the product default (LDS-staged recurrence step when the graph's order "
                         "is local); off = the plain gather kernels")
@@ -293,7 +294,7 @@ def main():
 
     # ---- end to end through the mirrored API: numpy in -> Filter.filter -> numpy out (PCIe both ways,
     # coefficient quadrature, shape handling); reported beside the device-resident rate, never as `value`
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_e2e:
         flt = filters.Heat(G, a.scale)
         flt.filter(x[:, :4], method="chebyshev", order=K)  # warm-up (allocations)
         te = time.perf_counter()
