@@ -238,6 +238,17 @@ int gspx_knn_download_w(gspx_knn* h, int32_t* indptr, int32_t* indices, double* 
 /* NN[:, 1:] and D[:, 1:] of the reference: N x k, nearest first (either may be NULL) */
 int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist);
 
+/* Stochastic block model / Erdos-Renyi graph sampled on the device: every unordered pair (r, c) of
+ * distinct vertices is an edge (unit weight) independently with probability M[z_r][z_c] - the
+ * distribution of pygsp/graphs/stochasticblockmodel.py:125-144 (directed=False, self_loops=False)
+ * and erdosrenyi.py (k = 1), in O(edges) instead of the reference's N^2 Python loop.  The random
+ * stream is the engine's own (counter-based), so graphs equal the reference's in distribution, not
+ * bit for bit.  order: the vertices grouped by block (a stable argsort of z), bounds[k + 1]: where
+ * each block starts in it, M: k x k symmetric, row-major.  The result is read with
+ * gspx_knn_info / gspx_knn_download_w and freed with gspx_knn_destroy. */
+int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const int64_t* bounds,
+                   const double* M, uint64_t seed, gspx_knn** out);
+
 /* Space-filling-curve keys of N points (coords: N x d doubles on the HOST, d >= 2; the first two /
  * three axes are used): curve 0 = Morton, 1 = Hilbert (2-D).  The engine's internal vertex order
  * for graphs with coordinates is the stable argsort of these keys (pygsp_amd.engine.locality_order). */

@@ -529,9 +529,218 @@ extern "C" int gspx_knn_download_w(gspx_knn* h, int32_t* indptr, int32_t* indice
 
 extern "C" int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist) {
   if (!h) return set_err(GSPX_ERR_INVALID, "null handle");
+  if (h->k == 0) return set_err(GSPX_ERR_INVALID, "this handle was not built by gspx_knn_build");
   HIPCHK(hipSetDevice(h->ctx->device));
   const size_t nk = (size_t)h->N * h->k;
   if (nn) HIPCHK(hipMemcpy(nn, h->nn.p, nk * sizeof(int), hipMemcpyDeviceToHost));
   if (dist) HIPCHK(hipMemcpy(dist, h->dist.p, nk * sizeof(double), hipMemcpyDeviceToHost));
+  return GSPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stochastic block model / Erdos-Renyi sampler on the device (second half).
+// The reference visits all N^2 ordered pairs in a Python loop and keeps pair (r > c) with probability
+// M[z_r][z_c] (pygsp/graphs/stochasticblockmodel.py:125-144; erdosrenyi.py is the one-block case).
+// Same distribution in O(edges): the candidates of every block pair (a, b <= a) - a triangle of
+// n_a (n_a - 1) / 2 pairs for a == b, a rectangle of n_a n_b otherwise - are cut into chunks; one
+// thread walks a chunk by geometric skips (the gap to the next kept pair of independent Bernoulli(p)
+// trials is Geometric(p)), so every pair is kept independently with probability p, chunks are
+// independent, and no duplicate can arise.  Counter-based random numbers (a hash of seed, chunk and
+// draw number): pass 1 counts, pass 2 replays the same stream and emits.  The stream differs from
+// numpy's, so graphs are equal in distribution to the reference's, not bit-equal.
+// ------------------------------------------------------------------------------------------------
+namespace gspx {
+
+struct SbmSeg {       // one block pair
+  long long total;    // candidate pairs
+  long long chunk;    // candidates per chunk
+  long long first;    // global index of its first chunk
+  double log1mp;      // log(1 - p)  (-inf for p == 1)
+  int lo_a, n_a, lo_b, n_b;  // member ranges in `order`; lo_a == lo_b: within-block triangle
+};
+
+__device__ __forceinline__ unsigned long long sbm_hash(unsigned long long x) {  // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// u in (0, 1]
+__device__ __forceinline__ double sbm_uniform(unsigned long long seed, unsigned long long chunk, unsigned draw) {
+  const unsigned long long h = sbm_hash(sbm_hash(seed ^ (chunk * 0xD1B54A32D192ED03ull)) + draw);
+  return (double)((h >> 11) + 1) * (1.0 / 9007199254740992.0);
+}
+
+// PASS 0: count per chunk; PASS 1: emit (er[], ec[]) at off[chunk] and count degrees
+template <int PASS>
+__global__ void k_sbm_chunks(const SbmSeg* __restrict__ seg, int nseg, long long nchunks,
+                             unsigned long long seed, const int* __restrict__ order,
+                             int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ er,
+                             int* __restrict__ ec, int* __restrict__ deg) {
+  const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= nchunks) return;
+  int lo = 0, hi = nseg - 1;  // last segment whose first chunk is <= ch
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid].first <= ch) lo = mid; else hi = mid - 1;
+  }
+  const SbmSeg s = seg[lo];
+  const long long base = (ch - s.first) * s.chunk;
+  const long long len = min(s.chunk, s.total - base);
+  long long pos = 0;
+  int n = 0;
+  const int o = PASS ? off[ch] : 0;
+  for (unsigned draw = 0;; ++draw) {
+    const double u = sbm_uniform(seed, (unsigned long long)ch, draw);
+    const double g = floor(log(u) / s.log1mp);  // failures before the next success
+    if (!(g < (double)(len - pos))) break;
+    pos += (long long)g;
+    if (PASS) {
+      const long long idx = base + pos;
+      long long r, c;
+      if (s.lo_a == s.lo_b) {  // idx = r (r - 1) / 2 + c, r > c
+        r = (long long)floor((1.0 + sqrt(1.0 + 8.0 * (double)idx)) * 0.5);
+        if (r * (r - 1) / 2 > idx) --r;
+        if ((r + 1) * r / 2 <= idx) ++r;
+        c = idx - r * (r - 1) / 2;
+      } else {
+        r = idx / s.n_b;
+        c = idx - r * s.n_b;
+      }
+      const int vr = order[s.lo_a + (int)r], vc = order[s.lo_b + (int)c];
+      er[o + n] = vr;
+      ec[o + n] = vc;
+      atomicAdd(&deg[vr], 1);
+      atomicAdd(&deg[vc], 1);
+    }
+    ++n;
+    ++pos;
+    if (pos >= len) break;
+  }
+  if (!PASS) cnt[ch] = n;
+}
+__global__ void k_sbm_fill(const int* __restrict__ er, const int* __restrict__ ec, long long m,
+                           const int* __restrict__ rowptr, int* __restrict__ cursor, int* __restrict__ col,
+                           double* __restrict__ val) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m) return;
+  const int r = er[e], c = ec[e];
+  const int a = rowptr[r] + atomicAdd(&cursor[r], 1);
+  col[a] = c;
+  val[a] = 1.0;
+  const int b = rowptr[c] + atomicAdd(&cursor[c], 1);
+  col[b] = r;
+  val[b] = 1.0;
+}
+
+}  // namespace gspx
+
+extern "C" int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const int64_t* bounds,
+                              const double* M, uint64_t seed, gspx_knn** out) {
+  if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null ctx or output");
+  *out = nullptr;
+  if (N < 1 || N >= ((int64_t)1 << 31) - 1 || k < 1 || k > 4096 || !order || !bounds || !M)
+    return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: bad argument");
+  if (bounds[0] != 0 || bounds[k] != N) return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: bounds must span [0, N]");
+  for (int a = 0; a < k; ++a) {
+    if (bounds[a + 1] < bounds[a]) return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: bounds must not decrease");
+    for (int b = 0; b < k; ++b) {
+      const double p = M[(size_t)a * k + b];
+      if (!(p >= 0.0 && p <= 1.0)) return set_err(GSPX_ERR_INVALID, "Probabilities should be in [0, 1].");
+      if (p != M[(size_t)b * k + a]) return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: M must be symmetric (undirected graphs)");
+    }
+  }
+  std::vector<SbmSeg> segs;
+  long long nchunks = 0;
+  for (int a = 0; a < k; ++a)
+    for (int b = 0; b <= a; ++b) {
+      const double p = M[(size_t)a * k + b];
+      const long long na = bounds[a + 1] - bounds[a], nbk = bounds[b + 1] - bounds[b];
+      const long long total = a == b ? na * (na - 1) / 2 : na * nbk;
+      if (p <= 0.0 || total <= 0) continue;
+      SbmSeg s{};
+      s.total = total;
+      long long c = 64;  // about 16 kept pairs per chunk
+      while (c < ((long long)1 << 22) && (double)c * p < 16.0) c <<= 1;
+      s.chunk = c;
+      s.first = nchunks;
+      s.log1mp = std::log1p(-p);
+      s.lo_a = (int)bounds[a];
+      s.n_a = (int)na;
+      s.lo_b = (int)bounds[b];
+      s.n_b = (int)nbk;
+      nchunks += (total + c - 1) / c;
+      segs.push_back(s);
+    }
+  if (nchunks >= ((long long)1 << 31)) return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: too many candidate chunks");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto t0 = std::chrono::steady_clock::now();
+  gspx_knn* h = new gspx_knn();
+  h->ctx = ctx;
+  h->N = N;
+  auto fail = [&](int rc) {
+    delete h;
+    return rc;
+  };
+#define KCHK(x)                      \
+  do {                               \
+    int rc__ = (x);                  \
+    if (rc__ != GSPX_OK) return fail(rc__); \
+  } while (0)
+#define KHIP(x)                                                                            \
+  do {                                                                                     \
+    hipError_t e__ = (x);                                                                  \
+    if (e__ != hipSuccess) return fail(set_err(GSPX_ERR_HIP, "%s: %s", #x, hipGetErrorString(e__))); \
+  } while (0)
+  const int n = (int)N;
+  DevMem dseg, dorder, cnt, off, er, ec, deg, cursor;
+  KCHK(h->rowptr.alloc(((size_t)N + 1) * sizeof(int)));
+  KCHK(deg.alloc(((size_t)N + 1) * sizeof(int)));
+  KHIP(hipMemsetAsync(deg.p, 0, ((size_t)N + 1) * sizeof(int), st));
+  long long m = 0;
+  if (nchunks > 0) {
+    KCHK(dseg.alloc(segs.size() * sizeof(SbmSeg)));
+    KCHK(dorder.alloc((size_t)N * sizeof(int)));
+    KCHK(cnt.alloc(((size_t)nchunks + 1) * sizeof(int)));
+    KCHK(off.alloc(((size_t)nchunks + 1) * sizeof(int)));
+    KHIP(hipMemcpyAsync(dseg.p, segs.data(), segs.size() * sizeof(SbmSeg), hipMemcpyHostToDevice, st));
+    KHIP(hipMemcpyAsync(dorder.p, order, (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+    KHIP(hipMemsetAsync(cnt.p, 0, ((size_t)nchunks + 1) * sizeof(int), st));
+    const unsigned nbc = (unsigned)((nchunks + 255) / 256);
+    hipLaunchKernelGGL((k_sbm_chunks<0>), dim3(nbc), dim3(256), 0, st, dseg.as<SbmSeg>(), (int)segs.size(), nchunks,
+                       (unsigned long long)seed, dorder.as<int>(), cnt.as<int>(), (const int*)nullptr,
+                       (int*)nullptr, (int*)nullptr, (int*)nullptr);
+    KCHK(scan_exclusive(ctx, cnt.as<int>(), off.as<int>(), (int)nchunks + 1));
+    int mi = 0;
+    KHIP(hipMemcpyAsync(&mi, off.as<int>() + nchunks, sizeof(int), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+    if (mi < 0 || (long long)mi * 2 >= ((long long)1 << 31))
+      return fail(set_err(GSPX_ERR_INVALID, "gspx_sbm_build: more than 2^30 edges"));
+    m = mi;
+    KCHK(er.alloc((size_t)std::max<long long>(m, 1) * sizeof(int)));
+    KCHK(ec.alloc((size_t)std::max<long long>(m, 1) * sizeof(int)));
+    hipLaunchKernelGGL((k_sbm_chunks<1>), dim3(nbc), dim3(256), 0, st, dseg.as<SbmSeg>(), (int)segs.size(), nchunks,
+                       (unsigned long long)seed, dorder.as<int>(), (int*)nullptr, off.as<int>(), er.as<int>(),
+                       ec.as<int>(), deg.as<int>());
+  }
+  KCHK(scan_exclusive(ctx, deg.as<int>(), h->rowptr.as<int>(), n + 1));
+  h->nnz = 2 * m;
+  KCHK(h->col.alloc((size_t)std::max<long long>(2 * m, 1) * sizeof(int)));
+  KCHK(h->val.alloc((size_t)std::max<long long>(2 * m, 1) * sizeof(double)));
+  if (m > 0) {
+    KCHK(cursor.alloc(((size_t)N + 1) * sizeof(int)));
+    KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)N + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(k_sbm_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, er.as<int>(), ec.as<int>(),
+                       m, h->rowptr.as<int>(), cursor.as<int>(), h->col.as<int>(), h->val.as<double>());
+    hipLaunchKernelGGL(k_knn_row_sort, dim3((n + 255) / 256), dim3(256), 0, st, h->rowptr.as<int>(), n,
+                       h->col.as<int>(), h->val.as<double>());
+  }
+  KHIP(hipGetLastError());
+  KHIP(hipStreamSynchronize(st));
+#undef KCHK
+#undef KHIP
+  h->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *out = h;
   return GSPX_OK;
 }

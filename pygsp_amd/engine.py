@@ -656,6 +656,38 @@ def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False):
     return W, sg.value, info
 
 
+def sbm_graph(z, M, seed=None, ctx=None):
+    """Stochastic-block-model adjacency sampled on the device (gspx_sbm_build): every unordered pair
+    of distinct vertices (r, c) is an edge with probability M[z[r], z[c]], unit weights
+    (stochasticblockmodel.py:125-144 with directed=False, self_loops=False; one block = Erdos-Renyi).
+    z: (N,) block labels in 0..k-1, M: (k, k) symmetric.  Returns (W csr float64, build_ms)."""
+    ctx = ctx or default_context()
+    z = np.asarray(z)
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    k = M.shape[0]
+    if M.shape != (k, k) or z.ndim != 1 or (z.size and (z.min() < 0 or z.max() >= k)):
+        raise ValueError("z must hold labels 0..k-1 and M must be k x k")
+    N = z.size
+    order = np.ascontiguousarray(np.argsort(z, kind="stable"), dtype=np.int32)
+    bounds = np.ascontiguousarray(np.searchsorted(z[order], np.arange(k + 1)), dtype=np.int64)
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    _capi.check(lib.gspx_sbm_build(ctx._h, N, k, _capi.ptr(order), _capi.ptr(bounds), _capi.ptr(M),
+                                   ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.byref(h)))
+    try:
+        nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))
+        indptr = np.empty(N + 1, dtype=np.int32)
+        indices = np.empty(nnz.value, dtype=np.int32)
+        data = np.empty(nnz.value, dtype=np.float64)
+        _capi.check(lib.gspx_knn_download_w(h, _capi.ptr(indptr), _capi.ptr(indices), _capi.ptr(data)))
+    finally:
+        lib.gspx_knn_destroy(h)
+    return sparse.csr_matrix((data, indices, indptr), shape=(N, N)), ms.value
+
+
 def plan_describe(coeffs, ctx=None):
     """The engine's step schedule for these coefficients (host-only; for schedule tests)."""
     c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))

@@ -440,15 +440,55 @@ def sbm_weights(N, k=5, z=None, p=0.7, q=None, seed=None):
 
 
 class StochasticBlockModel(Graph):
-    def __init__(self, N=1024, k=5, z=None, p=0.7, q=None, seed=None, **kwargs):
-        W, z = sbm_weights(N, k, z, p, q, seed)
-        self.z = z
-        super().__init__(W, **kwargs)
+    """stochasticblockmodel.py:12-181 for undirected graphs without self-loops: labels z (sorted random
+    labels from the same numpy stream as the reference when not given), probabilities M (or p on the
+    diagonal and q elsewhere), edges sampled on the device in O(edges) (engine.sbm_graph) - equal in
+    distribution to the reference's N^2 loop, not bit-equal.  ``sbm_weights`` is the numpy sampler of
+    the same distribution."""
+
+    def __init__(self, N=1024, k=5, z=None, M=None, p=0.7, q=None, directed=False, self_loops=False,
+                 connected=False, n_try=10, seed=None, **kwargs):
+        if directed or self_loops or connected:
+            raise NotImplementedError("the device sampler covers directed=False, self_loops=False, "
+                                      "connected=False")
+        self.k, self.directed, self.self_loops, self.connected = k, directed, self_loops, connected
+        self.n_try, self.seed = n_try, seed
+        rng = np.random.default_rng(seed)
+        if z is None:
+            z = rng.integers(0, k, N)
+            z.sort()  # stochasticblockmodel.py:84-87
+        self.z = np.asarray(z)
+        if M is None:
+            self.p = p
+            p = np.asanyarray(p, dtype=np.float64)
+            if p.size == 1:
+                p = p * np.ones(k)
+            if p.shape != (k,):
+                raise ValueError("Optional parameter p is neither a scalar nor a vector of length k.")
+            if q is None:
+                q = 0.3 / k
+            self.q = q
+            q = np.asanyarray(q, dtype=np.float64)
+            if q.size == 1:
+                q = q * np.ones((k, k))
+            if q.shape != (k, k):
+                raise ValueError("Optional parameter q is neither a scalar nor a matrix of size k x k.")
+            M = np.array(q, dtype=np.float64)
+            M.flat[::k + 1] = p
+        self.M = np.asarray(M, dtype=np.float64)
+        if (self.M < 0).any() or (self.M > 1).any():
+            raise ValueError("Probabilities should be in [0, 1].")
+        sub = int(rng.integers(0, 2 ** 63))  # the device stream's seed, drawn from the same generator
+        ctx = engine.default_context(int(kwargs.get("device", 0)))
+        W, self.sampler_ms = engine.sbm_graph(self.z, self.M, seed=sub, ctx=ctx)
+        W = sparse.csr_matrix((np.ones(W.nnz, dtype=np.int64), W.indices, W.indptr), shape=W.shape)  # int64 unit
+        super().__init__(W, **kwargs)                                  # weights, as the reference's W
 
 
-class ErdosRenyi(Graph):
+class ErdosRenyi(StochasticBlockModel):
     """erdosrenyi.py:49-61: the one-block stochastic block model."""
 
-    def __init__(self, N=100, p=0.1, seed=None, **kwargs):
-        W, _ = sbm_weights(N, 1, np.zeros(N, dtype=np.int64), p, 0, seed)
-        super().__init__(W, **kwargs)
+    def __init__(self, N=100, p=0.1, directed=False, self_loops=False, connected=False, n_try=10,
+                 seed=None, **kwargs):
+        super().__init__(N=N, k=1, p=p, directed=directed, self_loops=self_loops, connected=connected,
+                         n_try=n_try, seed=seed, **kwargs)

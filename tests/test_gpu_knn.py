@@ -134,3 +134,64 @@ def test_curve_keys_match_host_orders(ctx):
     Wk, coords = graphs.sensor_weights(20000, k=6, seed=1)
     p = engine.locality_order(Wk, coords)
     assert np.mean(p == engine.hilbert_order(coords)) > 0.999
+
+
+# ---------------------------------------------------------------------------------------------
+# stochastic block model / Erdos-Renyi sampler on the device (second half of SURVEY 8(f) row 4)
+# ---------------------------------------------------------------------------------------------
+def _block_counts(W, z, k):
+    coo = W.tocoo()
+    up = coo.row > coo.col
+    m = np.zeros((k, k))
+    np.add.at(m, (z[coo.row[up]], z[coo.col[up]]), 1)
+    return m + m.T - np.diag(np.diag(m))  # unordered pairs per block pair
+
+
+def test_sbm_sampler_distribution(ctx):
+    """Not bit-comparable with the reference (different random stream): checked as a distribution -
+    edge counts per block pair within 5 sigma of Binomial(#pairs, M[a, b]), symmetric, no self loops,
+    no duplicates, deterministic per seed; cross-checked against the numpy sampler's counts."""
+    rng = np.random.default_rng(0)
+    N, k = 60000, 4
+    z = np.sort(rng.integers(0, k, N))
+    M = np.array([[3e-4, 2e-5, 0, 1e-5], [2e-5, 5e-4, 4e-5, 0], [0, 4e-5, 2e-4, 3e-5], [1e-5, 0, 3e-5, 6e-4]])
+    W, ms = engine.sbm_graph(z, M, seed=123, ctx=ctx)
+    assert W.shape == (N, N) and W.has_sorted_indices and W.has_canonical_format
+    assert W.diagonal().max() == 0 and abs(W - W.T).max() == 0
+    assert W.data.min() == 1 and W.data.max() == 1          # unit weights, no duplicate pair
+    sizes = np.bincount(z, minlength=k).astype(np.float64)
+    pairs = np.outer(sizes, sizes)
+    pairs[np.diag_indices(k)] = sizes * (sizes - 1) / 2
+    cnt = _block_counts(W, z, k)
+    mean, sd = pairs * M, np.sqrt(pairs * M * (1 - M))
+    assert (np.abs(cnt - mean) <= 5 * sd + 1e-9).all(), (cnt, mean)
+    assert (cnt[M == 0] == 0).all()
+    # same seed -> same graph; another seed -> another graph with the same statistics
+    W2, _ = engine.sbm_graph(z, M, seed=123, ctx=ctx)
+    assert abs(W - W2).max() == 0
+    W3, _ = engine.sbm_graph(z, M, seed=124, ctx=ctx)
+    assert abs(W - W3).nnz > 0 and (np.abs(_block_counts(W3, z, k) - mean) <= 5 * sd + 1e-9).all()
+    # unsorted labels: the block structure follows z, not the vertex numbering
+    zp = rng.permutation(z)
+    Wp, _ = engine.sbm_graph(zp, M, seed=5, ctx=ctx)
+    assert (np.abs(_block_counts(Wp, zp, k) - mean) <= 5 * sd + 1e-9).all()
+    # degrees of an Erdos-Renyi graph: Binomial(N - 1, p), no vertex left out of the sampling
+    G = graphs.ErdosRenyi(200000, p=2e-5, seed=3)
+    d = np.ravel(G.W.sum(axis=0))
+    assert abs(d.mean() - 199999 * 2e-5) < 5 * np.sqrt(199999 * 2e-5 / 200000) * 1.5
+    assert abs(d.var() - 199999 * 2e-5) < 0.1 * 199999 * 2e-5
+    first, last = d[:1000].mean(), d[-1000:].mean()         # the triangle's ends are sampled like its middle
+    assert abs(first - 4.0) < 0.5 and abs(last - 4.0) < 0.5
+    # dense probabilities and p = 1 (every pair): small graph
+    Wd, _ = engine.sbm_graph(np.zeros(300, dtype=np.int64), np.array([[1.0]]), seed=1, ctx=ctx)
+    assert Wd.nnz == 300 * 299
+    Wh, _ = engine.sbm_graph(np.repeat([0, 1], 150), np.array([[0.7, 0.1], [0.1, 0.7]]), seed=1, ctx=ctx)
+    c2 = _block_counts(Wh, np.repeat([0, 1], 150), 2)
+    assert abs(c2[0, 0] - 0.7 * 150 * 149 / 2) < 5 * np.sqrt(0.21 * 150 * 149 / 2)
+    assert abs(c2[0, 1] - 0.1 * 150 * 150) < 5 * np.sqrt(0.09 * 150 * 150)
+    with pytest.raises(ValueError):
+        engine.sbm_graph(z, np.array([[2.0]]), ctx=ctx)
+    with pytest.raises(NotImplementedError):
+        graphs.StochasticBlockModel(100, directed=True)
+    G = graphs.StochasticBlockModel(2000, k=3, seed=7)       # defaults p = 0.7, q = 0.1
+    assert G.W.shape == (2000, 2000) and np.array_equal(G.z, np.sort(np.random.default_rng(7).integers(0, 3, 2000)))
