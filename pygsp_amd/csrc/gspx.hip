@@ -1050,9 +1050,12 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
     return s;
   }
   if (opt.kernel == 5 && ld > 4) kernel = 5;
-  // auto: fp32 panels -> LDS-staged kernel, fp64 panels -> scalar-metadata lane-group kernel
-  // (equal within 2 % in fp64, the LDS kernel is 25 % faster in fp32)
-  if (opt.kernel == 0 && kernel == 1 && elt == 4) kernel = 5;
+  // auto: fp32 panels and fp64 panels of up to 32 signals -> LDS-staged kernel; wide fp64 panels ->
+  // scalar-metadata lane-group kernel.  Measured (tools/experiments/exp_mid_width.py, headline graph):
+  // fp32 the LDS kernel is 25 % faster; fp64 x 8 / 16 / 32 signals 0.18 / 0.21 / 0.26 ms per order
+  // against 0.28 / 0.31 / 0.37 (many rows per row set make the scalar blends expensive); fp64 x 64
+  // the scalar-metadata kernel wins by 4 %.
+  if (opt.kernel == 0 && kernel == 1 && (elt == 4 || ld <= 32)) kernel = 5;
   s.kernel = kernel;
   if (kernel == 1 || kernel == 5) {
     s.vec = vec;
@@ -1280,7 +1283,9 @@ template <typename T>
 static bool tile_usable(const gspx_graph* g, const Options& opt, unsigned ld, const T* y, unsigned ldy) {
   constexpr int TVEC = 16 / (int)sizeof(T);
   const size_t U = (size_t)g->N * ld;
-  return opt.tile_gather && g->gt_rows == GSPX_TILE_BR && (ld % TVEC) == 0 && (ldy % TVEC) == 0 &&
+  // (rows of 16 bytes - 2 fp64 / 4 fp32 signals - stay with the narrow kernel, which measured faster there)
+  return opt.tile_gather && g->gt_rows == GSPX_TILE_BR && (size_t)ld * sizeof(T) >= 32 && (ld % TVEC) == 0 &&
+         (ldy % TVEC) == 0 &&
          (((uintptr_t)y / sizeof(T)) % TVEC) == 0 && U * sizeof(T) < ((size_t)1 << 31) &&
          (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31);
 }
