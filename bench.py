@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--nsig", type=int, default=64)
     p.add_argument("--order", type=int, default=30)
     p.add_argument("--scale", type=float, default=50.0)
-    p.add_argument("--cpu-cols", type=int, default=8, help="columns of the CPU-baseline sample")
+    p.add_argument("--cpu-cols", type=int, default=16, help="columns of the CPU-baseline sample")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
