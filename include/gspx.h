@@ -238,6 +238,13 @@ int gspx_knn_download_w(gspx_knn* h, int32_t* indptr, int32_t* indices, double* 
 /* NN[:, 1:] and D[:, 1:] of the reference: N x k, nearest first (either may be NULL) */
 int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist);
 
+/* Radius graphs: NNtype='radius' of NNGraph (nngraph.py:228-287) - neighbours within epsilon (the
+ * KD-tree's ball query, squared distance <= epsilon^2), weights exp(-d^2 / sigma), sigma == 0 selects
+ * the mean neighbour distance ("No neighbors found" -> GSPX_ERR_INVALID, as the reference's ValueError).
+ * Result read with gspx_knn_info / gspx_knn_download_w, freed with gspx_knn_destroy. */
+int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, double epsilon,
+                      double sigma, gspx_knn** out);
+
 /* Stochastic block model / Erdos-Renyi graph sampled on the device: every unordered pair (r, c) of
  * distinct vertices is an edge (unit weight) independently with probability M[z_r][z_c] - the
  * distribution of pygsp/graphs/stochasticblockmodel.py:125-144 (directed=False, self_loops=False)

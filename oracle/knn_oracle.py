@@ -59,3 +59,30 @@ def sensor_coords(N, seed=None, distributed=False):
         coords += rng.uniform(0, 1 / m, (N, 2))
         return coords
     return rng.uniform(0, 1, (N, 2))
+
+
+def radius_weights(Xout, epsilon, sigma=None):
+    """nngraph.py:228-297 (NNtype='radius', euclidean): ball query, distances by
+    scipy.spatial.distance.minkowski, sigma = mean neighbour distance, Gaussian weights, 'average'
+    symmetrisation.  Vectorised over the neighbour lists (the reference loops in Python; same values).
+    Returns (W csr, sigma)."""
+    from scipy.spatial import distance
+    N = Xout.shape[0]
+    kdt = spatial.KDTree(Xout)
+    NN = [kdt.query_ball_point(p, r=epsilon, p=2) for p in Xout]
+    rows, cols, dists = [], [], []
+    for i, nb in enumerate(NN):
+        for j in nb:
+            if j != i:
+                rows.append(i)
+                cols.append(j)
+                dists.append(distance.minkowski(Xout[i], Xout[j], p=2))
+    if not dists and sigma is None:
+        raise ValueError("No neighbors found")
+    dists = np.asarray(dists, dtype=np.float64)
+    if sigma is None:
+        sigma = np.mean(dists)
+    spv = np.exp(-np.power(dists, 2) / float(sigma))
+    W = sparse.csc_matrix((spv, (np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64))), shape=(N, N))
+    W = (W + W.T) / 2
+    return sparse.csr_matrix(W), float(sigma)

@@ -744,3 +744,198 @@ extern "C" int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* or
   *out = h;
   return GSPX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Radius graphs (NNtype='radius' of NNGraph, nngraph.py:228-287): neighbours = the points within
+// epsilon (squared distance <= epsilon^2, the KD-tree's ball query), weights exp(-d^2 / sigma) with
+// sigma = mean neighbour distance unless given.  The relation is symmetric and so are the weights, so
+// (W + W^T) / 2 = W.  Same grid as the k-NN search with cells of at least epsilon: 3^d cells per query;
+// pass 1 counts, pass 2 fills, rows are then sorted by column.
+// ------------------------------------------------------------------------------------------------
+namespace gspx {
+
+template <int PASS>
+__global__ __launch_bounds__(128) void k_radius_query(const double* __restrict__ sorted,
+                                                      const int* __restrict__ order,
+                                                      const int* __restrict__ start, int N, KnnGrid g,
+                                                      double eps2, int* __restrict__ cnt,
+                                                      const int* __restrict__ rowptr, int* __restrict__ col,
+                                                      double* __restrict__ dist) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const int self = order[s];
+  double q[3] = {0, 0, 0};
+  for (int j = 0; j < g.d; ++j) q[j] = sorted[(size_t)s * g.d + j];
+  int c[3];
+  knn_cell_of(g, q, c);
+  const int r2 = g.d >= 2 ? 1 : 0, r3 = g.d >= 3 ? 1 : 0;
+  int n = 0;
+  const int o = PASS ? rowptr[self] : 0;
+  for (int dz = -r3; dz <= r3; ++dz) {
+    const int cz = c[2] + dz;
+    if (cz < 0 || cz >= g.n[2]) continue;
+    for (int dy = -r2; dy <= r2; ++dy) {
+      const int cy = c[1] + dy;
+      if (cy < 0 || cy >= g.n[1]) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int cx = c[0] + dx;
+        if (cx < 0 || cx >= g.n[0]) continue;
+        const int cid = (cz * g.n[1] + cy) * g.n[0] + cx;
+        for (int a = start[cid]; a < start[cid + 1]; ++a) {
+          const int idx = order[a];
+          if (idx == self) continue;
+          const double d2 = knn_sqdist(q, sorted + (size_t)a * g.d, g.d);
+          if (d2 <= eps2) {
+            if (PASS) {
+              col[o + n] = idx;
+              dist[o + n] = knn_sqrt(d2);
+            }
+            ++n;
+          }
+        }
+      }
+    }
+  }
+  if (!PASS) cnt[self] = n;
+}
+__global__ void k_radius_weights(const double* __restrict__ dist, size_t nnz, double sigma,
+                                 double* __restrict__ val) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz) {
+    const double d = dist[e];
+    val[e] = exp(-(d * d) / sigma);
+  }
+}
+
+}  // namespace gspx
+
+extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, double epsilon,
+                                 double sigma, gspx_knn** out) {
+  if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null ctx or output");
+  *out = nullptr;
+  if (N < 1 || N >= ((int64_t)1 << 31) / 64) return set_err(GSPX_ERR_INVALID, "gspx_radius_build: bad N");
+  if (d < 1 || d > 3)
+    return set_err(GSPX_ERR_INVALID, "gspx_radius_build: the device search covers 1 to 3 dimensions (got %d)", d);
+  if (!coords) return set_err(GSPX_ERR_INVALID, "null coordinates");
+  if (!(epsilon > 0) || !std::isfinite(epsilon)) return set_err(GSPX_ERR_INVALID, "epsilon must be positive");
+  if (!(sigma >= 0) || !std::isfinite(sigma)) return set_err(GSPX_ERR_INVALID, "sigma must be >= 0 (0: mean distance)");
+  KnnGrid g{};
+  g.d = d;
+  double hi[3] = {0, 0, 0};
+  for (int j = 0; j < 3; ++j) {
+    g.lo[j] = 0;
+    g.inv_h[j] = 1;
+    g.n[j] = 1;
+  }
+  for (int j = 0; j < d; ++j) g.lo[j] = hi[j] = coords[j];
+  for (int64_t i = 0; i < N; ++i)
+    for (int j = 0; j < d; ++j) {
+      const double v = coords[i * d + j];
+      if (!std::isfinite(v)) return set_err(GSPX_ERR_INVALID, "non-finite coordinate");
+      g.lo[j] = std::min(g.lo[j], v);
+      hi[j] = std::max(hi[j], v);
+    }
+  // cells of at least epsilon (a little more, against rounding at the walls), at most `cap` per axis
+  const int cap = d == 1 ? (1 << 21) : (d == 2 ? 2048 : 128);
+  int64_t ncells = 1;
+  g.h_min = 1e300;
+  for (int j = 0; j < d; ++j) {
+    const double ext = hi[j] - g.lo[j];
+    int n = ext > 0 ? (int)std::min<double>((double)cap, std::floor(ext / (epsilon * 1.0000001))) : 1;
+    n = std::max(n, 1);
+    const double h = ext > 0 ? ext / n : 1.0;
+    g.n[j] = n;
+    g.inv_h[j] = 1.0 / h;
+    g.h_min = std::min(g.h_min, h);
+    ncells *= n;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto t0 = std::chrono::steady_clock::now();
+  gspx_knn* h = new gspx_knn();
+  h->ctx = ctx;
+  h->N = N;
+  h->d = d;
+  auto fail = [&](int rc) {
+    delete h;
+    return rc;
+  };
+#define KCHK(x)                      \
+  do {                               \
+    int rc__ = (x);                  \
+    if (rc__ != GSPX_OK) return fail(rc__); \
+  } while (0)
+#define KHIP(x)                                                                            \
+  do {                                                                                     \
+    hipError_t e__ = (x);                                                                  \
+    if (e__ != hipSuccess) return fail(set_err(GSPX_ERR_HIP, "%s: %s", #x, hipGetErrorString(e__))); \
+  } while (0)
+  const int n = (int)N;
+  DevMem x, sorted, cell, count, start, cursor, order, cnt, partial;
+  KCHK(x.alloc((size_t)N * d * sizeof(double)));
+  KCHK(sorted.alloc((size_t)N * d * sizeof(double)));
+  KCHK(cell.alloc((size_t)N * sizeof(int)));
+  KCHK(count.alloc(((size_t)ncells + 1) * sizeof(int)));
+  KCHK(start.alloc(((size_t)ncells + 1) * sizeof(int)));
+  KCHK(cursor.alloc(((size_t)ncells + 1) * sizeof(int)));
+  KCHK(order.alloc((size_t)N * sizeof(int)));
+  KCHK(cnt.alloc(((size_t)N + 1) * sizeof(int)));
+  KCHK(h->rowptr.alloc(((size_t)N + 1) * sizeof(int)));
+  KHIP(hipMemcpyAsync(x.p, coords, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, st));
+  KHIP(hipMemsetAsync(count.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
+  KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
+  KHIP(hipMemsetAsync(cnt.p, 0, ((size_t)N + 1) * sizeof(int), st));
+  const int nbN = (n + 255) / 256;
+  hipLaunchKernelGGL(k_knn_cell_count, dim3(nbN), dim3(256), 0, st, x.as<double>(), n, g, cell.as<int>(),
+                     count.as<int>());
+  KCHK(scan_exclusive(ctx, count.as<int>(), start.as<int>(), (int)ncells + 1));
+  hipLaunchKernelGGL(k_knn_scatter, dim3(nbN), dim3(256), 0, st, cell.as<int>(), n, start.as<int>(),
+                     cursor.as<int>(), order.as<int>());
+  hipLaunchKernelGGL(k_knn_cell_sort, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st,
+                     start.as<int>(), (int)ncells, order.as<int>(), x.as<double>(), d, sorted.as<double>());
+  const double eps2 = epsilon * epsilon;
+  hipLaunchKernelGGL((k_radius_query<0>), dim3((n + 127) / 128), dim3(128), 0, st, sorted.as<double>(),
+                     order.as<int>(), start.as<int>(), n, g, eps2, cnt.as<int>(), (const int*)nullptr,
+                     (int*)nullptr, (double*)nullptr);
+  KCHK(scan_exclusive(ctx, cnt.as<int>(), h->rowptr.as<int>(), n + 1));
+  int nnz = 0;
+  KHIP(hipMemcpyAsync(&nnz, h->rowptr.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+  KHIP(hipStreamSynchronize(st));
+  if (nnz < 0) return fail(set_err(GSPX_ERR_INVALID, "gspx_radius_build: more than 2^31 neighbour pairs"));
+  h->nnz = nnz;
+  KCHK(h->col.alloc((size_t)std::max(nnz, 1) * sizeof(int)));
+  KCHK(h->val.alloc((size_t)std::max(nnz, 1) * sizeof(double)));
+  KCHK(h->dist.alloc((size_t)std::max(nnz, 1) * sizeof(double)));
+  if (nnz > 0) {
+    hipLaunchKernelGGL((k_radius_query<1>), dim3((n + 127) / 128), dim3(128), 0, st, sorted.as<double>(),
+                       order.as<int>(), start.as<int>(), n, g, eps2, (int*)nullptr, h->rowptr.as<int>(),
+                       h->col.as<int>(), h->dist.as<double>());
+    hipLaunchKernelGGL(k_knn_row_sort, dim3(nbN), dim3(256), 0, st, h->rowptr.as<int>(), n, h->col.as<int>(),
+                       h->dist.as<double>());
+    if (sigma == 0.0) {  // mean neighbour distance (nngraph.py:248-262)
+      const int nb = 1024;
+      KCHK(partial.alloc((size_t)nb * sizeof(double)));
+      hipLaunchKernelGGL(k_knn_sum_partial, dim3(nb), dim3(256), 0, st, h->dist.as<double>(), (size_t)nnz,
+                         partial.as<double>());
+      std::vector<double> hp(nb);
+      KHIP(hipMemcpyAsync(hp.data(), partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
+      KHIP(hipStreamSynchronize(st));
+      double s = 0;
+      for (double v : hp) s += v;
+      sigma = s / (double)nnz;
+      if (!(sigma > 0)) return fail(set_err(GSPX_ERR_INVALID, "gspx_radius_build: all neighbour distances are zero"));
+    }
+    hipLaunchKernelGGL(k_radius_weights, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st,
+                       h->dist.as<double>(), (size_t)nnz, sigma, h->val.as<double>());
+  } else if (sigma == 0.0) {
+    return fail(set_err(GSPX_ERR_INVALID, "No neighbors found"));  // nngraph.py:263-264
+  }
+  h->sigma = sigma;
+  KHIP(hipGetLastError());
+  KHIP(hipStreamSynchronize(st));
+#undef KCHK
+#undef KHIP
+  h->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *out = h;
+  return GSPX_OK;
+}

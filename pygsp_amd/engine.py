@@ -656,6 +656,30 @@ def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False):
     return W, sg.value, info
 
 
+def radius_graph(coords, epsilon, sigma=None, ctx=None):
+    """Radius-graph weights on the device (gspx_radius_build): NNtype='radius' of NNGraph
+    (nngraph.py:228-287), euclidean, 1-3 dimensions.  Returns (W csr float64, sigma, info)."""
+    ctx = ctx or default_context()
+    X = np.ascontiguousarray(coords, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("coords must be (N, d)")
+    N, d = X.shape
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    _capi.check(lib.gspx_radius_build(ctx._h, N, d, _capi.ptr(X), float(epsilon), float(sigma or 0.0),
+                                      ctypes.byref(h)))
+    try:
+        nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))
+        indptr = np.empty(N + 1, dtype=np.int32)
+        indices = np.empty(nnz.value, dtype=np.int32)
+        data = np.empty(nnz.value, dtype=np.float64)
+        _capi.check(lib.gspx_knn_download_w(h, _capi.ptr(indptr), _capi.ptr(indices), _capi.ptr(data)))
+    finally:
+        lib.gspx_knn_destroy(h)
+    return sparse.csr_matrix((data, indices, indptr), shape=(N, N)), sg.value, {"build_ms": ms.value}
+
+
 def sbm_graph(z, M, seed=None, ctx=None):
     """Stochastic-block-model adjacency sampled on the device (gspx_sbm_build): every unordered pair
     of distinct vertices (r, c) is an edge with probability M[z[r], z[c]], unit weights

@@ -325,8 +325,8 @@ def sensor_weights(N, k=6, seed=None, return_coords=True):
 
 class NNGraph(Graph):
     """Nearest-neighbour graph from a point cloud (nngraphs/nngraph.py:13-313), built on the device
-    for the case the reference's own models use: NNtype='knn', euclidean distance, 'average'
-    symmetrisation, 1-3 dimensions.  Other settings raise NotImplementedError (no host fallback)."""
+    for euclidean distance, 'average' symmetrisation and 1-3 dimensions: NNtype='knn' (KD-tree query)
+    and NNtype='radius' (ball query).  Other settings raise NotImplementedError (no host fallback)."""
 
     def __init__(self, Xin, NNtype="knn", use_flann=False, center=True, rescale=True, k=10, sigma=None,
                  epsilon=0.01, plotting={}, symmetrize_type="average", dist_type="euclidean", order=0,
@@ -340,8 +340,10 @@ class NNGraph(Graph):
         if k >= N:
             raise ValueError("The number of neighbors (k={}) must be smaller "
                              "than the number of nodes ({}).".format(k, N))
-        if NNtype != "knn" or dist_type != "euclidean" or symmetrize_type != "average":
-            raise NotImplementedError("the device builder covers NNtype='knn', dist_type='euclidean', "
+        if NNtype not in ("knn", "radius"):
+            raise ValueError("Unknown NNtype {}".format(NNtype))
+        if dist_type != "euclidean" or symmetrize_type != "average":
+            raise NotImplementedError("the device builder covers dist_type='euclidean', "
                                       "symmetrize_type='average'")
         if self.center:  # nngraph.py:129-130
             Xout = self.Xin - np.kron(np.ones((N, 1)), np.mean(self.Xin, axis=0))
@@ -350,7 +352,10 @@ class NNGraph(Graph):
             scale = np.power(N, 1.0 / float(min(d, 3))) / 10.0
             Xout = Xout * (scale / bounding_radius)
         ctx = engine.default_context(int(kwargs.get("device", 0)))
-        W, self.sigma, info = engine.knn_graph(Xout, k, sigma, ctx=ctx)
+        if NNtype == "knn":
+            W, self.sigma, info = engine.knn_graph(Xout, k, sigma, ctx=ctx)
+        else:  # nngraph.py:228-287; a symmetric relation: (W + W.T) / 2 = W
+            W, self.sigma, info = engine.radius_graph(Xout, epsilon, sigma, ctx=ctx)
         self.knn_build_ms = info["build_ms"]
         super().__init__(W, plotting=plotting, coords=Xout, **kwargs)
 

@@ -200,6 +200,16 @@ def knn():
     G = graphs.Sensor(144, k=4, distributed=True, seed=7)
     out.update(csr_parts(G.W, "Wdist"))
     out["dist_coords"] = G.coords
+    # radius graphs (nngraph.py:228-287)
+    Xr = rng.uniform(0, 1, (300, 3))
+    G = graphs.NNGraph(Xr, NNtype="radius", epsilon=0.35)  # centred and rescaled: extents ~ 0.7 here
+    out["Xr"] = Xr
+    out.update(csr_parts(G.W, "Wr"))
+    out["sigma_r"] = np.float64(G.sigma)
+    X2 = rng.uniform(0, 1, (400, 2))
+    G = graphs.NNGraph(X2, NNtype="radius", epsilon=0.08, center=False, rescale=False, sigma=0.01)
+    out["X2r"] = X2
+    out.update(csr_parts(G.W, "W2r"))
     np.savez_compressed(os.path.join(OUT, "knn.npz"), **out)
 
 

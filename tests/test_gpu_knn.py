@@ -55,7 +55,7 @@ def test_golden(ctx, golden_knn):
     with pytest.raises(ValueError):
         graphs.Sensor(10, distributed=True)
     with pytest.raises(NotImplementedError):
-        graphs.NNGraph(g["X3"], NNtype="radius")
+        graphs.NNGraph(g["X3"], dist_type="manhattan")
     with pytest.raises(ValueError):
         engine.knn_graph(np.zeros((50, 4)), 3, ctx=ctx)      # 4 dimensions: not covered, says so
 
@@ -195,3 +195,29 @@ def test_sbm_sampler_distribution(ctx):
         graphs.StochasticBlockModel(100, directed=True)
     G = graphs.StochasticBlockModel(2000, k=3, seed=7)       # defaults p = 0.7, q = 0.1
     assert G.W.shape == (2000, 2000) and np.array_equal(G.z, np.sort(np.random.default_rng(7).integers(0, 3, 2000)))
+
+
+# ---------------------------------------------------------------------------------------------
+# radius graphs (NNtype='radius', nngraph.py:228-287)
+# ---------------------------------------------------------------------------------------------
+def test_radius_graphs(ctx, golden_knn):
+    g = golden_knn
+    G = graphs.NNGraph(g["Xr"], NNtype="radius", epsilon=0.35)
+    Wref = csr_from(g, "Wr")
+    assert G.W.nnz == Wref.nnz and abs(G.W - Wref).max() < 1e-14 and abs(G.sigma - float(g["sigma_r"])) < 1e-14
+    G2 = graphs.NNGraph(g["X2r"], NNtype="radius", epsilon=0.08, center=False, rescale=False, sigma=0.01)
+    assert G2.W.nnz == csr_from(g, "W2r").nnz and abs(G2.W - csr_from(g, "W2r")).max() < 1e-15
+    rng = np.random.default_rng(17)
+    for d, N, eps in ((1, 2000, 0.002), (2, 3000, 0.03), (3, 2500, 0.09), (2, 500, 0.6)):
+        X = rng.uniform(0, 1, (N, d))
+        W, sigma, _ = engine.radius_graph(X, eps, ctx=ctx)
+        Wr, sr = knn.radius_weights(X, eps)
+        assert W.nnz == Wr.nnz, (d, N)
+        np.testing.assert_array_equal(W.indices, Wr.indices)   # the same neighbour sets
+        assert abs(sigma - sr) <= 1e-13 * sr
+        assert np.max(np.abs(W.data - Wr.data) / Wr.data) < 1e-12
+        assert abs(W - W.T).max() == 0 and W.diagonal().max() == 0
+    with pytest.raises(ValueError):
+        engine.radius_graph(rng.uniform(0, 1, (50, 2)) * 100, 0.01, ctx=ctx)   # "No neighbors found"
+    with pytest.raises(ValueError):
+        graphs.NNGraph(g["Xr"], NNtype="hexagon")

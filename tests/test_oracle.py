@@ -205,3 +205,14 @@ def test_knn_golden(golden_knn):
     assert abs(knn.knn_weights(cd, 4)[0] - csr_from(g, "Wdist")).max() < 1e-16
     with pytest.raises(ValueError):
         knn.knn_weights(cd[:4], 4)
+
+
+def test_radius_golden(golden_knn):
+    g = golden_knn
+    W, sigma = knn.radius_weights(knn.preprocess(g["Xr"]), 0.35)
+    Wref = csr_from(g, "Wr")
+    assert W.nnz == Wref.nnz and abs(W - Wref).max() < 1e-16 and abs(sigma - float(g["sigma_r"])) < 1e-16
+    W2, s2 = knn.radius_weights(g["X2r"], 0.08, sigma=0.01)
+    assert s2 == 0.01 and W2.nnz == csr_from(g, "W2r").nnz and abs(W2 - csr_from(g, "W2r")).max() < 1e-16
+    with pytest.raises(ValueError):
+        knn.radius_weights(g["X2r"][:5] * 100, 0.01)  # nobody within reach: "No neighbors found"
