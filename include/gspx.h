@@ -226,11 +226,13 @@ int gspx_div_dev(gspx_graph* g, int64_t Nsig, const void* y_dev, void* z_dev, do
  *   D, NN = KDTree(X).query(X, k + 1);  sigma = mean(D[:, 1:]);  w = exp(-D^2 / sigma);
  *   W = (W + W.T) / 2
  * coords: N x d doubles on the HOST, already centred / rescaled by the caller (nngraph.py:129-137).
- * sigma == 0 selects the mean neighbour distance.  Neighbours and distances equal scipy's KD-tree
- * bit for bit (ties ordered by vertex index); a point is never its own neighbour. */
+ * sigma == 0 selects the mean neighbour distance.  metric: 0 euclidean, 1 manhattan, 2 max_dist (the
+ * reference's dist_type; 'minkowski' with order 1, 2 or inf maps onto them).  symmetrize: 0 'average',
+ * 1 'maximum' (= 'fill' for a k-NN matrix), 2 'tril', 3 'triu' (utils.symmetrize, utils.py:247-275).  Neighbours and distances
+ * equal scipy's KD-tree bit for bit (ties ordered by vertex index); a point is never its own neighbour. */
 typedef struct gspx_knn gspx_knn;
 int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, int k, double sigma,
-                   gspx_knn** out);
+                   int metric, int symmetrize, gspx_knn** out);
 int gspx_knn_destroy(gspx_knn* h);
 int gspx_knn_info(gspx_knn* h, int64_t* nnz, double* sigma, double* build_ms);
 /* symmetric W as CSR (sorted columns), float64 */
@@ -243,7 +245,7 @@ int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist);
  * the mean neighbour distance ("No neighbors found" -> GSPX_ERR_INVALID, as the reference's ValueError).
  * Result read with gspx_knn_info / gspx_knn_download_w, freed with gspx_knn_destroy. */
 int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, double epsilon,
-                      double sigma, gspx_knn** out);
+                      double sigma, int metric, gspx_knn** out);
 
 /* Stochastic block model / Erdos-Renyi graph sampled on the device: every unordered pair (r, c) of
  * distinct vertices is an edge (unit weight) independently with probability M[z_r][z_c] - the

@@ -27,27 +27,49 @@ def preprocess(Xin, center=True, rescale=True):
     return Xout
 
 
-def knn_query(Xout, k):
-    """nngraph.py:213-216 (euclidean): D, NN of shape (N, k + 1), self first."""
+P_OF = {"euclidean": 2, "manhattan": 1, "max_dist": np.inf}  # dist_translation, nngraph.py:139-145
+
+
+def knn_query(Xout, k, dist_type="euclidean"):
+    """nngraph.py:213-216: D, NN of shape (N, k + 1), self first."""
     kdt = spatial.KDTree(Xout)
-    return kdt.query(Xout, k=(k + 1), p=2)
+    return kdt.query(Xout, k=(k + 1), p=P_OF[dist_type])
 
 
-def knn_weights(Xout, k, sigma=None):
+def symmetrize(W, method="average"):
+    """utils.symmetrize for sparse input, utils.py:247-275."""
+    if method == "average":
+        return (W + W.T) / 2
+    if method == "maximum":
+        bigger = W.T > W
+        return W - W.multiply(bigger) + W.T.multiply(bigger)
+    if method == "fill":
+        A = W > 0
+        mask = (A + A.T) - A
+        W = W + mask.multiply(W.T)
+        return symmetrize(W, "average")
+    if method in ("tril", "triu"):
+        return symmetrize(getattr(sparse, method)(W), "maximum")
+    raise ValueError("Unknown symmetrization method {}.".format(method))
+
+
+def knn_weights(Xout, k, sigma=None, dist_type="euclidean", symmetrize_type="average"):
     """nngraph.py:139-226, 289-297.  Returns (W csr, sigma, NN[:, 1:], D[:, 1:])."""
     N = Xout.shape[0]
     if k >= N:
         raise ValueError("The number of neighbors (k={}) must be smaller "
                          "than the number of nodes ({}).".format(k, N))
-    D, NN = knn_query(Xout, k)
+    D, NN = knn_query(Xout, k, dist_type)
     if sigma is None:
         sigma = np.mean(D[:, 1:])
     spi = np.repeat(np.arange(N), k)
     spj = NN[:, 1:].ravel()
     spv = np.exp(-np.power(D[:, 1:].ravel(), 2) / float(sigma))
     W = sparse.csc_matrix((spv, (spi, spj)), shape=(N, N))
-    W = (W + W.T) / 2  # utils.symmetrize(W, 'average'), utils.py:247-248
-    return sparse.csr_matrix(W), float(sigma), NN[:, 1:], D[:, 1:]
+    W = symmetrize(W, symmetrize_type)  # utils.py:247-275
+    W = sparse.csr_matrix(W)
+    W.eliminate_zeros()
+    return W, float(sigma), NN[:, 1:], D[:, 1:]
 
 
 def sensor_coords(N, seed=None, distributed=False):
@@ -61,7 +83,7 @@ def sensor_coords(N, seed=None, distributed=False):
     return rng.uniform(0, 1, (N, 2))
 
 
-def radius_weights(Xout, epsilon, sigma=None):
+def radius_weights(Xout, epsilon, sigma=None, dist_type="euclidean"):
     """nngraph.py:228-297 (NNtype='radius', euclidean): ball query, distances by
     scipy.spatial.distance.minkowski, sigma = mean neighbour distance, Gaussian weights, 'average'
     symmetrisation.  Vectorised over the neighbour lists (the reference loops in Python; same values).
@@ -69,14 +91,15 @@ def radius_weights(Xout, epsilon, sigma=None):
     from scipy.spatial import distance
     N = Xout.shape[0]
     kdt = spatial.KDTree(Xout)
-    NN = [kdt.query_ball_point(p, r=epsilon, p=2) for p in Xout]
+    pn = P_OF[dist_type]
+    NN = [kdt.query_ball_point(p, r=epsilon, p=pn) for p in Xout]
     rows, cols, dists = [], [], []
     for i, nb in enumerate(NN):
         for j in nb:
             if j != i:
                 rows.append(i)
                 cols.append(j)
-                dists.append(distance.minkowski(Xout[i], Xout[j], p=2))
+                dists.append(distance.minkowski(Xout[i], Xout[j], p=pn))
     if not dists and sigma is None:
         raise ValueError("No neighbors found")
     dists = np.asarray(dists, dtype=np.float64)

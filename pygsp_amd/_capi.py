@@ -85,7 +85,7 @@ SIGNATURES = {
     "gspx_graph_download_edges": (_c.c_int, [_P, _P, _P, _P, _P, _P]),
     "gspx_grad_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
     "gspx_div_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
-    "gspx_knn_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_int, _c.c_double, _P]),
+    "gspx_knn_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_int, _c.c_double, _c.c_int, _c.c_int, _P]),
     "gspx_knn_destroy": (_c.c_int, [_P]),
     "gspx_knn_info": (_c.c_int, [_P, _P, _P, _P]),
     "gspx_knn_download_w": (_c.c_int, [_P, _P, _P, _P]),
@@ -94,7 +94,7 @@ SIGNATURES = {
     "gspx_curve_keys": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_int, _P]),
     "gspx_graph_build_gather_tiles": (_c.c_int, [_P, _P]),
     "gspx_sbm_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_uint64, _P]),
-    "gspx_radius_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_double, _c.c_double, _P]),
+    "gspx_radius_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_double, _c.c_double, _c.c_int, _P]),
     "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),
     "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,
                                         _c.c_int, _c.c_int]),

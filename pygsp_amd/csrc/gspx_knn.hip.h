@@ -21,6 +21,7 @@ struct KnnGrid {
   double h_min;
   int n[3];
   int d;
+  int metric;  // 0 euclidean, 1 manhattan, 2 max_dist (the reference's dist_type, nngraph.py:139-145)
 };
 
 __device__ __forceinline__ int knn_cell_of(const KnnGrid& g, const double* __restrict__ p, int c[3]) {
@@ -87,6 +88,17 @@ __device__ __forceinline__ double knn_sqdist(const double* q, const double* __re
   }
   return d2;
 }
+// the comparison key of a candidate: squared euclidean distance, or the manhattan / max distance itself
+// (ckdtree's MinkowskiDistP1 / Pinf: a sum of |differences| in dimension order / their maximum - exact)
+__device__ __forceinline__ double knn_key(const double* q, const double* __restrict__ p, int d, int metric) {
+  if (metric == 0) return knn_sqdist(q, p, d);
+  double s = 0;
+  for (int j = 0; j < d; ++j) {
+    const double a = fabs(q[j] - p[j]);
+    s = metric == 1 ? s + a : fmax(s, a);
+  }
+  return s;
+}
 // correctly rounded square root: the hardware-assisted sqrt is within an ulp; one exact residual
 // (fma) and a correction decide the last bit
 __device__ __forceinline__ double knn_sqrt(double x) {
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(128) void k_knn_query(const double* __restrict__ so
           for (int a = start[cid]; a < start[cid + 1]; ++a) {
             const int idx = order[a];
             if (idx == self) continue;
-            const double d2 = knn_sqdist(q, sorted + (size_t)a * g.d, g.d);
+            const double d2 = knn_key(q, sorted + (size_t)a * g.d, g.d, g.metric);
             if (d2 < bd[KMAX - 1] || (d2 == bd[KMAX - 1] && idx < bi[KMAX - 1])) {
               double cd = d2;
               int ci = idx;
@@ -170,13 +182,13 @@ __global__ __launch_bounds__(128) void k_knn_query(const double* __restrict__ so
     for (int t = 0; t < KMAX; ++t)
       if (t == k - 1) kth = bd[t];
     const double lb = (r * g.h_min + m) * (1.0 - 1e-12);
-    if (kth < 1e300 && kth <= lb * lb) break;
+    if (kth < 1e300 && kth <= (g.metric == 0 ? lb * lb : lb)) break;  // every p-norm is >= the max norm
   }
 #pragma unroll
   for (int t = 0; t < KMAX; ++t)
     if (t < k) {
       nn[(size_t)self * k + t] = bi[t];
-      dist[(size_t)self * k + t] = knn_sqrt(bd[t]);
+      dist[(size_t)self * k + t] = g.metric == 0 ? knn_sqrt(bd[t]) : bd[t];
     }
 }
 
@@ -195,9 +207,27 @@ __global__ __launch_bounds__(256) void k_knn_sum_partial(const double* __restric
 
 // w = exp(-d^2 / sigma) (nngraph.py:224-226: the distance is squared again after the sqrt); an edge
 // i -> j is mutual when i is among j's neighbours; non-mutual edges add one entry to row j
+// Symmetrisation of the directed k-NN matrix (utils.symmetrize, utils.py:247-275; the weights of a
+// mutual pair are equal):  0 'average'  (W + W^T) / 2 - a mutual pair keeps w, a one-sided edge leaves
+// w / 2 in both rows;  1 'maximum' / 'fill' - w in both rows either way;  2 'tril' / 3 'triu' - only
+// the entries below / above the diagonal count: the pair {i, j} exists iff its larger (smaller) end
+// chose the other.  Per directed edge i -> j: `self` = row i keeps (i, j), `other` = row j gets (j, i).
+__device__ __forceinline__ void knn_sym_rule(int sym, int i, int j, bool mutual, bool& self, bool& other,
+                                             double& scale) {
+  scale = 1.0;
+  if (sym <= 1) {
+    self = true;
+    other = !mutual;
+    if (sym == 0 && !mutual) scale = 0.5;
+  } else {
+    self = other = (sym == 2) ? (j < i) : (j > i);
+  }
+}
+// w = exp(-d^2 / sigma) (nngraph.py:224-226: the distance is squared again after the sqrt); an edge
+// i -> j is mutual when i is among j's neighbours; row lengths are counted here
 __global__ void k_knn_weights(const int* __restrict__ nn, const double* __restrict__ dist, int N, int k,
-                              double sigma, double* __restrict__ w, unsigned char* __restrict__ mutual,
-                              int* __restrict__ extra) {
+                              double sigma, int sym, double* __restrict__ w,
+                              unsigned char* __restrict__ mutual, int* __restrict__ len) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)N * k) return;
   const int i = (int)(e / k);
@@ -207,26 +237,31 @@ __global__ void k_knn_weights(const int* __restrict__ nn, const double* __restri
   bool mu = false;
   for (int t = 0; t < k; ++t) mu |= nn[(size_t)j * k + t] == i;
   mutual[e] = mu ? 1 : 0;
-  if (!mu) atomicAdd(&extra[j], 1);
+  bool self, other;
+  double scale;
+  knn_sym_rule(sym, i, j, mu, self, other, scale);
+  if (self) atomicAdd(&len[i], 1);
+  if (other) atomicAdd(&len[j], 1);
 }
-__global__ void k_knn_rowlen(const int* __restrict__ extra, int N, int k, int* __restrict__ len) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= N) len[i] = i < N ? k + extra[i] : 0;
-}
-// (W + W^T) / 2: a mutual pair keeps w (w/2 + w/2), a one-sided edge leaves w/2 in both rows
 __global__ void k_knn_fill(const int* __restrict__ nn, const double* __restrict__ w,
-                           const unsigned char* __restrict__ mutual, int N, int k,
+                           const unsigned char* __restrict__ mutual, int N, int k, int sym,
                            const int* __restrict__ rowptr, int* __restrict__ cursor,
                            int* __restrict__ col, double* __restrict__ val) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)N * k) return;
-  const int i = (int)(e / k), t = (int)(e - (size_t)i * k);
+  const int i = (int)(e / k);
   const int j = nn[e];
-  const double v = mutual[e] ? w[e] : w[e] * 0.5;
-  col[rowptr[i] + t] = j;
-  val[rowptr[i] + t] = v;
-  if (!mutual[e]) {
-    const int o = rowptr[j] + k + atomicAdd(&cursor[j], 1);
+  bool self, other;
+  double scale;
+  knn_sym_rule(sym, i, j, mutual[e] != 0, self, other, scale);
+  const double v = w[e] * scale;
+  if (self) {
+    const int o = rowptr[i] + atomicAdd(&cursor[i], 1);
+    col[o] = j;
+    val[o] = v;
+  }
+  if (other) {
+    const int o = rowptr[j] + atomicAdd(&cursor[j], 1);
     col[o] = i;
     val[o] = v;
   }
@@ -349,9 +384,12 @@ static void launch_knn_query(const double* sorted, const int* order, const int* 
 }
 
 extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, int k,
-                              double sigma, gspx_knn** out) {
+                              double sigma, int metric, int symmetrize, gspx_knn** out) {
   if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null ctx or output");
   *out = nullptr;
+  if (metric < 0 || metric > 2) return set_err(GSPX_ERR_INVALID, "metric: 0 euclidean, 1 manhattan, 2 max_dist");
+  if (symmetrize < 0 || symmetrize > 3)
+    return set_err(GSPX_ERR_INVALID, "symmetrize: 0 average, 1 maximum / fill, 2 tril, 3 triu");
   if (N < 2 || N >= ((int64_t)1 << 31) / 64) return set_err(GSPX_ERR_INVALID, "gspx_knn_build: bad N");
   if (d < 1 || d > 3)
     return set_err(GSPX_ERR_INVALID, "gspx_knn_build: the device k-NN search covers 1 to 3 dimensions (got %d)", d);
@@ -363,6 +401,7 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   if (!(sigma >= 0) || !std::isfinite(sigma)) return set_err(GSPX_ERR_INVALID, "sigma must be >= 0 (0: mean distance)");
   KnnGrid g{};
   g.d = d;
+  g.metric = metric;
   double hi[3] = {0, 0, 0};
   for (int j = 0; j < 3; ++j) {
     g.lo[j] = 0;
@@ -418,7 +457,7 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   } while (0)
   const int n = (int)N;
   const size_t nk = (size_t)N * k;
-  DevMem x, sorted, cell, count, start, cursor, order, w, mutual, extra, len, partial;
+  DevMem x, sorted, cell, count, start, cursor, order, w, mutual, len, partial;
   KCHK(x.alloc((size_t)N * d * sizeof(double)));
   KCHK(sorted.alloc((size_t)N * d * sizeof(double)));
   KCHK(cell.alloc((size_t)N * sizeof(int)));
@@ -469,15 +508,12 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   h->sigma = sigma;
   KCHK(w.alloc(nk * sizeof(double)));
   KCHK(mutual.alloc(nk));
-  KCHK(extra.alloc(((size_t)N + 1) * sizeof(int)));
   KCHK(len.alloc(((size_t)N + 1) * sizeof(int)));
   KCHK(h->rowptr.alloc(((size_t)N + 1) * sizeof(int)));
-  KHIP(hipMemsetAsync(extra.p, 0, ((size_t)N + 1) * sizeof(int), st));
   const unsigned nbE = (unsigned)((nk + 255) / 256);
+  KHIP(hipMemsetAsync(len.p, 0, ((size_t)N + 1) * sizeof(int), st));
   hipLaunchKernelGGL(k_knn_weights, dim3(nbE), dim3(256), 0, st, h->nn.as<int>(), h->dist.as<double>(), n, k,
-                     sigma, w.as<double>(), mutual.as<unsigned char>(), extra.as<int>());
-  hipLaunchKernelGGL(k_knn_rowlen, dim3((n + 1 + 255) / 256), dim3(256), 0, st, extra.as<int>(), n, k,
-                     len.as<int>());
+                     sigma, symmetrize, w.as<double>(), mutual.as<unsigned char>(), len.as<int>());
   KCHK(scan_exclusive(ctx, len.as<int>(), h->rowptr.as<int>(), n + 1));
   int nnz = 0;
   KHIP(hipMemcpyAsync(&nnz, h->rowptr.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -487,7 +523,7 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   KCHK(h->val.alloc((size_t)std::max(nnz, 1) * sizeof(double)));
   KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)N + 1) * sizeof(int), st));
   hipLaunchKernelGGL(k_knn_fill, dim3(nbE), dim3(256), 0, st, h->nn.as<int>(), w.as<double>(),
-                     mutual.as<unsigned char>(), n, k, h->rowptr.as<int>(), cursor.as<int>(), h->col.as<int>(),
+                     mutual.as<unsigned char>(), n, k, symmetrize, h->rowptr.as<int>(), cursor.as<int>(), h->col.as<int>(),
                      h->val.as<double>());
   hipLaunchKernelGGL(k_knn_row_sort, dim3(nbN), dim3(256), 0, st, h->rowptr.as<int>(), n, h->col.as<int>(),
                      h->val.as<double>());
@@ -784,11 +820,11 @@ __global__ __launch_bounds__(128) void k_radius_query(const double* __restrict__
         for (int a = start[cid]; a < start[cid + 1]; ++a) {
           const int idx = order[a];
           if (idx == self) continue;
-          const double d2 = knn_sqdist(q, sorted + (size_t)a * g.d, g.d);
+          const double d2 = knn_key(q, sorted + (size_t)a * g.d, g.d, g.metric);
           if (d2 <= eps2) {
             if (PASS) {
               col[o + n] = idx;
-              dist[o + n] = knn_sqrt(d2);
+              dist[o + n] = g.metric == 0 ? knn_sqrt(d2) : d2;
             }
             ++n;
           }
@@ -810,9 +846,10 @@ __global__ void k_radius_weights(const double* __restrict__ dist, size_t nnz, do
 }  // namespace gspx
 
 extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, double epsilon,
-                                 double sigma, gspx_knn** out) {
+                                 double sigma, int metric, gspx_knn** out) {
   if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null ctx or output");
   *out = nullptr;
+  if (metric < 0 || metric > 2) return set_err(GSPX_ERR_INVALID, "metric: 0 euclidean, 1 manhattan, 2 max_dist");
   if (N < 1 || N >= ((int64_t)1 << 31) / 64) return set_err(GSPX_ERR_INVALID, "gspx_radius_build: bad N");
   if (d < 1 || d > 3)
     return set_err(GSPX_ERR_INVALID, "gspx_radius_build: the device search covers 1 to 3 dimensions (got %d)", d);
@@ -821,6 +858,7 @@ extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* 
   if (!(sigma >= 0) || !std::isfinite(sigma)) return set_err(GSPX_ERR_INVALID, "sigma must be >= 0 (0: mean distance)");
   KnnGrid g{};
   g.d = d;
+  g.metric = metric;
   double hi[3] = {0, 0, 0};
   for (int j = 0; j < 3; ++j) {
     g.lo[j] = 0;
@@ -893,7 +931,7 @@ extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* 
                      cursor.as<int>(), order.as<int>());
   hipLaunchKernelGGL(k_knn_cell_sort, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st,
                      start.as<int>(), (int)ncells, order.as<int>(), x.as<double>(), d, sorted.as<double>());
-  const double eps2 = epsilon * epsilon;
+  const double eps2 = metric == 0 ? epsilon * epsilon : epsilon;  // threshold on the comparison key
   hipLaunchKernelGGL((k_radius_query<0>), dim3((n + 127) / 128), dim3(128), 0, st, sorted.as<double>(),
                      order.as<int>(), start.as<int>(), n, g, eps2, cnt.as<int>(), (const int*)nullptr,
                      (int*)nullptr, (double*)nullptr);

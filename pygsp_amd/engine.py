@@ -624,7 +624,11 @@ def _ops_methods():
 _ops_methods()
 
 
-def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False):
+METRICS = {"euclidean": 0, "manhattan": 1, "max_dist": 2}
+SYMMETRIZE = {"average": 0, "maximum": 1, "fill": 1, "tril": 2, "triu": 3}
+
+
+def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False, metric="euclidean", symmetrize="average"):
     """k-nearest-neighbour weights on the device (gspx_knn_build): the KD-tree query, Gaussian weights
     and symmetrisation of NNGraph (nngraph.py:213-226, 289-297) for euclidean distances in 1-3
     dimensions.  coords: (N, d), already centred / rescaled.  Returns (W csr float64, sigma, info)
@@ -636,7 +640,8 @@ def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False):
     N, d = X.shape
     lib = _capi.load()
     h = ctypes.c_void_p()
-    _capi.check(lib.gspx_knn_build(ctx._h, N, d, _capi.ptr(X), int(k), float(sigma or 0.0), ctypes.byref(h)))
+    _capi.check(lib.gspx_knn_build(ctx._h, N, d, _capi.ptr(X), int(k), float(sigma or 0.0), METRICS[metric],
+                                   SYMMETRIZE[symmetrize], ctypes.byref(h)))
     try:
         nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))
@@ -656,7 +661,7 @@ def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False):
     return W, sg.value, info
 
 
-def radius_graph(coords, epsilon, sigma=None, ctx=None):
+def radius_graph(coords, epsilon, sigma=None, ctx=None, metric="euclidean"):
     """Radius-graph weights on the device (gspx_radius_build): NNtype='radius' of NNGraph
     (nngraph.py:228-287), euclidean, 1-3 dimensions.  Returns (W csr float64, sigma, info)."""
     ctx = ctx or default_context()
@@ -667,7 +672,7 @@ def radius_graph(coords, epsilon, sigma=None, ctx=None):
     lib = _capi.load()
     h = ctypes.c_void_p()
     _capi.check(lib.gspx_radius_build(ctx._h, N, d, _capi.ptr(X), float(epsilon), float(sigma or 0.0),
-                                      ctypes.byref(h)))
+                                      METRICS[metric], ctypes.byref(h)))
     try:
         nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))

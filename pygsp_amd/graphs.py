@@ -325,8 +325,9 @@ def sensor_weights(N, k=6, seed=None, return_coords=True):
 
 class NNGraph(Graph):
     """Nearest-neighbour graph from a point cloud (nngraphs/nngraph.py:13-313), built on the device
-    for euclidean distance, 'average' symmetrisation and 1-3 dimensions: NNtype='knn' (KD-tree query)
-    and NNtype='radius' (ball query).  Other settings raise NotImplementedError (no host fallback)."""
+    in 1-3 dimensions: NNtype='knn' (KD-tree query) and NNtype='radius' (ball query), dist_type
+    'euclidean' / 'manhattan' / 'max_dist', every symmetrize_type of utils.symmetrize.  Other settings
+    raise NotImplementedError (no host fallback)."""
 
     def __init__(self, Xin, NNtype="knn", use_flann=False, center=True, rescale=True, k=10, sigma=None,
                  epsilon=0.01, plotting={}, symmetrize_type="average", dist_type="euclidean", order=0,
@@ -342,9 +343,15 @@ class NNGraph(Graph):
                              "than the number of nodes ({}).".format(k, N))
         if NNtype not in ("knn", "radius"):
             raise ValueError("Unknown NNtype {}".format(NNtype))
-        if dist_type != "euclidean" or symmetrize_type != "average":
-            raise NotImplementedError("the device builder covers dist_type='euclidean', "
-                                      "symmetrize_type='average'")
+        # nngraph.py:139-145: 'minkowski' is the p-norm of the given order
+        metric = {"euclidean": "euclidean", "manhattan": "manhattan", "max_dist": "max_dist"}.get(dist_type)
+        if dist_type == "minkowski":
+            metric = {1: "manhattan", 2: "euclidean", np.inf: "max_dist"}.get(order)
+        if metric is None:
+            raise NotImplementedError("the device builder covers dist_type 'euclidean', 'manhattan', 'max_dist' "
+                                      "(and 'minkowski' of order 1, 2, inf)")
+        if symmetrize_type not in engine.SYMMETRIZE:
+            raise ValueError("Unknown symmetrization method {}.".format(symmetrize_type))  # utils.py:277
         if self.center:  # nngraph.py:129-130
             Xout = self.Xin - np.kron(np.ones((N, 1)), np.mean(self.Xin, axis=0))
         if self.rescale:  # nngraph.py:132-137
@@ -353,9 +360,10 @@ class NNGraph(Graph):
             Xout = Xout * (scale / bounding_radius)
         ctx = engine.default_context(int(kwargs.get("device", 0)))
         if NNtype == "knn":
-            W, self.sigma, info = engine.knn_graph(Xout, k, sigma, ctx=ctx)
+            W, self.sigma, info = engine.knn_graph(Xout, k, sigma, ctx=ctx, metric=metric,
+                                                   symmetrize=symmetrize_type)
         else:  # nngraph.py:228-287; a symmetric relation: (W + W.T) / 2 = W
-            W, self.sigma, info = engine.radius_graph(Xout, epsilon, sigma, ctx=ctx)
+            W, self.sigma, info = engine.radius_graph(Xout, epsilon, sigma, ctx=ctx, metric=metric)
         self.knn_build_ms = info["build_ms"]
         super().__init__(W, plotting=plotting, coords=Xout, **kwargs)
 

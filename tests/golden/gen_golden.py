@@ -210,6 +210,16 @@ def knn():
     G = graphs.NNGraph(X2, NNtype="radius", epsilon=0.08, center=False, rescale=False, sigma=0.01)
     out["X2r"] = X2
     out.update(csr_parts(G.W, "W2r"))
+    # other metrics (dist_type, nngraph.py:139-145)
+    G = graphs.NNGraph(X3, k=6, dist_type="manhattan")
+    out.update(csr_parts(G.W, "W3_manhattan"))
+    G = graphs.NNGraph(X3, k=4, dist_type="max_dist", center=False, rescale=False)
+    out.update(csr_parts(G.W, "W3_maxdist"))
+    G = graphs.NNGraph(X2, NNtype="radius", epsilon=0.07, dist_type="manhattan", center=False, rescale=False)
+    out.update(csr_parts(G.W, "W2r_manhattan"))
+    for st in ("maximum", "fill", "tril", "triu"):  # utils.symmetrize, utils.py:247-275
+        G = graphs.NNGraph(X3, k=5, symmetrize_type=st)
+        out.update(csr_parts(G.W, "W3_" + st))
     np.savez_compressed(os.path.join(OUT, "knn.npz"), **out)
 
 

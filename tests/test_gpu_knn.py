@@ -55,7 +55,7 @@ def test_golden(ctx, golden_knn):
     with pytest.raises(ValueError):
         graphs.Sensor(10, distributed=True)
     with pytest.raises(NotImplementedError):
-        graphs.NNGraph(g["X3"], dist_type="manhattan")
+        graphs.NNGraph(g["X3"], dist_type="minkowski", order=2.5)
     with pytest.raises(ValueError):
         engine.knn_graph(np.zeros((50, 4)), 3, ctx=ctx)      # 4 dimensions: not covered, says so
 
@@ -221,3 +221,53 @@ def test_radius_graphs(ctx, golden_knn):
         engine.radius_graph(rng.uniform(0, 1, (50, 2)) * 100, 0.01, ctx=ctx)   # "No neighbors found"
     with pytest.raises(ValueError):
         graphs.NNGraph(g["Xr"], NNtype="hexagon")
+
+
+def test_other_metrics(ctx, golden_knn):
+    """dist_type 'manhattan' / 'max_dist' (and 'minkowski' of order 1, 2, inf), nngraph.py:139-145."""
+    g = golden_knn
+    G = graphs.NNGraph(g["X3"], k=6, dist_type="manhattan")
+    assert G.W.nnz == csr_from(g, "W3_manhattan").nnz and abs(G.W - csr_from(g, "W3_manhattan")).max() < 1e-14
+    G = graphs.NNGraph(g["X3"], k=4, dist_type="max_dist", center=False, rescale=False)
+    assert abs(G.W - csr_from(g, "W3_maxdist")).max() < 1e-14
+    G = graphs.NNGraph(g["X3"], k=4, dist_type="minkowski", order=np.inf, center=False, rescale=False)
+    assert abs(G.W - csr_from(g, "W3_maxdist")).max() < 1e-14
+    G = graphs.NNGraph(g["X2r"], NNtype="radius", epsilon=0.07, dist_type="manhattan", center=False, rescale=False)
+    assert G.W.nnz == csr_from(g, "W2r_manhattan").nnz and abs(G.W - csr_from(g, "W2r_manhattan")).max() < 1e-14
+    with pytest.raises(NotImplementedError):
+        graphs.NNGraph(g["X3"], dist_type="minkowski", order=3)
+    rng = np.random.default_rng(8)
+    for metric in ("manhattan", "max_dist"):
+        for d, N, k in ((1, 1500, 3), (2, 20000, 7), (3, 8000, 12)):
+            X = rng.uniform(0, 1, (N, d))
+            W, sg, info = engine.knn_graph(X, k, ctx=ctx, neighbors=True, metric=metric)
+            Wr, sr, NNr, Dr = knn.knn_weights(X, k, dist_type=metric)
+            np.testing.assert_array_equal(info["NN"], NNr)
+            np.testing.assert_array_equal(info["D"], Dr)
+            assert abs(sg - sr) <= 1e-13 * sr and np.max(np.abs(W.data - Wr.data) / Wr.data) < 1e-12
+        X = rng.uniform(0, 1, (2500, 2))
+        W, sg, _ = engine.radius_graph(X, 0.03, ctx=ctx, metric=metric)
+        Wr, sr = knn.radius_weights(X, 0.03, dist_type=metric)
+        assert W.nnz == Wr.nnz
+        np.testing.assert_array_equal(W.indices, Wr.indices)
+
+
+def test_symmetrize_types(ctx, golden_knn):
+    """symmetrize_type of NNGraph: utils.symmetrize 'average' / 'maximum' / 'fill' / 'tril' / 'triu'."""
+    g = golden_knn
+    for st in ("maximum", "fill", "tril", "triu"):
+        G = graphs.NNGraph(g["X3"], k=5, symmetrize_type=st)
+        Wref = csr_from(g, "W3_" + st)
+        Wref.eliminate_zeros()
+        assert G.W.nnz == Wref.nnz and abs(G.W - Wref).max() < 1e-14, st
+        assert abs(G.W - G.W.T).max() == 0
+    with pytest.raises(ValueError):
+        graphs.NNGraph(g["X3"], symmetrize_type="sum")
+    rng = np.random.default_rng(4)
+    X = rng.uniform(0, 1, (20000, 2))
+    for st in ("maximum", "tril", "triu"):
+        W, _, _ = engine.knn_graph(X, 6, ctx=ctx, symmetrize=st)
+        Wr = knn.knn_weights(X, 6, symmetrize_type=st)[0]
+        assert W.nnz == Wr.nnz, st
+        np.testing.assert_array_equal(W.indices, Wr.indices)
+        assert np.max(np.abs(W.data - Wr.data) / Wr.data) < 1e-12

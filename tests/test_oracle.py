@@ -216,3 +216,23 @@ def test_radius_golden(golden_knn):
     assert s2 == 0.01 and W2.nnz == csr_from(g, "W2r").nnz and abs(W2 - csr_from(g, "W2r")).max() < 1e-16
     with pytest.raises(ValueError):
         knn.radius_weights(g["X2r"][:5] * 100, 0.01)  # nobody within reach: "No neighbors found"
+
+
+def test_other_metrics_golden(golden_knn):
+    g = golden_knn
+    W = knn.knn_weights(knn.preprocess(g["X3"]), 6, dist_type="manhattan")[0]
+    assert abs(W - csr_from(g, "W3_manhattan")).max() < 1e-16
+    W = knn.knn_weights(g["X3"], 4, dist_type="max_dist")[0]
+    assert abs(W - csr_from(g, "W3_maxdist")).max() < 1e-16
+    W = knn.radius_weights(g["X2r"], 0.07, dist_type="manhattan")[0]
+    assert W.nnz == csr_from(g, "W2r_manhattan").nnz and abs(W - csr_from(g, "W2r_manhattan")).max() < 1e-16
+
+
+def test_symmetrize_types_golden(golden_knn):
+    g = golden_knn
+    X = knn.preprocess(g["X3"])
+    for st in ("maximum", "fill", "tril", "triu"):
+        W = knn.knn_weights(X, 5, symmetrize_type=st)[0]
+        Wref = csr_from(g, "W3_" + st)
+        Wref.eliminate_zeros()
+        assert W.nnz == Wref.nnz and abs(W - Wref).max() < 1e-16, st
