@@ -80,6 +80,12 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "tile_gather" 1 (default) recurrence steps stage the gathered panel in LDS when the graph
  *                 carries gather tiles (gspx_graph_set_gather_tiles); 0 plain gather kernels
  *   "tile_workgroups" persistent workgroups of that kernel (0 = two per CU)
+ *   "tile_dynamic"  1 = blocks are handed to the persistent workgroups by per-XCD ticket counters
+ *                   (even finish times; measured no faster: the kernel is bandwidth bound and the
+ *                   returning atomic costs more than the tail it removes); 0 (default) static walk
+ *   "tile_extra_every" E > 0: static walk in which the first-dispatched half of the workgroups takes
+ *                   an extra half-width round after every E rounds (they run ~8 % faster); 0 default
+ *   "tile_stamps"   1 = record per-workgroup entry/exit clocks (gspx_debug_tile_stamps); 0 default
  *   "newton_pair" 1 (default) Newton-form filtering runs two orders per launch when the graph
  *                 carries tiles (gspx_graph_set_tiles); 0 one order per launch
  *   "pair_workgroups" persistent workgroups of the fused pair kernel (0 = two per CU)
@@ -282,6 +288,12 @@ int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, doubl
  * eigenvalue of L lies within that distance; the reference asks ARPACK for 5e-3) or after
  * `max_iter` steps.  The caller applies the reference's 1 % margin (graph.py:920). */
 int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int* iterations);
+
+/* Profiling hook for the LDS-staged step kernel: with option "tile_stamps" = 1 every k_step_tile
+ * launch records, per persistent workgroup, the 100 MHz wall clock at entry and exit.  Downloads the
+ * last (at most 64) launches as out[launch][workgroup][2] and resets the record; out may be null to
+ * query the counts.  No reference counterpart (measurement only). */
+int gspx_debug_tile_stamps(gspx_ctx* ctx, int64_t* out, int64_t capacity, int64_t* launches, int* workgroups);
 
 /* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two
  * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */

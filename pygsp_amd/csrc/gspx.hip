@@ -106,6 +106,10 @@ struct Options {
   int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
+  int64_t tile_dynamic = 0;     // 1: blocks handed out by per-XCD ticket counters; 0: static walk
+  int64_t tile_extra_every = 0; // static walk: extra half round for the first-dispatched workgroups every E rounds
+  int64_t tile_prio = 0;        // experiment: wave priorities of the younger workgroups
+  int64_t tile_stamps = 0;      // profiling: record per-workgroup entry/exit clocks of k_step_tile launches
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
@@ -124,6 +128,10 @@ struct gspx_ctx {
   DevMem ws_r;      // accumulators
   DevMem ws_w;      // per-step flush weights / combine coefficients
   DevMem io_x, io_y;  // staging for the host-pointer entry point
+  DevMem tickets;     // k_step_tile's ticket counters (zero between launches)
+  DevMem stamps;      // tile_stamps: [64 launches][workgroups][2] wall clocks
+  int64_t stamp_launches = 0;
+  unsigned stamp_nwg = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev_pool;
   double timing[5] = {0, 0, 0, 0, 0};
@@ -281,6 +289,10 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_gather")) return &o.tile_gather;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
+  if (!strcmp(key, "tile_stamps")) return &o.tile_stamps;
+  if (!strcmp(key, "tile_dynamic")) return &o.tile_dynamic;
+  if (!strcmp(key, "tile_extra_every")) return &o.tile_extra_every;
+  if (!strcmp(key, "tile_prio")) return &o.tile_prio;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
@@ -1330,6 +1342,28 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)g->ctx->cu_count) / 8 * 8);
   if (opt.tile_workgroups > 0)
     nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
+  t.extra_every = opt.tile_dynamic ? 0 : (int)opt.tile_extra_every;  // the ticket walk has its own static prefix
+  t.prio_mode = (int)opt.tile_prio;
+  t.tickets = nullptr;
+  if (opt.tile_dynamic) {
+    gspx_ctx* c = g->ctx;
+    if (!c->tickets.p) {
+      if (c->capturing) return set_err(GSPX_ERR_INVALID, "tile tickets must exist before a graph capture");
+      CHK(c->tickets.alloc(64));
+      HIPCHK(hipMemsetAsync(c->tickets.p, 0, 64, st));
+    }
+    t.tickets = c->tickets.as<int>();
+  }
+  t.stamps = nullptr;
+  if (opt.tile_stamps) {
+    gspx_ctx* c = g->ctx;
+    if (c->stamp_nwg != nwg) {
+      CHK(c->stamps.ensure((size_t)64 * nwg * 2 * sizeof(long long)));
+      c->stamp_nwg = nwg;
+      c->stamp_launches = 0;
+    }
+    t.stamps = c->stamps.as<long long>() + (size_t)(c->stamp_launches++ % 64) * nwg * 2;
+  }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), g->gt_lds, st, t);
   return GSPX_OK;
 }
@@ -2258,6 +2292,26 @@ extern "C" int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double
 // calibration: streaming copy with the engine's own 16-byte-per-lane copy kernel (k_permute_in
 // without a permutation) - the measured HBM ceiling quoted beside every roofline fraction.
 // ------------------------------------------------------------------------------------------------
+// profiling hook: clocks recorded by the last (at most 64) k_step_tile launches under option
+// "tile_stamps"; out[launch][workgroup][2] (100 MHz wall clock at entry, exit)
+extern "C" int gspx_debug_tile_stamps(gspx_ctx* ctx, int64_t* out, int64_t capacity, int64_t* launches,
+                                      int* workgroups) {
+  if (!ctx || !launches || !workgroups) return set_err(GSPX_ERR_INVALID, "gspx_debug_tile_stamps: null argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int64_t n = std::min<int64_t>(ctx->stamp_launches, 64);
+  *launches = n;
+  *workgroups = (int)ctx->stamp_nwg;
+  const int64_t want = n * ctx->stamp_nwg * 2;
+  if (out && want > 0) {
+    if (capacity < want) return set_err(GSPX_ERR_INVALID, "gspx_debug_tile_stamps: buffer too small");
+    if (ctx->stamp_launches > 64) return set_err(GSPX_ERR_INVALID, "gspx_debug_tile_stamps: more than 64 launches recorded");
+    HIPCHK(hipMemcpy(out, ctx->stamps.p, (size_t)want * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  ctx->stamp_launches = 0;
+  return GSPX_OK;
+}
+
 extern "C" int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps) {
   if (!ctx || !gbps || bytes < 4096 || iters < 1)
     return set_err(GSPX_ERR_INVALID, "gspx_bench_copy: bad argument");

@@ -899,3 +899,31 @@ def test_graph_replay(ctx):
         bx.free()
         by.free()
     dev.destroy()
+
+
+def test_tile_block_walks(ctx):
+    """The walks of k_step_tile over the blocks (static strided, uneven static, ticket counters) visit
+    every block exactly once: results are bit-identical, also when most workgroups have no block."""
+    rng = np.random.default_rng(29)
+    for n in (3000, 150000):  # 47 blocks (fewer than workgroups) / 2344 blocks
+        W, coords = graphs.sensor_weights(n, k=8, seed=5)
+        lmax = upper_lmax(W)
+        dev = engine.DeviceGraph.from_w(W, dtype=np.float64, perm=engine.locality_order(W, coords), ctx=ctx)
+        dev.enable_gather_tiles()
+        c = orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, 11)
+        for nsig in (16, 64):
+            x = rng.standard_normal((n, nsig))
+            y0, _ = dev.cheby_filter(c, x, lmax)
+            assert rel_err(y0[0], orc.cheby_op(orc.laplacian(W), lmax, c, x)) < 1e-12
+            for opts in ({"tile_dynamic": 1}, {"tile_extra_every": 4}, {"tile_extra_every": 1},
+                         {"tile_dynamic": 1, "tile_workgroups": 64}, {"tile_extra_every": 3, "tile_workgroups": 128}):
+                try:
+                    for k, v in opts.items():
+                        ctx.set_option(k, v)
+                    for _ in range(2):  # twice: the ticket counters must be back at zero
+                        y1, _ = dev.cheby_filter(c, x, lmax)
+                        assert np.array_equal(y0, y1), (n, nsig, opts)
+                finally:
+                    for k in opts:
+                        ctx.set_option(k, 0)
+        dev.destroy()
