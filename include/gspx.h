@@ -101,6 +101,16 @@ int gspx_buf_download(gspx_buf* buf, void* host, int64_t bytes);
 int gspx_buf_ptr(gspx_buf* buf, void** device_ptr); /* raw device pointer (interop) */
 int gspx_buf_bytes(gspx_buf* buf, int64_t* bytes);
 
+/* The path's one collective, single-process form (one process driving several contexts / GPUs from
+ * threads): concatenates parts[0..n) - each a buffer of its own context - into root_out, in argument
+ * order.  Copies are queued on the source contexts' streams (behind the filtering that produced the
+ * parts) and run concurrently, peer-to-peer over xGMI, one link per source; returns when all have
+ * landed.  ctxs may be null (or ctxs[i] == the context parts[i] was allocated on).  In the
+ * one-process-per-GPU launch (bench.py --gpus N under torch.distributed.run) the same gather is RCCL
+ * send/recv through torch.distributed (pygsp_amd/dist.py).  Replaces nothing in the reference (it
+ * has no multi-device path); SURVEY section 8(b)/(e). */
+int gspx_gather(gspx_ctx** ctxs, int n, gspx_buf** parts, gspx_buf* root_out);
+
 /* ---- graphs ---------------------------------------------------------------------------- */
 /* Upload the (symmetric, canonical CSR: sorted indices, no duplicates, no explicit zeros)
  * weight matrix W and build the Laplacian ON DEVICE.  Replaces graph.py:618-628 (+ dw,

@@ -372,6 +372,57 @@ extern "C" int gspx_buf_download(gspx_buf* b, void* host, int64_t bytes) {
   return GSPX_OK;
 }
 
+// The path's one collective in single-process form: every part (a buffer on its own context /
+// device) is pushed into root_out, one after the other in argument order.  Each copy is queued on
+// the SOURCE context's stream, behind whatever produced the part, so the n copies run concurrently,
+// each over its own xGMI link (peer DMA); same-device parts are plain device copies.
+extern "C" int gspx_gather(gspx_ctx** ctxs, int n, gspx_buf** parts, gspx_buf* root_out) {
+  if (n < 0 || (n > 0 && !parts) || !root_out)
+    return set_err(GSPX_ERR_INVALID, "gspx_gather: bad argument");
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!parts[i]) return set_err(GSPX_ERR_INVALID, "gspx_gather: null part");
+    if (ctxs && ctxs[i] && ctxs[i] != parts[i]->ctx)
+      return set_err(GSPX_ERR_INVALID, "gspx_gather: part %d does not belong to context %d", i, i);
+    if (parts[i] == root_out) return set_err(GSPX_ERR_INVALID, "gspx_gather: a part aliases the output");
+    total += parts[i]->bytes;
+  }
+  if (total > root_out->bytes)
+    return set_err(GSPX_ERR_INVALID, "gspx_gather: output holds %lld bytes, parts add up to %lld",
+                   (long long)root_out->bytes, (long long)total);
+  gspx_ctx* root = root_out->ctx;
+  HIPCHK(hipSetDevice(root->device));
+  HIPCHK(hipStreamSynchronize(root->stream));  // earlier work on the output buffer
+  int64_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    gspx_ctx* src = parts[i]->ctx;
+    const size_t nb = (size_t)parts[i]->bytes;
+    if (nb) {
+      HIPCHK(hipSetDevice(src->device));
+      unsigned char* dst = (unsigned char*)root_out->mem.p + off;
+      if (src->device == root->device) {
+        HIPCHK(hipMemcpyAsync(dst, parts[i]->mem.p, nb, hipMemcpyDeviceToDevice, src->stream));
+      } else {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, src->device, root->device) == hipSuccess && can) {
+          const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            return set_err(GSPX_ERR_HIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+          (void)hipGetLastError();
+        }
+        HIPCHK(hipMemcpyPeerAsync(dst, root->device, parts[i]->mem.p, src->device, nb, src->stream));
+      }
+    }
+    off += parts[i]->bytes;
+  }
+  for (int i = 0; i < n; ++i) {
+    HIPCHK(hipSetDevice(parts[i]->ctx->device));
+    HIPCHK(hipStreamSynchronize(parts[i]->ctx->stream));
+  }
+  HIPCHK(hipSetDevice(root->device));
+  return GSPX_OK;
+}
+
 extern "C" int gspx_buf_ptr(gspx_buf* b, void** p) {
   if (!b || !p) return set_err(GSPX_ERR_INVALID, "gspx_buf_ptr: null argument");
   *p = b->mem.p;

@@ -96,7 +96,8 @@ class DeviceBuffer:
 
     def free(self):
         if getattr(self, "_h", None):
-            _capi.load().gspx_buf_free(self._h)
+            if getattr(self.ctx, "_h", None):  # a closed context took the device state with it:
+                _capi.load().gspx_buf_free(self._h)  # never hand libgspx a dangling context
             self._h = None
 
     def __del__(self):
@@ -121,6 +122,63 @@ class DeviceBuffer:
         out = np.empty(shape, dtype=dtype)
         _capi.check(_capi.load().gspx_buf_download(self._h, _capi.ptr(out), out.nbytes))
         return out
+
+
+def gather(parts, root_out):
+    """Concatenate device buffers living on (possibly) different contexts / GPUs into `root_out`:
+    the single-process form of the path's one collective (gspx_gather; peer copies over xGMI)."""
+    n = len(parts)
+    arr = (ctypes.c_void_p * max(n, 1))(*[b._h for b in parts])
+    _capi.check(_capi.load().gspx_gather(None, n, arr, root_out._h))
+    return root_out
+
+
+def filter_batch(jobs, root_ctx=None):
+    """Independent (graph, coefficients, signals, lmax) jobs, one driver thread per context: job i
+    runs on the context its DeviceGraph lives on (ctypes releases the GIL inside libgspx), the
+    outputs are gathered onto `root_ctx` and returned as one list of host arrays.
+
+    jobs: list of (DeviceGraph, c (Nf, K+1) or (K+1,), x (N, Nsig) host array, lmax).
+    This is the single-process counterpart of `bench.py --gpus N` (one process per GPU there)."""
+    import threading as _th
+    root_ctx = root_ctx or jobs[0][0].ctx
+    outs = [None] * len(jobs)
+    errs = []
+
+    def work(i):
+        try:
+            dev, c, x, lmax = jobs[i]
+            c2 = np.atleast_2d(np.asarray(c, dtype=np.float64))
+            x = np.ascontiguousarray(x, dtype=dev.dtype)
+            bx = dev.ctx.upload(x)
+            by = dev.ctx.alloc(x.nbytes * c2.shape[0])
+            dev.cheby_filter_dev(c2, bx.ptr, by.ptr, x.shape[1], lmax)
+            bx.free()
+            outs[i] = (by, (c2.shape[0],) + x.shape, dev.dtype)
+        except Exception as e:  # surfaced on the caller's thread
+            errs.append(e)
+
+    by_ctx = {}
+    for i, j in enumerate(jobs):
+        by_ctx.setdefault(id(j[0].ctx), []).append(i)
+    threads = [_th.Thread(target=lambda idx=idx: [work(i) for i in idx]) for idx in by_ctx.values()]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    total = sum(b.nbytes for b, _, _ in outs)
+    root = root_ctx.alloc(total)
+    gather([b for b, _, _ in outs], root)
+    flat = root.download((total,), np.uint8)
+    res, off = [], 0
+    for b, shape, dt in outs:
+        res.append(flat[off:off + b.nbytes].view(dt).reshape(shape))
+        off += b.nbytes
+        b.free()
+    root.free()
+    return res
 
 
 def _canonical_csr(M):
@@ -286,7 +344,8 @@ class DeviceGraph:
 
     def destroy(self):
         if getattr(self, "_h", None):
-            _capi.load().gspx_graph_destroy(self._h)
+            if getattr(self.ctx, "_h", None):
+                _capi.load().gspx_graph_destroy(self._h)
             self._h = None
 
     def __del__(self):
