@@ -68,7 +68,7 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "xcd_remap"   1 (default) contiguous row ranges per XCD, 0 plain order
  *   "synthesis"   0 (default) vector-coefficient Clenshaw: K sparse products for any Nf;
  *                 1 the reference's per-filter loop (K*Nf products)
- *   "alternate_sweep" 1 (default) odd steps sweep the rows from the end: the tail of the previous
+ *   "alternate_sweep" 1 (default) odd steps sweep the rows (k_step_tile: every XCD's block range) from the end: the tail of the previous
  *                 step's output is still in the Infinity Cache (measured -3..5 %)
  *   "waves_per_block" 4 (default), 8 or 16 waves per workgroup (kernel 1)
  *   "ws_limit_mb" / "max_batch"  workspace budget / cap on signals per batch
@@ -83,6 +83,8 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "tile_dynamic"  1 = blocks are handed to the persistent workgroups by per-XCD ticket counters
  *                   (even finish times; measured no faster: the kernel is bandwidth bound and the
  *                   returning atomic costs more than the tail it removes); 0 (default) static walk
+ *   "tile_nt"       bit 0 (default on): the step kernel loads its matrix entries non-temporal;
+ *                   bit 1: the accumulator traffic too (measured: no effect)
  *   "tile_extra_every" E > 0: static walk in which the first-dispatched half of the workgroups takes
  *                   an extra half-width round after every E rounds (they run ~8 % faster); 0 default
  *   "tile_stamps"   1 = record per-workgroup entry/exit clocks (gspx_debug_tile_stamps); 0 default

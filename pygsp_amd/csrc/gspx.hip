@@ -108,6 +108,7 @@ struct Options {
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t tile_dynamic = 0;     // 1: blocks handed out by per-XCD ticket counters; 0: static walk
   int64_t tile_extra_every = 0; // static walk: extra half round for the first-dispatched workgroups every E rounds
+  int64_t tile_nt = 1;          // bit 0: matrix entries of k_step_tile loaded non-temporal (-0.7..1 %); bit 1: accumulator too (no effect)
   int64_t tile_prio = 0;        // experiment: wave priorities of the younger workgroups
   int64_t tile_stamps = 0;      // profiling: record per-workgroup entry/exit clocks of k_step_tile launches
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
@@ -293,6 +294,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_dynamic")) return &o.tile_dynamic;
   if (!strcmp(key, "tile_extra_every")) return &o.tile_extra_every;
   if (!strcmp(key, "tile_prio")) return &o.tile_prio;
+  if (!strcmp(key, "tile_nt")) return &o.tile_nt;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
@@ -1395,6 +1397,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
     nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
   t.extra_every = opt.tile_dynamic ? 0 : (int)opt.tile_extra_every;  // the ticket walk has its own static prefix
   t.prio_mode = (int)opt.tile_prio;
+  t.nt = (int)opt.tile_nt;
   t.tickets = nullptr;
   if (opt.tile_dynamic) {
     gspx_ctx* c = g->ctx;
@@ -1529,6 +1532,7 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
       t.beta = T(0);
       t.flush = ps.flush;
       t.final = ps.final;
+      t.reverse = (opt.alternate_sweep && (k & 1)) ? 1 : 0;
       if (ps.flush) {
         t.wn = (T)ps.w[0];
         t.wc = (T)ps.w[1];
@@ -1815,6 +1819,7 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
       t.nin = nf;
       t.flush = 0;
       t.final = (k == 0) ? 1 : 0;
+      t.reverse = (opt.alternate_sweep && (k & 1)) ? 1 : 0;
       CHK(launch_step_tile<T>(g, opt, t, ld, st));
       continue;
     }
@@ -2009,6 +2014,7 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       step_params(s, t.scale, t.beta, t.gamma);
       t.flush = 0;
       t.final = (j == 0) ? 1 : 0;
+      t.reverse = (opt.alternate_sweep && (j & 1)) ? 1 : 0;
       CHK(launch_step_tile<T>(g, opt, t, ld, st));
       continue;
     }

@@ -58,6 +58,9 @@ template <typename T> struct TileArgs {
   // static walk: the first-dispatched half of the workgroups (one per CU; they win the CU's issue
   // arbitration and run ~8 % faster) take an extra half-width round after every `extra_every` rounds
   int extra_every;
+  int reverse;    // 1: every XCD walks its block range from the end (odd steps: the tail of the previous
+                  // step's panels is still in the Infinity Cache)
+  int nt;         // experiment: 1 = matrix entries loaded non-temporal (keep them out of the Infinity Cache)
   int prio_mode;  // experiment: 1 = younger workgroups raise their wave priority, 2 = alternate per block
 };
 
@@ -111,7 +114,10 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   const u32 ldb = a.ld * (u32)sizeof(T);
 
   struct Meta { int rows[ST]; int rp[RPG + 1]; };
-  auto load_hdr = [&](int k) { return *(const int4*)(a.hdr + (size_t)k * 4); };
+  // walk position -> block: the XCD's range front to back, or back to front
+  const int xflip = xlo + k1 - 1;
+  auto phys = [&](int p) { return a.reverse ? xflip - p : p; };
+  auto load_hdr = [&](int p) { return *(const int4*)(a.hdr + (size_t)phys(p) * 4); };
   auto uniform = [](int4 h) {
     int4 u;
     u.x = __builtin_amdgcn_readfirstlane(h.x); u.y = __builtin_amdgcn_readfirstlane(h.y);
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
       const int u = grp + NG * t;
       m.rows[t] = a.s1rows[h.x + (u < n1 ? u : 0)];
     }
-    int r = k * GSPX_TILE_BR + grp * RPG;
+    int r = phys(k) * GSPX_TILE_BR + grp * RPG;
 #pragma unroll
     for (int t = 0; t < RPG + 1; ++t) m.rp[t] = a.rowptr[(r + t) <= a.N ? (r + t) : a.N];
     return m;
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     const bool fast = n1 >= 0;
     T* const mval = (T*)(tile + (fast ? n1 : 0) * LG);
     u16* const midx = (u16*)(mval + ent);
-    const int row0 = k * GSPX_TILE_BR + grp * RPG;
+    const int row0 = phys(k) * GSPX_TILE_BR + grp * RPG;
     int rs[RPG + 1];
 #pragma unroll
     for (int t = 0; t < RPG + 1; ++t) rs[t] = M.rp[t] & ~3;
@@ -184,7 +190,9 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     for (int t = 0; t < RPG; ++t) {
       const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
       ov[t] = VT<T, VEC>::bload(rold, a.gamma != T(0) ? off : POISON);
-      ra[t] = VT<T, VEC>::bload(rra, a.flush == 2 ? off : POISON);
+      const u32 ro = a.flush == 2 ? off : POISON;
+      if (a.nt & 2) ra[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rra, ro, 0, 2));
+      else ra[t] = VT<T, VEC>::bload(rra, ro);
     }
     V ins[RPG];
 #pragma unroll
@@ -204,8 +212,15 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     u32x4 ev = 0, ei = 0;
     const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent * 2 + 15) >> 4;
     if (first && fast) {
-      ev = __builtin_amdgcn_raw_buffer_load_b128(rv, tid < nv16 ? (u32)rp0 * (u32)sizeof(T) + tid * 16u : POISON, 0, 0);
-      ei = __builtin_amdgcn_raw_buffer_load_b128(ri, tid < ni16 ? (u32)rp0 * 2u + tid * 16u : POISON, 0, 0);
+      const u32 vo = tid < nv16 ? (u32)rp0 * (u32)sizeof(T) + tid * 16u : POISON;
+      const u32 io = tid < ni16 ? (u32)rp0 * 2u + tid * 16u : POISON;
+      if (a.nt & 1) {
+        ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 2);
+        ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 2);
+      } else {
+        ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0);
+        ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 0);
+      }
     }
     int4 Hv = Hn;
     if (last) {  // the next block's row lists, the header after that
@@ -294,7 +309,8 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
             const size_t orow = a.perm ? (size_t)a.perm[row] : (size_t)row;
             *(V*)(a.y + orow * a.ldy + col0) = res;
           } else {
-            *(V*)(a.racc + (size_t)row * a.ld + col0) = res;
+            if (a.nt & 2) __builtin_nontemporal_store(res, (V*)(a.racc + (size_t)row * a.ld + col0));
+            else *(V*)(a.racc + (size_t)row * a.ld + col0) = res;
           }
         }
       }
