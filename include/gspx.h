@@ -83,8 +83,10 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "tile_dynamic"  1 = blocks are handed to the persistent workgroups by per-XCD ticket counters
  *                   (even finish times; measured no faster: the kernel is bandwidth bound and the
  *                   returning atomic costs more than the tail it removes); 0 (default) static walk
- *   "tile_nt"       bit 0 (default on): the step kernel loads its matrix entries non-temporal;
- *                   bit 1: the accumulator traffic too (measured: no effect)
+ *   "tile_nt"       non-temporal accesses of the step kernel: bit 0 matrix entries, bit 2 T_{k-2}
+ *                   rows (each about -1 % when the panel exceeds the 256 MB Infinity Cache, +5 % when it
+ *                   fits); bit 1 accumulator, bit 3 T_k stores (no effect).  -1 (default): 5 for
+ *                   panels of 192 MiB and more, else 0
  *   "tile_extra_every" E > 0: static walk in which the first-dispatched half of the workgroups takes
  *                   an extra half-width round after every E rounds (they run ~8 % faster); 0 default
  *   "tile_stamps"   1 = record per-workgroup entry/exit clocks (gspx_debug_tile_stamps); 0 default

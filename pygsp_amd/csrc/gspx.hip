@@ -108,7 +108,9 @@ struct Options {
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t tile_dynamic = 0;     // 1: blocks handed out by per-XCD ticket counters; 0: static walk
   int64_t tile_extra_every = 0; // static walk: extra half round for the first-dispatched workgroups every E rounds
-  int64_t tile_nt = 1;          // bit 0: matrix entries of k_step_tile loaded non-temporal (-0.7..1 %); bit 1: accumulator too (no effect)
+  int64_t tile_nt = -1;         // k_step_tile non-temporal accesses: bit 0 matrix entries, bit 2 T_{k-2} loads (each
+                                // -1 % on panels beyond the 256 MB Infinity Cache, +5 % each on panels that fit in
+                                // it); bit 1 accumulator, bit 3 T_k stores (no effect).  -1: 5 for panels >= 192 MiB
   int64_t tile_prio = 0;        // experiment: wave priorities of the younger workgroups
   int64_t tile_stamps = 0;      // profiling: record per-workgroup entry/exit clocks of k_step_tile launches
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
@@ -1397,7 +1399,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
     nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
   t.extra_every = opt.tile_dynamic ? 0 : (int)opt.tile_extra_every;  // the ticket walk has its own static prefix
   t.prio_mode = (int)opt.tile_prio;
-  t.nt = (int)opt.tile_nt;
+  t.nt = opt.tile_nt >= 0 ? (int)opt.tile_nt : ((size_t)g->N * ld * sizeof(T) >= ((size_t)192 << 20) ? 5 : 0);
   t.tickets = nullptr;
   if (opt.tile_dynamic) {
     gspx_ctx* c = g->ctx;

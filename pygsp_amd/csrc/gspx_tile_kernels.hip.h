@@ -189,7 +189,9 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
 #pragma unroll
     for (int t = 0; t < RPG; ++t) {
       const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
-      ov[t] = VT<T, VEC>::bload(rold, a.gamma != T(0) ? off : POISON);
+      const u32 oo = a.gamma != T(0) ? off : POISON;
+      if (a.nt & 4) ov[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rold, oo, 0, 2));
+      else ov[t] = VT<T, VEC>::bload(rold, oo);
       const u32 ro = a.flush == 2 ? off : POISON;
       if (a.nt & 2) ra[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rra, ro, 0, 2));
       else ra[t] = VT<T, VEC>::bload(rra, ro);
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
           *(V*)(a.y + orow * a.ldy + col0) = nv[t];
           continue;
         }
-        *(V*)(a.out + (size_t)row * a.ld + col0) = nv[t];
+        if (a.nt & 8) __builtin_nontemporal_store(nv[t], (V*)(a.out + (size_t)row * a.ld + col0));
+        else *(V*)(a.out + (size_t)row * a.ld + col0) = nv[t];
         if (a.flush) {
           V res = a.wn * nv[t] + a.wc * cv[t] + a.wo * ov[t];
           if (a.flush == 2) res += ra[t];
