@@ -83,6 +83,9 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "tile_dynamic"  1 = blocks are handed to the persistent workgroups by per-XCD ticket counters
  *                   (even finish times; measured no faster: the kernel is bandwidth bound and the
  *                   returning atomic costs more than the tail it removes); 0 (default) static walk
+ *   "fuse_input"    1 (default): with gather tiles on every block, steps 1 and 2 of a single-filter
+ *                   call read the caller's panel directly (gather lists mapped through the vertex
+ *                   order) instead of copying it into the internal order first; 0 = always copy
  *   "tile_nt"       non-temporal accesses of the step kernel: bit 0 matrix entries, bit 2 T_{k-2}
  *                   rows (each about -1 % when the panel exceeds the 256 MB Infinity Cache, +5 % when it
  *                   fits); bit 1 accumulator, bit 3 T_k stores (no effect).  -1 (default): 5 for

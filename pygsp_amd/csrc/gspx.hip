@@ -108,6 +108,7 @@ struct Options {
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t tile_dynamic = 0;     // 1: blocks handed out by per-XCD ticket counters; 0: static walk
   int64_t tile_extra_every = 0; // static walk: extra half round for the first-dispatched workgroups every E rounds
+  int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
   int64_t tile_nt = -1;         // k_step_tile non-temporal accesses: bit 0 matrix entries, bit 2 T_{k-2} loads (each
                                 // -1 % on panels beyond the 256 MB Infinity Cache, +5 % each on panels that fit in
                                 // it); bit 1 accumulator, bit 3 T_k stores (no effect).  -1: 5 for panels >= 192 MiB
@@ -188,6 +189,8 @@ struct gspx_graph {
   double build_ms = 0.0;
   // one-level row tiles of the LDS-staged recurrence step (optional; gspx_tile_kernels.hip.h)
   DevMem gt_hdr, gt_s1rows, gt_lidx;
+  DevMem gt_s1nat;   // gt_s1rows mapped through perm: the same lists as rows of the caller's (unpermuted) panel
+  int gt_ns1 = 0;
   int gt_rows = 0, gt_nb = 0, gt_slow = 0;
   size_t gt_lds = 0;
   // differential operator (built on first use; gspx_ops.hip.h)
@@ -297,6 +300,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_extra_every")) return &o.tile_extra_every;
   if (!strcmp(key, "tile_prio")) return &o.tile_prio;
   if (!strcmp(key, "tile_nt")) return &o.tile_nt;
+  if (!strcmp(key, "fuse_input")) return &o.fuse_input;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
@@ -936,6 +940,8 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
   HIPCHK(hipMemcpy(g->gt_lidx.p, lidx, (size_t)g->nnz_int * 2, hipMemcpyHostToDevice));
   g->gt_rows = block_rows;
   g->gt_nb = nb;
+  g->gt_ns1 = n_s1;
+  g->gt_s1nat.release();
   g->gt_slow = slow;
   g->gt_lds = lds;
   if (stats) {
@@ -985,6 +991,8 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   HIPCHK(hipStreamSynchronize(st));
   g->gt_rows = GSPX_TILE_BR;
   g->gt_nb = nb;
+  g->gt_ns1 = n_s1;
+  g->gt_s1nat.release();
   g->gt_slow = slow;
   g->gt_lds = lds;
   if (stats) {
@@ -1346,6 +1354,20 @@ static hipEvent_t pool_event(gspx_ctx* ctx, size_t& i_ref) {
 // x/y column c0.  x: [N][ldx] (+c0), y: [nf][N][ldy] (+c0).
 // LDS-staged gather step (gspx_tile_kernels.hip.h): usable when the graph carries gather tiles and
 // every panel the kernel touches is made of 16-byte lane pieces
+// the gather lists as rows of an unpermuted panel: nat[i] = perm[s1rows[i]]
+__global__ void k_s1nat(const int* __restrict__ s1, const int* __restrict__ perm, int n, int* __restrict__ nat) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) nat[i] = perm[s1[i]];
+}
+static int ensure_s1nat(gspx_graph* g, hipStream_t st) {
+  if (g->gt_s1nat.p || !g->has_perm) return GSPX_OK;
+  CHK(g->gt_s1nat.alloc((size_t)std::max(g->gt_ns1, 1) * 4 + 64));
+  if (g->gt_ns1 > 0)
+    hipLaunchKernelGGL(k_s1nat, dim3((g->gt_ns1 + 255) / 256), dim3(256), 0, st, g->gt_s1rows.as<int>(),
+                       g->perm.as<int>(), g->gt_ns1, g->gt_s1nat.as<int>());
+  return GSPX_OK;
+}
+
 template <typename T>
 static bool tile_usable(const gspx_graph* g, const Options& opt, unsigned ld, const T* y, unsigned ldy) {
   constexpr int TVEC = 16 / (int)sizeof(T);
@@ -1368,6 +1390,11 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
                                     : ncol == 1 ? k_step_tile<T, 1>
                                     : ncol == 2 ? k_step_tile<T, 2>
                                                 : k_step_tile<T, 0>;
+  if (t.old_rows)  // T_{k-2} read from the caller's unpermuted panel (step 2 of a fused-input filter)
+    kern = narrow      ? k_step_tile<T, 1, 8, true>
+           : ncol == 1 ? k_step_tile<T, 1, 16, true>
+           : ncol == 2 ? k_step_tile<T, 2, 16, true>
+                       : k_step_tile<T, 0, 16, true>;
   {  // once per kernel build and device (a driver call per launch would cost microseconds each)
     static std::map<std::pair<const void*, int>, size_t> lds_set;
     static std::mutex lds_mu;
@@ -1383,7 +1410,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   t.col = g->rcol.as<int>();
   t.val = vals ? vals : g->fval.as<T>();  // any values array on the internal pattern
   t.hdr = g->gt_hdr.as<int>();
-  t.s1rows = g->gt_s1rows.as<int>();
+  if (!t.s1rows) t.s1rows = g->gt_s1rows.as<int>();  // (the caller may pass the lists in its panel's row order)
   t.lidx = g->gt_lidx.as<unsigned short>();
   t.N = (int)g->N;
   t.ld = ld;
@@ -1479,10 +1506,27 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
     if (!e0 || !e1 || !e2 || !e3) return set_err(GSPX_ERR_HIP, "hipEventCreate failed");
     HIPCHK(hipEventRecord(e0, st));
   }
-  // permute-in vector width: x rows must be aligned too
-  int pvec = shape.vec;
-  while (pvec > 1 && ((ldx % pvec) != 0 || (((uintptr_t)x / sizeof(T)) % pvec) != 0)) pvec /= 2;
-  launch_permute_in<T>(x, ldx, slots, ld, N, perm, pvec, st);
+  // LDS-staged gather: one filter with the fused flush
+  // (or a filterbank's deferred combine, whose steps are plain recurrence steps into kept slots)
+  const bool tile_ok = (deferred || nf == 1) && tile_usable<T>(g, opt, ld, y, ldy);
+  // Fused input: step 1 gathers straight from the caller's panel (the tile lists mapped through the
+  // vertex order) and step 2 reads T_0 from it, so the copy into the internal order never happens.
+  // Needs every block on the LDS path, the panel in the internal row pitch, and x not aliasing y
+  // (the copy used to make in-place calls safe).
+  const unsigned char* xb = (const unsigned char*)x;
+  const unsigned char* yb = (const unsigned char*)y;
+  const size_t xbytes = (size_t)N * ldx * sizeof(T), ybytes = (size_t)nf * N * ldy * sizeof(T);
+  const bool fuse_in = tile_ok && !deferred && opt.fuse_input && g->gt_slow == 0 && ldx == ld &&
+                       ((uintptr_t)x % 16) == 0 && (xb + xbytes <= yb || yb + ybytes <= xb) &&
+                       (!g->has_perm || (g->gt_ns1 > 0 && (!cap || g->gt_s1nat.p)));
+  if (fuse_in) {
+    CHK(ensure_s1nat(g, st));
+  } else {
+    // permute-in vector width: x rows must be aligned too
+    int pvec = shape.vec;
+    while (pvec > 1 && ((ldx % pvec) != 0 || (((uintptr_t)x / sizeof(T)) % pvec) != 0)) pvec /= 2;
+    launch_permute_in<T>(x, ldx, slots, ld, N, perm, pvec, st);
+  }
   if (!cap) HIPCHK(hipEventRecord(e1, st));
 
   const int pad_self = (shape.kernel == 3 || shape.kernel == 4) ? 1 : 0;
@@ -1509,9 +1553,6 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   a.y = y;
   a.ldy = ldy;
   a.perm = perm;
-  // LDS-staged gather: one filter with the fused flush
-  // (or a filterbank's deferred combine, whose steps are plain recurrence steps into kept slots)
-  const bool tile_ok = (deferred || nf == 1) && tile_usable<T>(g, opt, ld, y, ldy);
   for (int k = 1; k <= K; ++k) {
     const PlanStep& ps = plan[(size_t)k - 1];
     if (tile_ok) {
@@ -1524,6 +1565,14 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
         t.cur = slots + (size_t)((k - 1) & 1) * U;
         t.old = ps.gamma == 0.0 ? t.cur : slots + (size_t)(k & 1) * U;
         t.out = slots + (size_t)(k & 1) * U;
+        if (fuse_in && k == 1) {  // T_0 is the caller's panel
+          t.cur = x;
+          t.old = x;
+          t.s1rows = g->has_perm ? g->gt_s1nat.as<int>() : nullptr;
+        } else if (fuse_in && k == 2) {
+          t.old = x;
+          t.old_rows = perm;  // null without an internal order: plain rows
+        }
       }
       t.racc = racc;
       t.y = y;

@@ -26,11 +26,12 @@ static int prepare_coff(gspx_graph* g, const Shape& shape, unsigned ld, hipStrea
 // with y != null the result goes to y in the caller's order instead (rows y[perm[i]])
 template <typename T>
 static int spmm_internal(gspx_graph* g, const T* vals, T scale, T beta, const T* cur, T* out,
-                         unsigned ld, T* y, unsigned ldy) {
+                         unsigned ld, T* y, unsigned ldy, const int* s1rows = nullptr) {
   gspx_ctx* ctx = g->ctx;
   Options opt = ctx->opt;
   if (tile_usable<T>(g, opt, ld, y ? y : out, y ? ldy : ld)) {  // LDS-staged gather, as the filter steps
     TileArgs<T> t{};
+    t.s1rows = s1rows;  // non-null: cur is a panel in the caller's vertex order (lists mapped through perm)
     t.cur = cur;
     t.old = cur;
     t.out = out;
@@ -108,6 +109,24 @@ static int lap_apply_t(gspx_graph* g, int64_t Nsig, const T* x, T* y, double* ms
   if (max_ld < 1) return set_err(GSPX_ERR_INVALID, "graph too large: one signal column exceeds 2 GiB");
   const int* perm = g->has_perm ? g->perm.as<int>() : nullptr;
   HIPCHK(hipEventRecord(ctx->ev[0], st));
+  // one batch, every block on the LDS path: the step kernel gathers straight from x (the tile lists mapped
+  // through the vertex order) and writes y in the caller's order - one launch, no copies
+  const unsigned char *xb = (const unsigned char*)x, *yb = (const unsigned char*)y;
+  const size_t pb = (size_t)N * Nsig * sizeof(T);
+  if (Nsig <= max_ld && ctx->opt.fuse_input && g->gt_slow == 0 && ((uintptr_t)x % 16) == 0 &&
+      (xb + pb <= yb || yb + pb <= xb) && (!g->has_perm || g->gt_ns1 > 0) &&
+      tile_usable<T>(g, ctx->opt, (unsigned)Nsig, y, (unsigned)Nsig)) {
+    CHK(ensure_s1nat(g, st));
+    CHK(spmm_internal<T>(g, g->rval.as<T>(), T(1), T(0), x, nullptr, (unsigned)Nsig, y, (unsigned)Nsig,
+                         g->has_perm ? g->gt_s1nat.as<int>() : nullptr));
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    float f1 = 0;
+    HIPCHK(hipEventElapsedTime(&f1, ctx->ev[0], ctx->ev[1]));
+    if (ms) *ms = f1;
+    return GSPX_OK;
+  }
   for (int64_t c0 = 0; c0 < Nsig; c0 += max_ld) {
     const unsigned ld = (unsigned)std::min<int64_t>(max_ld, Nsig - c0);
     CHK(ctx->ws_t.ensure((size_t)N * ld * sizeof(T) + 256));

@@ -33,6 +33,7 @@ template <typename T> struct TileArgs {
   const u16* lidx;     // [nnz_int] position of each entry's column in its block's S1 (pads: 0)
   const T* cur;
   const T* old;
+  const int* old_rows;  // OLDNAT builds: row of `old` holding T_{k-2} of internal row r (the caller's x, unpermuted)
   T* out;
   T* racc;
   T* y;
@@ -69,7 +70,9 @@ constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group
 
 // LG = lanes per row group: 16 (256-byte column chunks; 32 groups x 2 rows) or 8 (128-byte chunks for
 // narrow panels; 64 groups x 1 row).  NCOL = 1, 2: that many column chunks per row; 0: a.ncol chunks
-template <typename T, int NCOL, int LG = 16>
+// OLDNAT: T_{k-2} rows are read through a.old_rows (step 2 of a filter whose input panel was not
+// copied into the internal order first)
+template <typename T, int NCOL, int LG = 16, bool OLDNAT = false>
 __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   constexpr int VEC = 16 / (int)sizeof(T);
   typedef typename VT<T, VEC>::t V;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   const rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)a.lidx, 0, a.lidx_bytes, 0x00020000);
   const u32 ldb = a.ld * (u32)sizeof(T);
 
-  struct Meta { int rows[ST]; int rp[RPG + 1]; };
+  struct Meta { int rows[ST]; int rp[RPG + 1]; int orow[OLDNAT ? RPG : 1]; };
   // walk position -> block: the XCD's range front to back, or back to front
   const int xflip = xlo + k1 - 1;
   auto phys = [&](int p) { return a.reverse ? xflip - p : p; };
@@ -135,6 +138,10 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     int r = phys(k) * GSPX_TILE_BR + grp * RPG;
 #pragma unroll
     for (int t = 0; t < RPG + 1; ++t) m.rp[t] = a.rowptr[(r + t) <= a.N ? (r + t) : a.N];
+    if constexpr (OLDNAT) {
+#pragma unroll
+      for (int t = 0; t < RPG; ++t) m.orow[t] = a.old_rows[(r + t) < a.N ? (r + t) : a.N - 1];
+    }
     return m;
   };
   V* const tile = (V*)gspx_smem;
@@ -189,7 +196,8 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
 #pragma unroll
     for (int t = 0; t < RPG; ++t) {
       const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
-      const u32 oo = a.gamma != T(0) ? off : POISON;
+      u32 oo = a.gamma != T(0) ? off : POISON;
+      if constexpr (OLDNAT) oo = (row0 + t < a.N && a.gamma != T(0)) ? (u32)M.orow[t] * ldb + cb : POISON;
       if (a.nt & 4) ov[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rold, oo, 0, 2));
       else ov[t] = VT<T, VEC>::bload(rold, oo);
       const u32 ro = a.flush == 2 ? off : POISON;

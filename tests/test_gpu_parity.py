@@ -966,3 +966,38 @@ def test_gather_and_batch_across_contexts(ctx):
             buf.free()
     finally:
         ctx2.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_input_panel(ctx, dtype):
+    """Steps 1-2 reading the caller's panel in place of the permute-in copy: identical results, also for
+    orders 1 and 2, in-place calls (x aliasing y: the copy path) and graphs without an internal order."""
+    rng = np.random.default_rng(37)
+    W, coords = graphs.sensor_weights(30000, k=8, seed=3)
+    lmax = upper_lmax(W)
+    for perm in (engine.locality_order(W, coords), None):
+        dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+        st = dev.enable_gather_tiles()
+        for nsig in (8, 64, 96):
+            x = rng.standard_normal((W.shape[0], nsig)).astype(dtype)
+            bx, by0, by1 = ctx.upload(x), ctx.alloc(x.nbytes), ctx.alloc(x.nbytes)
+            for order in (1, 2, 3, 30):
+                c = np.atleast_2d(orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, order))
+                ctx.set_option("fuse_input", 0)
+                dev.cheby_filter_dev(c, bx.ptr, by0.ptr, nsig, lmax)
+                ctx.set_option("fuse_input", 1)
+                dev.cheby_filter_dev(c, bx.ptr, by1.ptr, nsig, lmax)
+                y0, y1 = by0.download(x.shape, dtype), by1.download(x.shape, dtype)
+                if st["slow_blocks"] == 0:
+                    assert np.array_equal(y0, y1), (nsig, order)
+                ref = orc.cheby_op(orc.laplacian(W), lmax, c[0], x.astype(np.float64))
+                assert rel_err(y1, ref) < TOL[np.dtype(dtype)] * 10
+                assert np.array_equal(bx.download(x.shape, dtype), x)  # the input panel is never written
+                if order == 3:  # in place
+                    bz = ctx.upload(x)
+                    dev.cheby_filter_dev(c, bz.ptr, bz.ptr, nsig, lmax)
+                    assert np.array_equal(bz.download(x.shape, dtype), y0)
+                    bz.free()
+            for b in (bx, by0, by1):
+                b.free()
+        dev.destroy()

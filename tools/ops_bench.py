@@ -34,7 +34,7 @@ for dtype in (np.float64, np.float32):
     ms = min(dev.laplacian_apply_dev(bx.ptr, by.ptr, nsig) for _ in range(5))
     csr = dev.nnz_l * (elt + 4) + 4 * (N + 1)
     res["laplacian_apply"] = {"ms": ms, "alg_GBps": (csr + 2 * X.nbytes) / ms / 1e6,
-                              "note": "includes the permute-in pass of x (read+write of one more panel)"}
+                              "note": "one launch: the step kernel gathers from x in the caller's order and writes y in it (no permute passes)"}
     y = by.download((N, nsig), dtype)
     t0 = time.perf_counter(); ref = L.dot(X[:, :8].astype(np.float64)); t_cpu = time.perf_counter() - t0
     res["laplacian_apply"]["scipy_1core_ms_per_8cols"] = t_cpu * 1e3
