@@ -93,6 +93,8 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "tile_extra_every" E > 0: static walk in which the first-dispatched half of the workgroups takes
  *                   an extra half-width round after every E rounds (they run ~8 % faster); 0 default
  *   "tile_stamps"   1 = record per-workgroup entry/exit clocks (gspx_debug_tile_stamps); 0 default
+ *   "tile_prio"     experiment: 1 = the second-dispatched workgroups raise their wave priority, 2 = the
+ *                   two workgroups of a CU alternate it per block (measured: no faster); 0 default
  *   "newton_pair" 1 (default) Newton-form filtering runs two orders per launch when the graph
  *                 carries tiles (gspx_graph_set_tiles); 0 one order per launch
  *   "pair_workgroups" persistent workgroups of the fused pair kernel (0 = two per CU)
