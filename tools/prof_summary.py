@@ -20,6 +20,25 @@ for f in find("stats/**/*kernel_stats.csv"):
         print("{:70.70s} calls={:>6} total_ns={:>12} avg_ns={:>10} pct={}".format(
             r.get("Name", ""), r.get("Calls", ""), r.get("TotalDurationNs", ""),
             r.get("AverageNs", ""), r.get("Percentage", "")))
+# rocprofv3's average is over every launch of the run, warm-up included; bench.py times the launches after
+# its warm-up with HIP events.  Same launches, both clocks:
+import json as _json
+for f in find("stats/**/*kernel_trace.csv"):
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+               for r in csv.DictReader(open(f)) if "k_step" in r.get("Kernel_Name", ""))
+    try:
+        b = _json.loads(open(os.path.join(out, "stats_bench.json")).read().strip().splitlines()[-1])
+        timed = int(b["roofline"]["launches_timed"])
+        ev = float(b["roofline"]["avg_launch_ms"]) * 1e3
+    except Exception:
+        continue
+    if len(d) >= timed > 0:
+        tail = [x[1] for x in d[-timed:]]
+        head = [x[1] for x in d[:-timed]]
+        print("step-kernel launches: {} in the trace; the last {} (bench.py's timed region): rocprofv3 avg {:.1f} us, "
+              "bench.py HIP events of the same launches {:.1f} us; the {} warm-up launches before them avg {:.1f} us".format(
+                  len(d), timed, sum(tail) / len(tail) / 1e3, ev, len(head),
+                  (sum(head) / len(head) / 1e3) if head else 0.0))
 print()
 print("== PMC (per kernel: mean counter value per dispatch) ==")
 for f in find("pmc_*/**/*counter_collection.csv"):
