@@ -83,6 +83,8 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "tile_dynamic"  1 = blocks are handed to the persistent workgroups by per-XCD ticket counters
  *                   (even finish times; measured no faster: the kernel is bandwidth bound and the
  *                   returning atomic costs more than the tail it removes); 0 (default) static walk
+ *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order (16-byte lanes,
+ *                   neighbour rows from L2); 0 = the edge-order kernels
  *   "fuse_input"    1 (default): with gather tiles on every block, steps 1 and 2 of a single-filter
  *                   call read the caller's panel directly (gather lists mapped through the vertex
  *                   order) instead of copying it into the internal order first; 0 = always copy

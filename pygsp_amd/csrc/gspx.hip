@@ -108,6 +108,7 @@ struct Options {
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t tile_dynamic = 0;     // 1: blocks handed out by per-XCD ticket counters; 0: static walk
   int64_t tile_extra_every = 0; // static walk: extra half round for the first-dispatched workgroups every E rounds
+  int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
   int64_t tile_nt = -1;         // k_step_tile non-temporal accesses: bit 0 matrix entries, bit 2 T_{k-2} loads (each
                                 // -1 % on panels beyond the 256 MB Infinity Cache, +5 % each on panels that fit in
@@ -301,6 +302,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_prio")) return &o.tile_prio;
   if (!strcmp(key, "tile_nt")) return &o.tile_nt;
   if (!strcmp(key, "fuse_input")) return &o.fuse_input;
+  if (!strcmp(key, "edge_vertex_walk")) return &o.edge_vertex_walk;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;

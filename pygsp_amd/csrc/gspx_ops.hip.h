@@ -410,7 +410,24 @@ static int grad_div_t(gspx_graph* g, bool is_div, int64_t Nsig, const T* in, T* 
   while (cw < 64 && cw < Nsig) cw <<= 1;
   const unsigned nb = (unsigned)std::min<size_t>((rows + (256 / cw) - 1) / (256 / cw), 1 << 20);
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  if (is_div)
+  constexpr int TV = 16 / (int)sizeof(T);
+  if ((Nsig % TV) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && g->N >= 8 &&
+      ctx->opt.edge_vertex_walk) {
+    // vertex walk in the internal order (see k_grad_v): lane groups of 16-byte lanes, one per vertex
+    int gs = 1;
+    while (gs < 64 && gs < Nsig / TV) gs <<= 1;
+    const int per_xcd = (int)((g->N + 7) / 8), gpb = 256 / gs;
+    const unsigned nbx = (unsigned)std::min<int64_t>(((int64_t)per_xcd + gpb - 1) / gpb, 8192);
+    const int* perm = g->has_perm ? g->perm.as<int>() : nullptr;
+    if (is_div)
+      hipLaunchKernelGGL((k_div_v<T, TV>), dim3(nbx * 8), dim3(256), 0, st, perm, g->e_off.as<int>(),
+                         g->e_toff.as<int>(), g->e_tedge.as<int>(), g->e_cs.as<T>(), g->e_ct.as<T>(), in, out,
+                         (int)g->N, (int)Nsig, gs, per_xcd);
+    else
+      hipLaunchKernelGGL((k_grad_v<T, TV>), dim3(nbx * 8), dim3(256), 0, st, perm, g->e_off.as<int>(),
+                         g->e_dst.as<int>(), g->e_cs.as<T>(), g->e_ct.as<T>(), in, out, (int)g->N, (int)Nsig, gs,
+                         per_xcd);
+  } else if (is_div)
     hipLaunchKernelGGL((k_div<T>), dim3(nb), dim3(256), 0, st, g->e_off.as<int>(), g->e_toff.as<int>(),
                        g->e_tedge.as<int>(), g->e_cs.as<T>(), g->e_ct.as<T>(), in, out, (int)g->N,
                        (int)Nsig, cw);

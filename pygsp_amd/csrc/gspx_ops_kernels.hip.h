@@ -303,4 +303,76 @@ __global__ __launch_bounds__(256) void k_div(const int* __restrict__ eoff, const
   }
 }
 
+// The same two operators walking the VERTICES in the engine's internal (space-filling-curve) order, one
+// lane group per vertex, 16-byte lanes, XCD-contiguous vertex ranges: the rows of the other endpoints
+// (grad) and the edge rows shared by two vertices (div) were touched a moment ago by a neighbouring
+// vertex on the same XCD and come from its L2, where the edge-order kernels above fetch them from HBM
+// again.  Edges of a vertex are consecutive (the list is sorted by source), so grad writes whole runs.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_grad_v(const int* __restrict__ perm, const int* __restrict__ eoff,
+                                                const int* __restrict__ edst, const T* __restrict__ cs,
+                                                const T* __restrict__ ct, const T* __restrict__ x,
+                                                T* __restrict__ y, int N, int ld, int gs, int per_xcd) {
+  typedef typename VT<T, VEC>::t V;
+  const int lane = threadIdx.x % gs, grp = threadIdx.x / gs, gpb = 256 / gs, cpr = ld / VEC;
+  const int lo = (int)(blockIdx.x & 7) * per_xcd, hi = min(N, lo + per_xcd);
+  const int stride = (int)(gridDim.x >> 3) * gpb;
+  for (int i = lo + (int)(blockIdx.x >> 3) * gpb + grp; i < hi; i += stride) {
+    const int v = perm ? perm[i] : i;
+    const int e0 = eoff[v], e1 = eoff[v + 1];
+    for (int c = lane; c < cpr; c += gs) {
+      const V xv = *(const V*)(x + (size_t)v * ld + (size_t)c * VEC);
+      for (int k = e0; k < e1; k += 4) {  // four neighbour rows in flight per lane
+        int kk[4];
+        V xd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kk[j] = k + j < e1 ? k + j : e1 - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xd[j] = *(const V*)(x + (size_t)edst[kk[j]] * ld + (size_t)c * VEC);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k + j < e1) *(V*)(y + (size_t)kk[j] * ld + (size_t)c * VEC) = cs[kk[j]] * xv + ct[kk[j]] * xd[j];
+      }
+    }
+  }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_div_v(const int* __restrict__ perm, const int* __restrict__ eoff,
+                                               const int* __restrict__ toff, const int* __restrict__ tedge,
+                                               const T* __restrict__ cs, const T* __restrict__ ct,
+                                               const T* __restrict__ y, T* __restrict__ z, int N, int ld,
+                                               int gs, int per_xcd) {
+  typedef typename VT<T, VEC>::t V;
+  const int lane = threadIdx.x % gs, grp = threadIdx.x / gs, gpb = 256 / gs, cpr = ld / VEC;
+  const int lo = (int)(blockIdx.x & 7) * per_xcd, hi = min(N, lo + per_xcd);
+  const int stride = (int)(gridDim.x >> 3) * gpb;
+  for (int i = lo + (int)(blockIdx.x >> 3) * gpb + grp; i < hi; i += stride) {
+    const int v = perm ? perm[i] : i;
+    const int e0 = eoff[v], e1 = eoff[v + 1], t0 = toff[v], t1 = toff[v + 1];
+    for (int c = lane; c < cpr; c += gs) {
+      V acc = 0;  // same order as k_div: the vertex's own edges, then the edges pointing at it
+      for (int k = e0; k < e1; k += 4) {  // four edge rows in flight per lane
+        V yv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = *(const V*)(y + (size_t)(k + j < e1 ? k + j : e1 - 1) * ld + (size_t)c * VEC);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k + j < e1) acc += cs[k + j] * yv[j];
+      }
+      for (int m = t0; m < t1; m += 4) {
+        int kk[4];
+        V yv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kk[j] = tedge[m + j < t1 ? m + j : t1 - 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = *(const V*)(y + (size_t)kk[j] * ld + (size_t)c * VEC);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (m + j < t1) acc += ct[kk[j]] * yv[j];
+      }
+      *(V*)(z + (size_t)v * ld + (size_t)c * VEC) = acc;
+    }
+  }
+}
+
 }  // namespace gspx

@@ -104,7 +104,7 @@ def test_oracle_sensor20k(ctx, dtype, lap_type):
         dev = engine.DeviceGraph.from_w(W, lap_type, dtype=dtype, perm=perm, ctx=ctx)
         if perm is not None:  # with gather tiles the products run on the LDS-staged kernel
             assert dev.build_gather_tiles()["slow_blocks"] == 0
-        for nsig in (1, 3, 16, 64):
+        for nsig in (1, 3, 16, 64, 200):
             X = rng.standard_normal((N, nsig)).astype(dtype)
             X64 = X.astype(np.float64)
             assert rel_err(dev.laplacian_apply(X), L.dot(X64)) < tol, (nsig, "Lx")
@@ -113,7 +113,13 @@ def test_oracle_sensor20k(ctx, dtype, lap_type):
             Y = dev.grad(X)
             assert Y.shape == (D.shape[1], nsig)
             assert rel_err(Y, ops.grad(D, X64)) < tol, (nsig, "grad")
-            assert rel_err(dev.div(Y), ops.div(D, Y.astype(np.float64))) < tol, (nsig, "div")
+            Z = dev.div(Y)
+            assert rel_err(Z, ops.div(D, Y.astype(np.float64))) < tol, (nsig, "div")
+            ctx.set_option("edge_vertex_walk", 0)  # the edge-order kernels: same sums, same order
+            try:
+                assert rel_err(dev.grad(X), Y) < 4 * np.finfo(dtype).eps and rel_err(dev.div(Y), Z) < 4 * np.finfo(dtype).eps
+            finally:
+                ctx.set_option("edge_vertex_walk", 1)
         # div(grad(x)) = L x (difference.py:38-45)
         x = rng.standard_normal(N)
         assert rel_err(dev.div(dev.grad(x)), L.dot(x.astype(dtype).astype(np.float64))) < tol * 10
