@@ -57,10 +57,10 @@ __global__ __launch_bounds__(256) void k_coldot_partial(const T* __restrict__ A,
   }
   ws[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < ldp) {
+  if ((int)threadIdx.x < ldp) {
     double s = 0;
     for (int k = 0; k < rstep; ++k) s += ws[k * ldp + threadIdx.x];
-    if (threadIdx.x < ld) partial[(size_t)blockIdx.x * ld + threadIdx.x] = s;
+    if ((int)threadIdx.x < ld) partial[(size_t)blockIdx.x * ld + threadIdx.x] = s;
   }
 }
 // out[c] = sum_b partial[b][c]: one 64-lane wave per column, fixed summation tree (deterministic)
