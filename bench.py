@@ -195,11 +195,14 @@ def main():
     newton = newton_pair = None
     if a.evaluation == "recurrence" and not a.no_newton:
         newton = time_newton()
-        # the same, two orders per launch (fused pair kernel; needs the host-built row tiles)
+    if a.evaluation == "recurrence" and not a.no_newton and world == 1:
+        # the same, two orders per launch (fused pair kernel; needs the host-built row tiles: seconds of
+        # numpy per rank, so only in the single-GPU run)
         tiles = dev.enable_pair_tiles()
         newton_pair = time_newton() + (tiles,)
         dev.disable_pair_tiles()
-        step_recurrence()  # leave the headline result in y for the parity check below
+    if newton is not None:
+        step_recurrence()  # leave the headline result in y for the parity check / the gather below
         fence()
 
     # ---- the path's one collective, outside the timed region: outputs -> rank 0 ----------------
