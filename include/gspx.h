@@ -310,6 +310,10 @@ int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, doubl
  * `max_iter` steps.  The caller applies the reference's 1 % margin (graph.py:920). */
 int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int* iterations);
 
+/* Measurement hook: device addresses (out[0..2]: T_k slots, accumulators, weights) and sizes of the
+ * context's workspaces; bytes[2] is 1 when the slots are mapped through the virtual-memory API. */
+int gspx_debug_workspace(gspx_ctx* ctx, void* out[3], int64_t bytes[3]);
+
 /* Profiling hook for the LDS-staged step kernel: with option "tile_stamps" = 1 every k_step_tile
  * launch records, per persistent workgroup, the 100 MHz wall clock at entry and exit.  Downloads the
  * last (at most 64) launches as out[launch][workgroup][2] and resets the record; out may be null to

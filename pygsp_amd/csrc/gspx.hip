@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -61,21 +62,97 @@ extern "C" const char* gspx_version(void) { return "gspx 0.1 (gfx950)"; }
 // ------------------------------------------------------------------------------------------------
 // small RAII device allocation
 // ------------------------------------------------------------------------------------------------
+// Large buffers can be built from separately allocated physical chunks mapped into one address range
+// (placement experiment: GSPX_VMM_CHUNK_MB in the environment; 0 / unset = hipMalloc).
+static size_t vmm_align_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("GSPX_VMM_CHUNK_MB");
+    return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)0;
+  }();
+  return v;
+}
 struct DevMem {
   void* p = nullptr;
   size_t bytes = 0;
+  size_t vmm_size = 0;  // > 0: p is a VMM mapping of that many bytes
   DevMem() = default;
   DevMem(const DevMem&) = delete;
   DevMem& operator=(const DevMem&) = delete;
   ~DevMem() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && vmm_size) {
+      (void)hipMemUnmap(p, vmm_size);
+      for (auto h : vmm_chunks) (void)hipMemRelease(h);
+      vmm_chunks.clear();
+      (void)hipMemAddressFree(p, vmm_size);
+    } else if (p) {
+      (void)hipFree(p);
+    }
     p = nullptr;
     bytes = 0;
+    vmm_size = 0;
+  }
+  // the buffer as `chunk`-byte physical pieces mapped in a scrambled order into one address range
+  // (placement experiment: GSPX_VMM_CHUNK_MB)
+  std::vector<hipMemGenericAllocationHandle_t> vmm_chunks;
+  int alloc_vmm(size_t n, size_t chunk) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran)
+      return -1;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t nch = (n + chunk - 1) / chunk, size = nch * chunk;
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) return -1;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    vmm_chunks.clear();
+    bool ok = true;
+    for (size_t i = 0; i < nch && ok; ++i) {
+      hipMemGenericAllocationHandle_t h;
+      ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess;
+      if (ok) vmm_chunks.push_back(h);
+    }
+    size_t mult = 257;  // odd and not a divisor pattern of typical counts: a scrambled, fixed order
+    while (ok && nch > 1 && std::__gcd(mult, nch) != 1) mult += 2;
+    for (size_t i = 0; i < nch && ok; ++i) {
+      const size_t slot = (i * mult) % nch;
+      ok = hipMemMap((char*)va + slot * chunk, chunk, 0, vmm_chunks[i], 0) == hipSuccess;
+    }
+    if (ok) ok = hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
+    if (!ok) {
+      (void)hipMemUnmap(va, size);
+      for (auto h : vmm_chunks) (void)hipMemRelease(h);
+      vmm_chunks.clear();
+      (void)hipMemAddressFree(va, size);
+      (void)hipGetLastError();
+      return -1;
+    }
+    p = va;
+    vmm_size = size;
+    bytes = n;
+    return 0;
   }
   int alloc(size_t n) {
     release();
     if (n == 0) n = 16;
+    if (vmm_align_bytes() && n >= ((size_t)32 << 20) && alloc_vmm(n, vmm_align_bytes()) == 0) return GSPX_OK;
+    (void)hipGetLastError();
+    static const bool contig = getenv("GSPX_CONTIG") && atoi(getenv("GSPX_CONTIG")) > 0;  // experiment
+    if (contig && n >= ((size_t)32 << 20)) {
+      if (hipExtMallocWithFlags(&p, n, hipDeviceMallocContiguous) == hipSuccess) {
+        bytes = n;
+        return GSPX_OK;
+      }
+      (void)hipGetLastError();
+      p = nullptr;
+    }
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) {
       p = nullptr;
@@ -87,6 +164,12 @@ struct DevMem {
   int ensure(size_t n) {  // grow-only
     if (n <= bytes && p) return GSPX_OK;
     return alloc(n);
+  }
+  void swap(DevMem& o) {
+    std::swap(p, o.p);
+    std::swap(bytes, o.bytes);
+    std::swap(vmm_chunks, o.vmm_chunks);
+    std::swap(vmm_size, o.vmm_size);
   }
   template <typename T> T* as() const { return (T*)p; }
 };
@@ -109,10 +192,14 @@ struct Options {
   int64_t tile_dynamic = 0;     // 1: blocks handed out by per-XCD ticket counters; 0: static walk
   int64_t tile_extra_every = 0; // static walk: extra half round for the first-dispatched workgroups every E rounds
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
+  int64_t placement_probe = 0;  // candidates tried when a large workspace is first allocated (0 / 1: none)
+  int64_t panel_gap = 0;        // bytes between the T_k slots of the workspace (placement experiments)
+  int64_t racc_shift = 0;       // byte offset of the accumulator inside its workspace (placement experiments)
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
   int64_t tile_nt = -1;         // k_step_tile non-temporal accesses: bit 0 matrix entries, bit 2 T_{k-2} loads (each
                                 // -1 % on panels beyond the 256 MB Infinity Cache, +5 % each on panels that fit in
                                 // it); bit 1 accumulator, bit 3 T_k stores (no effect).  -1: 5 for panels >= 192 MiB
+  int64_t tile_xcd_flip = 0;    // XCDs with odd parity of (id & mask) walk their block range in the opposite direction
   int64_t tile_prio = 0;        // experiment: wave priorities of the younger workgroups
   int64_t tile_stamps = 0;      // profiling: record per-workgroup entry/exit clocks of k_step_tile launches
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
@@ -142,6 +229,7 @@ struct gspx_ctx {
   double timing[5] = {0, 0, 0, 0, 0};
   // hipGraph replay of a repeated identical filter call (launch-bound small graphs)
   bool capturing = false;     // run_batch is being recorded: no copies, syncs or events inside
+  bool probing = false;       // probe_placement is timing candidate workspaces
   uint64_t seen_key = 0;      // key of the last eager call
   uint64_t graph_key = 0;     // key the instantiated graph was captured for
   hipGraphExec_t graph_exec = nullptr;
@@ -300,8 +388,12 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_dynamic")) return &o.tile_dynamic;
   if (!strcmp(key, "tile_extra_every")) return &o.tile_extra_every;
   if (!strcmp(key, "tile_prio")) return &o.tile_prio;
+  if (!strcmp(key, "tile_xcd_flip")) return &o.tile_xcd_flip;
   if (!strcmp(key, "tile_nt")) return &o.tile_nt;
   if (!strcmp(key, "fuse_input")) return &o.fuse_input;
+  if (!strcmp(key, "panel_gap")) return &o.panel_gap;
+  if (!strcmp(key, "placement_probe")) return &o.placement_probe;
+  if (!strcmp(key, "racc_shift")) return &o.racc_shift;
   if (!strcmp(key, "edge_vertex_walk")) return &o.edge_vertex_walk;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
@@ -936,10 +1028,21 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
   const int n_s1 = s1ptr[nb];
   CHK(g->gt_hdr.alloc(hdr.size() * 4 + 64));
   CHK(g->gt_s1rows.alloc((size_t)std::max(n_s1, 1) * 4 + 64));
-  CHK(g->gt_lidx.alloc((size_t)g->nnz_int * 2 + 128));
+  CHK(g->gt_lidx.alloc((size_t)g->nnz_int + 128));
   HIPCHK(hipMemcpy(g->gt_hdr.p, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g->gt_s1rows.p, s1rows, (size_t)n_s1 * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->gt_lidx.p, lidx, (size_t)g->nnz_int * 2, hipMemcpyHostToDevice));
+  {  // the device keeps 8-bit positions (only staged blocks use them: n1 <= GSPX_TILE_MAXN1 < 256)
+    std::vector<unsigned char> l8((size_t)g->nnz_int);
+    for (int b = 0; b < nb; ++b) {
+      const bool fast = hdr[(size_t)b * 4 + 1] >= 0;
+      const int e0 = hdr[(size_t)b * 4 + 2], e1 = e0 + hdr[(size_t)b * 4 + 3];
+      for (int e = e0; e < e1; ++e) {
+        if (fast && lidx[e] >= 256) return set_err(GSPX_ERR_INVALID, "gspx_graph_set_gather_tiles: tile position out of range");
+        l8[(size_t)e] = fast ? (unsigned char)lidx[e] : 0;
+      }
+    }
+    HIPCHK(hipMemcpy(g->gt_lidx.p, l8.data(), l8.size(), hipMemcpyHostToDevice));
+  }
   g->gt_rows = block_rows;
   g->gt_nb = nb;
   g->gt_ns1 = n_s1;
@@ -982,10 +1085,10 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   HIPCHK(hipStreamSynchronize(st));
   CHK(g->gt_hdr.alloc((size_t)nb * 4 * sizeof(int) + 64));
   CHK(g->gt_s1rows.alloc((size_t)std::max(n_s1, 1) * 4 + 64));
-  CHK(g->gt_lidx.alloc((size_t)g->nnz_int * 2 + 128));
+  CHK(g->gt_lidx.alloc((size_t)g->nnz_int + 128));
   hipLaunchKernelGGL(k_tiles_fill, dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
                      tmp.as<int>(), n1.as<int>(), s1lo.as<int>(), (int)elt_size(g->dtype), (int)lds,
-                     g->gt_s1rows.as<int>(), g->gt_lidx.as<unsigned short>(), g->gt_hdr.as<int>(),
+                     g->gt_s1rows.as<int>(), g->gt_lidx.as<unsigned char>(), g->gt_hdr.as<int>(),
                      nslow.as<int>());
   int slow = 0;
   HIPCHK(hipMemcpyAsync(&slow, nslow.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1413,12 +1516,12 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   t.val = vals ? vals : g->fval.as<T>();  // any values array on the internal pattern
   t.hdr = g->gt_hdr.as<int>();
   if (!t.s1rows) t.s1rows = g->gt_s1rows.as<int>();  // (the caller may pass the lists in its panel's row order)
-  t.lidx = g->gt_lidx.as<unsigned short>();
+  t.lidx = g->gt_lidx.as<unsigned char>();
   t.N = (int)g->N;
   t.ld = ld;
   t.panel_bytes = (unsigned)((size_t)g->N * ld * sizeof(T));
   t.val_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
-  t.lidx_bytes = (unsigned)((size_t)g->nnz_int * 2);
+  t.lidx_bytes = (unsigned)((size_t)g->nnz_int);
   t.nb = g->gt_nb;
   t.ncol = ncol;
   t.per_xcd = (t.nb + 7) / 8;
@@ -1428,6 +1531,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
     nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
   t.extra_every = opt.tile_dynamic ? 0 : (int)opt.tile_extra_every;  // the ticket walk has its own static prefix
   t.prio_mode = (int)opt.tile_prio;
+  t.xcd_flip = (int)opt.tile_xcd_flip;
   t.nt = opt.tile_nt >= 0 ? (int)opt.tile_nt : ((size_t)g->N * ld * sizeof(T) >= ((size_t)192 << 20) ? 5 : 0);
   t.tickets = nullptr;
   if (opt.tile_dynamic) {
@@ -1494,10 +1598,14 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   }
 
   const size_t nslots = deferred ? (size_t)M : 2;
-  CHK(ctx->ws_t.ensure(nslots * U * sizeof(T) + 256));
-  if (!deferred) CHK(ctx->ws_r.ensure((size_t)nf * U * sizeof(T) + 256));
+  // slot pitch / accumulator offset: U plus an optional gap (placement experiments, options panel_gap /
+  // racc_shift in bytes, multiples of 256)
+  const size_t SU = U + (size_t)(opt.panel_gap & ~(int64_t)255) / sizeof(T);
+  const size_t rshift = (size_t)(opt.racc_shift & ~(int64_t)255) / sizeof(T);
+  CHK(ctx->ws_t.ensure(nslots * SU * sizeof(T) + 256));
+  if (!deferred) CHK(ctx->ws_r.ensure(((size_t)nf * U + rshift) * sizeof(T) + 256));
   T* slots = ctx->ws_t.as<T>();
-  T* racc = ctx->ws_r.as<T>();
+  T* racc = ctx->ws_r.as<T>() + rshift;
 
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   if (!cap) {
@@ -1560,13 +1668,13 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
     if (tile_ok) {
       TileArgs<T> t{};
       if (deferred) {
-        t.cur = slots + (size_t)(k - 1) * U;
-        t.old = (k >= 2 && ps.gamma != 0.0) ? slots + (size_t)(k - 2) * U : t.cur;
-        t.out = slots + (size_t)k * U;
+        t.cur = slots + (size_t)(k - 1) * SU;
+        t.old = (k >= 2 && ps.gamma != 0.0) ? slots + (size_t)(k - 2) * SU : t.cur;
+        t.out = slots + (size_t)k * SU;
       } else {
-        t.cur = slots + (size_t)((k - 1) & 1) * U;
-        t.old = ps.gamma == 0.0 ? t.cur : slots + (size_t)(k & 1) * U;
-        t.out = slots + (size_t)(k & 1) * U;
+        t.cur = slots + (size_t)((k - 1) & 1) * SU;
+        t.old = ps.gamma == 0.0 ? t.cur : slots + (size_t)(k & 1) * SU;
+        t.out = slots + (size_t)(k & 1) * SU;
         if (fuse_in && k == 1) {  // T_0 is the caller's panel
           t.cur = x;
           t.old = x;
@@ -1595,13 +1703,13 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
       continue;
     }
     if (deferred) {
-      a.cur = slots + (size_t)(k - 1) * U;
-      a.old = k >= 2 ? slots + (size_t)(k - 2) * U : slots;
-      a.out = slots + (size_t)k * U;
+      a.cur = slots + (size_t)(k - 1) * SU;
+      a.old = k >= 2 ? slots + (size_t)(k - 2) * SU : slots;
+      a.out = slots + (size_t)k * SU;
     } else {
-      a.cur = slots + (size_t)((k - 1) & 1) * U;
-      a.old = slots + (size_t)(k & 1) * U;
-      a.out = slots + (size_t)(k & 1) * U;
+      a.cur = slots + (size_t)((k - 1) & 1) * SU;
+      a.old = slots + (size_t)(k & 1) * SU;
+      a.out = slots + (size_t)(k & 1) * SU;
     }
     if (ps.gamma == 0.0) a.old = a.cur;  // never read for its value; keeps the kernel branch-free
     a.scale = (T)ps.scale;
@@ -1616,7 +1724,7 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   if (deferred) {
     int cvec = shape.vec;
     while (cvec > 1 && ((ldy % cvec) != 0 || (((uintptr_t)y / sizeof(T)) % cvec) != 0)) cvec /= 2;
-    launch_combine<T>(slots, M, U, ctx->ws_w.as<T>(), M, nf, N, ld, y, ldy, (size_t)N * ldy, perm,
+    launch_combine<T>(slots, M, SU, ctx->ws_w.as<T>(), M, nf, N, ld, y, ldy, (size_t)N * ldy, perm,
                       cvec, st);
   }
   if (!cap) {
@@ -1633,6 +1741,70 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
 
 template <typename T>
 static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
+                        int64_t Nsig, const T* x, T* y, int mode);
+
+// Where the driver places a large workspace matters: the same recurrence runs 0.36 ms or 0.39 ms per
+// order (1M x 64 fp64) depending on the physical memory behind the two T_k slots - stable for the life
+// of the allocation, different from one allocation to the next, independent of the distances between the
+// panels (tools/experiments/exp_layout*.py).  So a large workspace is not taken as it comes: a few
+// candidates are allocated side by side, each runs a short filter (six orders on a zero panel), the
+// fastest stays and the others are freed.  Costs a few milliseconds, once per workspace size.
+template <typename T>
+static int probe_placement(gspx_graph* g, double lmax, int64_t Nsig, size_t need_t, size_t need_r) {
+  gspx_ctx* ctx = g->ctx;
+  const int tries = (int)std::min<int64_t>(ctx->opt.placement_probe, 8);
+  struct Guard {
+    gspx_ctx* c;
+    ~Guard() { c->probing = false; }
+  } guard{ctx};
+  ctx->probing = true;
+  const size_t pb = (size_t)g->N * (size_t)Nsig * sizeof(T);
+  DevMem px, py;
+  CHK(px.alloc(pb));
+  CHK(py.alloc(pb));
+  HIPCHK(hipMemsetAsync(px.p, 0, pb, ctx->stream));
+  const double cf[7] = {1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125, 0.015625};
+  std::vector<std::unique_ptr<DevMem>> cand;
+  int best = -1;
+  double best_ms = 0;
+  for (int i = 0; i < tries; ++i) {
+    cand.emplace_back(new DevMem());
+    cand.emplace_back(new DevMem());
+    DevMem& ct = *cand[(size_t)2 * i];
+    DevMem& cr = *cand[(size_t)2 * i + 1];
+    if (ct.alloc(need_t) != GSPX_OK || cr.alloc(need_r) != GSPX_OK) {  // out of memory: use what there is
+      (void)hipGetLastError();
+      ct.release();
+      cr.release();
+      break;
+    }
+    HIPCHK(hipMemsetAsync(ct.p, 0, need_t, ctx->stream));
+    HIPCHK(hipMemsetAsync(cr.p, 0, need_r, ctx->stream));
+    ctx->ws_t.swap(ct);
+    ctx->ws_r.swap(cr);
+    double ms = 0;
+    int rc = GSPX_OK;
+    for (int rep = 0; rep < 2 && rc == GSPX_OK; ++rep) {  // the second run is the measurement
+      rc = filter_dev_t<T>(g, lmax, 1, 7, cf, Nsig, px.as<T>(), py.as<T>(), GSPX_ANALYSIS);
+      ms = ctx->timing[1];
+    }
+    ctx->ws_t.swap(ct);
+    ctx->ws_r.swap(cr);
+    if (rc != GSPX_OK) return rc;
+    if (best < 0 || ms < best_ms) {
+      best = i;
+      best_ms = ms;
+    }
+  }
+  if (best >= 0) {
+    ctx->ws_t.swap(*cand[(size_t)2 * best]);
+    ctx->ws_r.swap(*cand[(size_t)2 * best + 1]);
+  }
+  return GSPX_OK;
+}
+
+template <typename T>
+static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                         int64_t Nsig, const T* x, T* y, int mode) {
   gspx_ctx* ctx = g->ctx;
   const Options& opt = ctx->opt;
@@ -1640,6 +1812,16 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
   for (int i = 0; i < 5; ++i) ctx->timing[i] = 0;
   if (N == 0 || Nsig == 0) return GSPX_OK;
   CHK(ensure_factor<T>(g, lmax));
+  {  // a large single-filter workspace about to be (re)allocated: choose its placement by measurement
+    const size_t U1 = (size_t)N * (size_t)Nsig * sizeof(T);
+    const size_t need_t = 2 * U1 + 256, need_r = U1 + 256;
+    if (opt.placement_probe > 1 && !ctx->probing && !ctx->capturing && Nf == 1 && mode == GSPX_ANALYSIS &&
+        U1 >= ((size_t)128 << 20) && U1 < ((size_t)1 << 31) - 65536 && ctx->ws_t.bytes < need_t &&
+        3 * U1 <= ((size_t)std::max<int64_t>(opt.ws_limit_mb, 1) << 20)) {
+      CHK(probe_placement<T>(g, lmax, Nsig, need_t, need_r));
+      for (int i = 0; i < 5; ++i) ctx->timing[i] = 0;
+    }
+  }
 
   std::vector<double> cp;
   halve_c0(Nf, M, coeffs, cp);
@@ -2402,6 +2584,15 @@ extern "C" int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double
 // calibration: streaming copy with the engine's own 16-byte-per-lane copy kernel (k_permute_in
 // without a permutation) - the measured HBM ceiling quoted beside every roofline fraction.
 // ------------------------------------------------------------------------------------------------
+// placement experiments: device addresses of the context's workspaces (T_k slots, accumulators, weights)
+extern "C" int gspx_debug_workspace(gspx_ctx* ctx, void* out[3], int64_t bytes[3]) {
+  if (!ctx || !out || !bytes) return set_err(GSPX_ERR_INVALID, "gspx_debug_workspace: null argument");
+  out[0] = ctx->ws_t.p; out[1] = ctx->ws_r.p; out[2] = ctx->ws_w.p;
+  bytes[0] = (int64_t)ctx->ws_t.bytes; bytes[1] = (int64_t)ctx->ws_r.bytes;
+  bytes[2] = ctx->ws_t.vmm_size ? 1 : 0;  // 1: the slots are a VMM mapping
+  return GSPX_OK;
+}
+
 // profiling hook: clocks recorded by the last (at most 64) k_step_tile launches under option
 // "tile_stamps"; out[launch][workgroup][2] (100 MHz wall clock at entry, exit)
 extern "C" int gspx_debug_tile_stamps(gspx_ctx* ctx, int64_t* out, int64_t capacity, int64_t* launches,

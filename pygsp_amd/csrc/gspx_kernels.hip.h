@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(256) void k_step_lds(const int* __restrict__ rowptr
 // ---------------------------------------------------------------------------------------------
 #define GSPX_PAD16 0xFFFFu
 typedef unsigned short u16;
+typedef unsigned char u8;
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct PairArgs {
@@ -1118,14 +1119,15 @@ __device__ __forceinline__ V tile_row_dot(const T* __restrict__ val, const u16* 
 
 // The same dot product with the entries already in LDS (pads resolved), one 4-entry chunk per trip:
 // small register footprint, the staged kernel keeps a prefetched block's row lists live across it.
-template <typename T, typename V, int LG = 16>  // LG: lanes (16-byte pieces) per tile row
-__device__ __forceinline__ V lds_row_dot(const T* val, const u16* idx, int len, const V* tile, int lane16,
-                                         V& self) {
+template <typename T, typename V, int LG = 16, typename I = u16>  // LG: lanes (16-byte pieces) per tile row;
+__device__ __forceinline__ V lds_row_dot(const T* val, const I* idx, int len, const V* tile, int lane16,
+                                         V& self) {                   // I: tile positions, 16 or 8 bits
   typedef T T4 __attribute__((ext_vector_type(4)));
+  typedef I I4 __attribute__((ext_vector_type(4)));
   V acc = 0;
   self = 0;
   for (int j = 0; j < len; j += 4) {
-    const u16x4 ia = *(const u16x4*)(idx + j);
+    const I4 ia = *(const I4*)(idx + j);
     const T4 va = *(const T4*)(val + j);
     const V t0 = tile[ia.x * LG + lane16];
     const V t1 = tile[ia.y * LG + lane16];

@@ -5,15 +5,16 @@
 //
 // The internal vertex order is cut into 64-row blocks.  The host (pygsp_amd/tiling.py) lists, per
 // block, the distinct rows its entries touch (S1: 123 rows on average on the headline graph) and,
-// for every stored entry, the 16-bit position of its column inside that list.  A workgroup
+// for every stored entry, the 8-bit position of its column inside that list (a staged tile has at most
+// 160 rows).  A workgroup
 //   1. loads the S1 rows of T_{k-1} straight into LDS (buffer_load ... lds: 1 KiB per wave
 //      instruction, no VGPRs), one 256-byte column chunk at a time;
-//   2. copies the block's contiguous slice of matrix entries (value + 16-bit position) into LDS,
+//   2. copies the block's contiguous slice of matrix entries (value + 8-bit position) into LDS,
 //      coalesced, once for all column chunks of the block;
 //   3. computes its rows from LDS (ds_read_b128 gathers, broadcast reads of the entries).
 // Against the plain gather kernels this turns 11 gathers per row (a third of which miss the L1 and
 // re-fetch from L2) into 1.9 coalesced row fetches per row, and shrinks the streamed matrix from
-// (elt + 4) to (elt + 2) bytes per entry.  Workgroups are persistent; XCD x walks a contiguous
+// (elt + 4) to (elt + 1) bytes per entry.  Workgroups are persistent; XCD x walks a contiguous
 // eighth of the blocks, its workgroups interleaved, so the halo rows of concurrently staged blocks
 // meet in that XCD's L2.  Block headers are prefetched two blocks ahead, row lists one block ahead.
 // Blocks whose tile does not fit (n1 > 160 rows or rows longer than the LDS slice) take a plain
@@ -30,7 +31,7 @@ template <typename T> struct TileArgs {
   const T* val;        // factor values F
   const int* hdr;      // [nb][4]: s1lo, n1 (-1: slow path), rp0 (first entry of the block), ent (entries)
   const int* s1rows;   // concatenated S1 lists
-  const u16* lidx;     // [nnz_int] position of each entry's column in its block's S1 (pads: 0)
+  const u8* lidx;      // [nnz_int] position of each entry's column in its block's S1 (< 256; pads: 0)
   const T* cur;
   const T* old;
   const int* old_rows;  // OLDNAT builds: row of `old` holding T_{k-2} of internal row r (the caller's x, unpermuted)
@@ -62,6 +63,7 @@ template <typename T> struct TileArgs {
   int reverse;    // 1: every XCD walks its block range from the end (odd steps: the tail of the previous
                   // step's panels is still in the Infinity Cache)
   int nt;         // experiment: 1 = matrix entries loaded non-temporal (keep them out of the Infinity Cache)
+  int xcd_flip;   // mask over the XCD id: XCDs with odd parity of (id & mask) walk their range the other way
   int prio_mode;  // experiment: 1 = younger workgroups raise their wave priority, 2 = alternate per block
 };
 
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   struct Meta { int rows[ST]; int rp[RPG + 1]; int orow[OLDNAT ? RPG : 1]; };
   // walk position -> block: the XCD's range front to back, or back to front
   const int xflip = xlo + k1 - 1;
-  auto phys = [&](int p) { return a.reverse ? xflip - p : p; };
+  const bool rev = (a.reverse != 0) != ((__builtin_popcount((int)(blockIdx.x & 7) & a.xcd_flip) & 1) != 0);
+  auto phys = [&](int p) { return rev ? xflip - p : p; };
   auto load_hdr = [&](int p) { return *(const int4*)(a.hdr + (size_t)phys(p) * 4); };
   auto uniform = [](int4 h) {
     int4 u;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     const int n1 = H.y, rp0 = H.z, ent = H.w;
     const bool fast = n1 >= 0;
     T* const mval = (T*)(tile + (fast ? n1 : 0) * LG);
-    u16* const midx = (u16*)(mval + ent);
+    u8* const midx = (u8*)(mval + ent);
     const int row0 = phys(k) * GSPX_TILE_BR + grp * RPG;
     int rs[RPG + 1];
 #pragma unroll
@@ -220,10 +223,10 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     }
     // the block's slice of matrix entries, coalesced (values: 16-byte pieces, positions likewise)
     u32x4 ev = 0, ei = 0;
-    const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent * 2 + 15) >> 4;
+    const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent + 15) >> 4;
     if (first && fast) {
       const u32 vo = tid < nv16 ? (u32)rp0 * (u32)sizeof(T) + tid * 16u : POISON;
-      const u32 io = tid < ni16 ? (u32)rp0 * 2u + tid * 16u : POISON;
+      const u32 io = tid < ni16 ? (u32)rp0 + tid * 16u : POISON;
       if (a.nt & 1) {
         ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 2);
         ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 2);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
             __builtin_amdgcn_raw_buffer_load_b128(rv, (u32)rp0 * (u32)sizeof(T) + i * 16u, 0, 0);
       for (int i = tid + 512; i < ni16; i += 512)
         *(u32x4*)((unsigned char*)midx + i * 16) =
-            __builtin_amdgcn_raw_buffer_load_b128(ri, (u32)rp0 * 2u + i * 16u, 0, 0);
+            __builtin_amdgcn_raw_buffer_load_b128(ri, (u32)rp0 + i * 16u, 0, 0);
     }
     if (last && a.tickets && tid == 0) s_ticket = tkt;
     __syncthreads();  // tile and entries in place
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
       for (int t = 0; t < RPG; ++t) {
         const int s = rs[t], e = rs[t + 1];
         V self;
-        const V acc = lds_row_dot<T, V, LG>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
+        const V acc = lds_row_dot<T, V, LG, u8>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
                                         lane16, self);
         nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
         cv[t] = self;
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(256) void k_tiles_fill(const int* __restrict__ rowp
                                                     const int* __restrict__ col, int N, int nb,
                                                     const int* __restrict__ tmp, const int* __restrict__ n1,
                                                     const int* __restrict__ s1lo, int esz, int lds_bytes,
-                                                    int* __restrict__ s1rows, u16* __restrict__ lidx,
+                                                    int* __restrict__ s1rows, u8* __restrict__ lidx,
                                                     int* __restrict__ hdr, int* __restrict__ nslow) {
   const int b = blockIdx.x;
   const int r0 = b * GSPX_TILE_BR, r1 = min(r0 + GSPX_TILE_BR, N);
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void k_tiles_fill(const int* __restrict__ rowp
       }
       pos = a;
     }
-    lidx[e0 + i] = (u16)pos;
+    lidx[e0 + i] = (u8)pos;  // fast blocks: pos < GSPX_TILE_MAXN1 <= 255
   }
 }
 // kept rows per block for the scan (a slow block beyond the cap contributes none)
