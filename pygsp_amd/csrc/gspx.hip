@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <numeric>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -120,7 +121,7 @@ struct DevMem {
       if (ok) vmm_chunks.push_back(h);
     }
     size_t mult = 257;  // odd and not a divisor pattern of typical counts: a scrambled, fixed order
-    while (ok && nch > 1 && std::__gcd(mult, nch) != 1) mult += 2;
+    while (ok && nch > 1 && std::gcd(mult, nch) != 1) mult += 2;
     for (size_t i = 0; i < nch && ok; ++i) {
       const size_t slot = (i * mult) % nch;
       ok = hipMemMap((char*)va + slot * chunk, chunk, 0, vmm_chunks[i], 0) == hipSuccess;
