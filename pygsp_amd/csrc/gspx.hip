@@ -63,12 +63,17 @@ extern "C" const char* gspx_version(void) { return "gspx 0.1 (gfx950)"; }
 // ------------------------------------------------------------------------------------------------
 // small RAII device allocation
 // ------------------------------------------------------------------------------------------------
-// Large buffers can be built from separately allocated physical chunks mapped into one address range
-// (placement experiment: GSPX_VMM_CHUNK_MB in the environment; 0 / unset = hipMalloc).
-static size_t vmm_align_bytes() {
+// Large internal buffers are not taken from hipMalloc as one piece: they are assembled from 2 MB physical
+// chunks (hipMemCreate) mapped in a scrambled order into one reserved address range.  On MI355X the
+// physical placement of a streamed buffer moves its bandwidth by several percent - a plain copy of
+// 2 x 1 GiB runs at 5.3-5.4 TB/s from hipMalloc memory, 5.4-5.7 from physically contiguous memory and
+// 5.7-6.0 from scrambled 2 MB chunks (reads: 5.7 / 5.8-6.0 / 6.2) - and the recurrence follows it
+// (fp64 headline step 0.352 ms against 0.375 in the same session; tools/experiments/exp_layout*.py).
+// GSPX_VMM_CHUNK_MB in the environment overrides the chunk size; 0 = plain hipMalloc.
+static size_t vmm_chunk_bytes() {
   static const size_t v = [] {
     const char* e = getenv("GSPX_VMM_CHUNK_MB");
-    return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)0;
+    return (e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2) << 20;
   }();
   return v;
 }
@@ -140,10 +145,14 @@ struct DevMem {
     bytes = n;
     return 0;
   }
-  int alloc(size_t n) {
+  int alloc(size_t n, bool plain = false) {  // plain: one hipMalloc (buffers handed to callers / peers)
     release();
     if (n == 0) n = 16;
-    if (vmm_align_bytes() && n >= ((size_t)32 << 20) && alloc_vmm(n, vmm_align_bytes()) == 0) return GSPX_OK;
+    if (!plain && vmm_chunk_bytes() && n >= ((size_t)32 << 20)) {
+      size_t chunk = vmm_chunk_bytes();
+      while ((n + chunk - 1) / chunk > 4096) chunk *= 2;  // at most 4096 pieces per buffer
+      if (alloc_vmm(n, chunk) == 0) return GSPX_OK;
+    }
     (void)hipGetLastError();
     static const bool contig = getenv("GSPX_CONTIG") && atoi(getenv("GSPX_CONTIG")) > 0;  // experiment
     if (contig && n >= ((size_t)32 << 20)) {
@@ -438,7 +447,7 @@ extern "C" int gspx_buf_alloc(gspx_ctx* ctx, int64_t bytes, gspx_buf** out) {
   gspx_buf* b = new gspx_buf();
   b->ctx = ctx;
   b->bytes = bytes;
-  int rc = b->mem.alloc((size_t)bytes);
+  int rc = b->mem.alloc((size_t)bytes, true);  // caller-visible memory: one plain allocation (peer copies, interop)
   if (rc != GSPX_OK) {
     delete b;
     return rc;
