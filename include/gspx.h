@@ -85,6 +85,9 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *                   returning atomic costs more than the tail it removes); 0 (default) static walk
  *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order (16-byte lanes,
  *                   neighbour rows from L2); 0 = the edge-order kernels
+ *   (environment, read once per process) GSPX_VMM_CHUNK_MB: internal buffers of 32 MB and more are
+ *                   assembled from physical chunks of that size mapped in a scrambled order (default 2;
+ *                   0 = plain hipMalloc); GSPX_CONTIG=1: physically contiguous memory (experiment)
  *   "fuse_input"    1 (default): with gather tiles on every block, steps 1 and 2 of a single-filter
  *                   call read the caller's panel directly (gather lists mapped through the vertex
  *                   order) instead of copying it into the internal order first; 0 = always copy
