@@ -85,7 +85,7 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(a.gpus, world))
 
-    from pygsp_amd import _capi, engine, graphs
+    from pygsp_amd import engine, graphs
     from pygsp_amd import dist as gdist
 
     torch = None
