@@ -87,9 +87,7 @@ struct DevMem {
   ~DevMem() { release(); }
   void release() {
     if (p && vmm_size) {
-      (void)hipMemUnmap(p, vmm_size);
-      for (auto h : vmm_chunks) (void)hipMemRelease(h);
-      vmm_chunks.clear();
+      unmap_chunks(p, vmm_chunks.size());
       (void)hipMemAddressFree(p, vmm_size);
     } else if (p) {
       (void)hipFree(p);
@@ -101,6 +99,17 @@ struct DevMem {
   // the buffer as `chunk`-byte physical pieces mapped in a scrambled order into one address range
   // (placement experiment: GSPX_VMM_CHUNK_MB)
   std::vector<hipMemGenericAllocationHandle_t> vmm_chunks;
+  size_t vmm_chunk = 0, vmm_mult = 1;  // piece size; piece i sits at slot (i * vmm_mult) % pieces
+  // unmap exactly what was mapped, piece by piece (the first `mapped` pieces), and drop the handles
+  void unmap_chunks(void* va, size_t mapped) {
+    const size_t nch = vmm_chunks.size();
+    for (size_t i = 0; i < nch; ++i) {
+      if (i < mapped) (void)hipMemUnmap((char*)va + ((i * vmm_mult) % nch) * vmm_chunk, vmm_chunk);
+      (void)hipMemRelease(vmm_chunks[i]);
+    }
+    vmm_chunks.clear();
+    (void)hipGetLastError();
+  }
   int alloc_vmm(size_t n, size_t chunk) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -125,17 +134,19 @@ struct DevMem {
       ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess;
       if (ok) vmm_chunks.push_back(h);
     }
-    size_t mult = 257;  // odd and not a divisor pattern of typical counts: a scrambled, fixed order
-    while (ok && nch > 1 && std::gcd(mult, nch) != 1) mult += 2;
+    size_t mult = 257;  // coprime with the piece count: a scrambled, fixed order that visits every slot once
+    while (nch > 1 && std::gcd(mult, nch) != 1) mult += 2;
+    vmm_chunk = chunk;
+    vmm_mult = mult;
+    size_t mapped = 0;
     for (size_t i = 0; i < nch && ok; ++i) {
       const size_t slot = (i * mult) % nch;
       ok = hipMemMap((char*)va + slot * chunk, chunk, 0, vmm_chunks[i], 0) == hipSuccess;
+      if (ok) mapped = i + 1;
     }
     if (ok) ok = hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
     if (!ok) {
-      (void)hipMemUnmap(va, size);
-      for (auto h : vmm_chunks) (void)hipMemRelease(h);
-      vmm_chunks.clear();
+      unmap_chunks(va, mapped);
       (void)hipMemAddressFree(va, size);
       (void)hipGetLastError();
       return -1;
@@ -179,6 +190,8 @@ struct DevMem {
     std::swap(p, o.p);
     std::swap(bytes, o.bytes);
     std::swap(vmm_chunks, o.vmm_chunks);
+    std::swap(vmm_chunk, o.vmm_chunk);
+    std::swap(vmm_mult, o.vmm_mult);
     std::swap(vmm_size, o.vmm_size);
   }
   template <typename T> T* as() const { return (T*)p; }
