@@ -97,7 +97,7 @@ struct DevMem {
     vmm_size = 0;
   }
   // the buffer as `chunk`-byte physical pieces mapped in a scrambled order into one address range
-  // (placement experiment: GSPX_VMM_CHUNK_MB)
+  // (the default for large internal buffers, see vmm_chunk_bytes)
   std::vector<hipMemGenericAllocationHandle_t> vmm_chunks;
   size_t vmm_chunk = 0, vmm_mult = 1;  // piece size; piece i sits at slot (i * vmm_mult) % pieces
   // unmap exactly what was mapped, piece by piece (the first `mapped` pieces), and drop the handles
