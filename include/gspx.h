@@ -59,51 +59,32 @@ int gspx_device_count(int* n);
 int gspx_ctx_create(int device, gspx_ctx** out);
 int gspx_ctx_destroy(gspx_ctx* ctx);
 int gspx_ctx_sync(gspx_ctx* ctx);
-/* tuning knobs (integers).  Unknown key -> GSPX_ERR_INVALID.  Keys:
- *   "kernel"      0 auto, 1 panel (lane groups own rows), 2 narrow (sub-wave rows), 3 wave-row
- *                 (one row per wave, all metadata scalar)
- *   "vec"         0 auto, else elements per lane (1,2,4)
- *   "rows_per_wave"  consecutive rows per wave (0 = auto)
- *   "narrow_g_log2"  narrow kernel: log2 of lanes splitting one row's entries (-1 = auto)
- *   "xcd_remap"   1 (default) contiguous row ranges per XCD, 0 plain order
- *   "synthesis"   0 (default) vector-coefficient Clenshaw: K sparse products for any Nf;
- *                 1 the reference's per-filter loop (K*Nf products)
- *   "alternate_sweep" 1 (default) odd steps sweep the rows (k_step_tile: every XCD's block range) from the end: the tail of the previous
- *                 step's output is still in the Infinity Cache (measured -3..5 %)
- *   "waves_per_block" 4 (default), 8 or 16 waves per workgroup (kernel 1)
- *   "ws_limit_mb" / "max_batch"  workspace budget / cap on signals per batch
- *   "combine"     0 auto, 1 fused flush every 3rd step, 2 deferred combine (keep all T_k)
- *   "graph_launch" 2 (default) an analysis call that repeats the previous one exactly (same graph,
- *                 lmax, coefficients, pointers, options) is recorded once as a hipGraph and replayed
- *                 when its panel is at most 32 MB (launch-bound); 1 always; 0 never.  A replayed call
- *                 reports one total time (gspx_last_timing out[0] == out[1])
- *   "tile_gather" 1 (default) recurrence steps stage the gathered panel in LDS when the graph
- *                 carries gather tiles (gspx_graph_set_gather_tiles); 0 plain gather kernels
- *   "tile_workgroups" persistent workgroups of that kernel (0 = two per CU)
- *   "tile_dynamic"  1 = blocks are handed to the persistent workgroups by per-XCD ticket counters
- *                   (even finish times; measured no faster: the kernel is bandwidth bound and the
- *                   returning atomic costs more than the tail it removes); 0 (default) static walk
- *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order (16-byte lanes,
- *                   neighbour rows from L2); 0 = the edge-order kernels
- *   (environment, read once per process) GSPX_VMM_CHUNK_MB: internal buffers of 32 MB and more are
- *                   assembled from physical chunks of that size mapped in a scrambled order (default 2;
- *                   0 = plain hipMalloc); GSPX_CONTIG=1: physically contiguous memory (experiment)
- *   "fuse_input"    1 (default): with gather tiles on every block, steps 1 and 2 of a single-filter
- *                   call read the caller's panel directly (gather lists mapped through the vertex
- *                   order) instead of copying it into the internal order first; 0 = always copy
- *   "tile_nt"       non-temporal accesses of the step kernel: bit 0 matrix entries, bit 2 T_{k-2}
- *                   rows (each about -1 % when the panel exceeds the 256 MB Infinity Cache, +5 % when it
- *                   fits); bit 1 accumulator, bit 3 T_k stores (no effect).  -1 (default): 5 for
- *                   panels of 192 MiB and more, else 0
- *   "tile_extra_every" E > 0: static walk in which the first-dispatched half of the workgroups takes
- *                   an extra half-width round after every E rounds (they run ~8 % faster); 0 default
- *   "tile_stamps"   1 = record per-workgroup entry/exit clocks (gspx_debug_tile_stamps); 0 default
- *   "tile_prio"     experiment: 1 = the second-dispatched workgroups raise their wave priority, 2 = the
- *                   two workgroups of a CU alternate it per block (measured: no faster); 0 default
- *   "newton_pair" 1 (default) Newton-form filtering runs two orders per launch when the graph
- *                 carries tiles (gspx_graph_set_tiles); 0 one order per launch
- *   "pair_workgroups" persistent workgroups of the fused pair kernel (0 = two per CU)
- */
+/* Integer options of a context.  Unknown key -> GSPX_ERR_INVALID.  The defaults are what the engine
+ * is measured with; the others exist so that every kernel variant stays testable against the oracle.
+ *   "kernel"        0 auto; 1 lane-group panel kernel; 2 narrow (sub-wave rows, 1-4 signals);
+ *                   3 / 4 wave-row kernels; 5 LDS-staged CSR slice.  Ignored when gather tiles apply
+ *   "tile_gather"   1 (default): recurrence steps stage the gathered panel in LDS when the graph carries
+ *                   gather tiles (k_step_tile); 0: plain gather kernels
+ *   "fuse_input"    1 (default): with gather tiles, steps 1-2 of a single-filter call read the caller's
+ *                   panel in place instead of copying it into the internal vertex order first
+ *   "combine"       0 auto; 1 fused flush (accumulate every third step); 2 deferred (keep all T_k, one
+ *                   combine pass; the default for filterbanks)
+ *   "synthesis"     0 (default) one vector-coefficient Clenshaw recurrence (K sparse products for any
+ *                   Nf); 1 the reference's per-filter loop (K*Nf products, filter.py:317-321)
+ *   "graph_launch"  2 (default) an analysis call that repeats the previous one exactly is recorded as a
+ *                   hipGraph and replayed when its panel is at most 32 MB (launch-bound); 1 always;
+ *                   0 never.  A replayed call reports one total time (gspx_last_timing out[0] == out[1])
+ *   "ws_limit_mb" / "max_batch"   workspace budget per call / cap on signals per batch
+ *   "alternate_sweep" 1 (default) odd steps sweep the rows from the end (Infinity-Cache reuse)
+ *   "xcd_remap"     1 (default) contiguous row ranges per XCD in the plain gather kernels
+ *   "tile_nt"       k_step_tile non-temporal accesses, bit 0 matrix entries, bit 1 accumulator, bit 2
+ *                   T_{k-2} rows, bit 3 T_k stores; -1 (default): 5 for panels of 192 MiB and more
+ *   "tile_workgroups" / "pair_workgroups"   persistent workgroups of k_step_tile / k_newton_pair (0: 2 per CU)
+ *   "vec", "rows_per_wave", "narrow_g_log2", "waves_per_block"   launch shapes of the plain gather
+ *                   kernels (0 / -1 = auto)
+ *   "newton_pair"   1 (default) Newton-form filtering runs two orders per launch when the graph carries
+ *                   pair tiles (gspx_graph_set_tiles)
+ *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order; 0 edge order */
 int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value);
 int gspx_ctx_get_option(gspx_ctx* ctx, const char* key, int64_t* value);
 
@@ -312,16 +293,6 @@ int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, doubl
  * eigenvalue of L lies within that distance; the reference asks ARPACK for 5e-3) or after
  * `max_iter` steps.  The caller applies the reference's 1 % margin (graph.py:920). */
 int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int* iterations);
-
-/* Measurement hook: device addresses (out[0..2]: T_k slots, accumulators, weights) and sizes of the
- * context's workspaces; bytes[2] is 1 when the slots are mapped through the virtual-memory API. */
-int gspx_debug_workspace(gspx_ctx* ctx, void* out[3], int64_t bytes[3]);
-
-/* Profiling hook for the LDS-staged step kernel: with option "tile_stamps" = 1 every k_step_tile
- * launch records, per persistent workgroup, the 100 MHz wall clock at entry and exit.  Downloads the
- * last (at most 64) launches as out[launch][workgroup][2] and resets the record; out may be null to
- * query the counts.  No reference counterpart (measurement only). */
-int gspx_debug_tile_stamps(gspx_ctx* ctx, int64_t* out, int64_t capacity, int64_t* launches, int* workgroups);
 
 /* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two
  * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */

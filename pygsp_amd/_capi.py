@@ -104,8 +104,6 @@ SIGNATURES = {
                                      _c.POINTER(_c.c_int)]),
     "gspx_bench_read": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),
     "gspx_gather": (_c.c_int, [_P, _c.c_int, _P, _P]),
-    "gspx_debug_workspace": (_c.c_int, [_P, _P, _P]),
-    "gspx_debug_tile_stamps": (_c.c_int, [_P, _P, _c.c_int64, _P, _P]),
     "gspx_bench_copy": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),
 }
 

@@ -63,117 +63,144 @@ extern "C" const char* gspx_version(void) { return "gspx 0.1 (gfx950)"; }
 // ------------------------------------------------------------------------------------------------
 // small RAII device allocation
 // ------------------------------------------------------------------------------------------------
-// Large internal buffers are not taken from hipMalloc as one piece: they are assembled from 2 MB physical
-// chunks (hipMemCreate) mapped in a scrambled order into one reserved address range.  On MI355X the
-// physical placement of a streamed buffer moves its bandwidth by several percent - a plain copy of
-// 2 x 1 GiB runs at 5.3-5.4 TB/s from hipMalloc memory, 5.4-5.7 from physically contiguous memory and
-// 5.7-6.0 from scrambled 2 MB chunks (reads: 5.7 / 5.8-6.0 / 6.2) - and the recurrence follows it
-// (fp64 headline step 0.352 ms against 0.375 in the same session; tools/experiments/exp_layout*.py).
-// GSPX_VMM_CHUNK_MB in the environment overrides the chunk size; 0 = plain hipMalloc.
-static size_t vmm_chunk_bytes() {
-  static const size_t v = [] {
-    const char* e = getenv("GSPX_VMM_CHUNK_MB");
-    return (e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2) << 20;
-  }();
-  return v;
-}
+// Plain buffers are one hipMalloc.  The two streamed workspaces of a context (T_k slots, accumulators)
+// are "streamed" buffers: from 32 MB on they are assembled from 2 MB physical chunks (hipMemCreate)
+// mapped in a scrambled order into one reserved address range.  On MI355X the physical placement of a
+// streamed buffer moves its bandwidth by several percent - a plain copy of 2 x 1 GiB runs at
+// 5.3-5.4 TB/s from hipMalloc memory and 5.7-6.0 from scrambled 2 MB chunks - and the recurrence
+// follows it.
+// Safety rules of the mapping.  Round 1 shipped a version that, on growth, unmapped the chunks, gave the
+// address range back (hipMemAddressFree), reserved a larger one and mapped recycled chunks into it; on
+// ROCm 7.0 the next kernels then read through stale translations (fp64 error 4e-2 in the fuzz test).
+// The bisect of round 2 (profiles/r02_vmm_bisect.log: same test, five allocator policies) showed that a
+// device synchronisation before the unmap does NOT cure it and that never handing an address range back
+// does.  Hence:
+//   * a range GROWS IN PLACE: the reservation is larger than the first request (address space only) and
+//     later requests map more chunks behind the ones already there; nothing is unmapped while the buffer
+//     lives;
+//   * release() synchronises the device, unmaps and frees the physical chunks, and RETIRES the address
+//     range: it stays reserved for the life of the process, so no later mapping can ever alias it
+//     (costs address space only: at most max(2 x size, 1 GiB) of the 2^47-byte space per retired buffer);
+//   * a request beyond the reservation retires the range that way and starts a new one.
 struct DevMem {
   void* p = nullptr;
-  size_t bytes = 0;
-  size_t vmm_size = 0;  // > 0: p is a VMM mapping of that many bytes
+  size_t bytes = 0;     // usable bytes
+  bool streamed = false;  // eligible for the chunked mapping (set once by the owner)
+  // chunked mapping
+  size_t va_size = 0;   // > 0: p is a reserved address range of that many bytes
+  size_t mapped = 0;    // bytes mapped from its start (a multiple of chunk)
+  size_t chunk = 0;
+  struct Piece { hipMemGenericAllocationHandle_t h; size_t off; };
+  std::vector<Piece> pieces;
   DevMem() = default;
   DevMem(const DevMem&) = delete;
   DevMem& operator=(const DevMem&) = delete;
   ~DevMem() { release(); }
   void release() {
-    if (p && vmm_size) {
-      unmap_chunks(p, vmm_chunks.size());
-      (void)hipMemAddressFree(p, vmm_size);
+    if (p && va_size) {
+      (void)hipDeviceSynchronize();  // nothing in flight may still translate through the range
+      for (const Piece& pc : pieces) {
+        (void)hipMemUnmap((char*)p + pc.off, chunk);
+        (void)hipMemRelease(pc.h);
+      }
+      pieces.clear();
+      (void)hipGetLastError();  // the range itself is retired, never freed (see above)
     } else if (p) {
       (void)hipFree(p);
     }
     p = nullptr;
     bytes = 0;
-    vmm_size = 0;
+    va_size = 0;
+    mapped = 0;
   }
-  // the buffer as `chunk`-byte physical pieces mapped in a scrambled order into one address range
-  // (the default for large internal buffers, see vmm_chunk_bytes)
-  std::vector<hipMemGenericAllocationHandle_t> vmm_chunks;
-  size_t vmm_chunk = 0, vmm_mult = 1;  // piece size; piece i sits at slot (i * vmm_mult) % pieces
-  // unmap exactly what was mapped, piece by piece (the first `mapped` pieces), and drop the handles
-  void unmap_chunks(void* va, size_t mapped) {
-    const size_t nch = vmm_chunks.size();
-    for (size_t i = 0; i < nch; ++i) {
-      if (i < mapped) (void)hipMemUnmap((char*)va + ((i * vmm_mult) % nch) * vmm_chunk, vmm_chunk);
-      (void)hipMemRelease(vmm_chunks[i]);
-    }
-    vmm_chunks.clear();
-    (void)hipGetLastError();
-  }
-  int alloc_vmm(size_t n, size_t chunk) {
+  // map chunks so that [0, n) of the range is backed; false on any failure (the range stays consistent:
+  // what was mapped before the call is still mapped)
+  bool map_up_to(size_t n) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    const size_t want = (n + chunk - 1) / chunk * chunk;
+    if (want <= mapped) return true;
+    if (want > va_size) return false;
+    const size_t base = mapped, cnt = (want - mapped) / chunk;
+    size_t mult = 257;  // coprime with the piece count: a scrambled, fixed order that visits every slot once
+    while (cnt > 1 && std::gcd(mult, cnt) != 1) mult += 2;
+    const size_t first = pieces.size();
+    bool ok = true;
+    for (size_t i = 0; i < cnt && ok; ++i) {
+      hipMemGenericAllocationHandle_t h;
+      ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess;
+      if (!ok) break;
+      const size_t off = base + ((i * mult) % cnt) * chunk;
+      if (hipMemMap((char*)p + off, chunk, 0, h, 0) != hipSuccess) {
+        (void)hipMemRelease(h);
+        ok = false;
+        break;
+      }
+      pieces.push_back({h, off});
+    }
+    if (ok) {
+      hipMemAccessDesc acc = {};
+      acc.location = prop.location;
+      acc.flags = hipMemAccessFlagsProtReadWrite;
+      ok = hipMemSetAccess((char*)p + base, want - base, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {  // undo this call's pieces only
+      (void)hipDeviceSynchronize();
+      while (pieces.size() > first) {
+        (void)hipMemUnmap((char*)p + pieces.back().off, chunk);
+        (void)hipMemRelease(pieces.back().h);
+        pieces.pop_back();
+      }
+      (void)hipGetLastError();
+      return false;
+    }
+    mapped = want;
+    return true;
+  }
+  bool alloc_chunked(size_t n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = dev;
     size_t gran = 0;
     if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran)
-      return -1;
-    chunk = (chunk + gran - 1) / gran * gran;
-    const size_t nch = (n + chunk - 1) / chunk, size = nch * chunk;
+      return false;
+    size_t c = (size_t)2 << 20;
+    c = (c + gran - 1) / gran * gran;
+    const size_t need = (n + c - 1) / c * c;
+    // room to grow in place: twice the request, at least 1 GiB (address space only)
+    const size_t reserve = std::max<size_t>(2 * need, (size_t)1 << 30);
     void* va = nullptr;
-    if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) return -1;
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    vmm_chunks.clear();
-    bool ok = true;
-    for (size_t i = 0; i < nch && ok; ++i) {
-      hipMemGenericAllocationHandle_t h;
-      ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess;
-      if (ok) vmm_chunks.push_back(h);
-    }
-    size_t mult = 257;  // coprime with the piece count: a scrambled, fixed order that visits every slot once
-    while (nch > 1 && std::gcd(mult, nch) != 1) mult += 2;
-    vmm_chunk = chunk;
-    vmm_mult = mult;
-    size_t mapped = 0;
-    for (size_t i = 0; i < nch && ok; ++i) {
-      const size_t slot = (i * mult) % nch;
-      ok = hipMemMap((char*)va + slot * chunk, chunk, 0, vmm_chunks[i], 0) == hipSuccess;
-      if (ok) mapped = i + 1;
-    }
-    if (ok) ok = hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
-    if (!ok) {
-      unmap_chunks(va, mapped);
-      (void)hipMemAddressFree(va, size);
+    if (hipMemAddressReserve(&va, reserve, 0, nullptr, 0) != hipSuccess) {
       (void)hipGetLastError();
-      return -1;
+      return false;
     }
     p = va;
-    vmm_size = size;
-    bytes = n;
-    return 0;
-  }
-  int alloc(size_t n, bool plain = false) {  // plain: one hipMalloc (buffers handed to callers / peers)
-    release();
-    if (n == 0) n = 16;
-    if (!plain && vmm_chunk_bytes() && n >= ((size_t)32 << 20)) {
-      size_t chunk = vmm_chunk_bytes();
-      while ((n + chunk - 1) / chunk > 4096) chunk *= 2;  // at most 4096 pieces per buffer
-      if (alloc_vmm(n, chunk) == 0) return GSPX_OK;
-    }
-    (void)hipGetLastError();
-    static const bool contig = getenv("GSPX_CONTIG") && atoi(getenv("GSPX_CONTIG")) > 0;  // experiment
-    if (contig && n >= ((size_t)32 << 20)) {
-      if (hipExtMallocWithFlags(&p, n, hipDeviceMallocContiguous) == hipSuccess) {
-        bytes = n;
-        return GSPX_OK;
-      }
+    va_size = reserve;
+    chunk = c;
+    mapped = 0;
+    pieces.clear();
+    if (!map_up_to(n)) {  // nothing was ever mapped into this range: safe to hand back
+      (void)hipMemAddressFree(va, reserve);
       (void)hipGetLastError();
       p = nullptr;
+      va_size = 0;
+      return false;
     }
+    bytes = n;
+    return true;
+  }
+  int alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    if (streamed && n >= ((size_t)32 << 20) && alloc_chunked(n)) return GSPX_OK;
+    (void)hipGetLastError();
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) {
       p = nullptr;
@@ -184,15 +211,11 @@ struct DevMem {
   }
   int ensure(size_t n) {  // grow-only
     if (n <= bytes && p) return GSPX_OK;
+    if (p && va_size && n <= va_size && map_up_to(n)) {  // grow in place
+      bytes = n;
+      return GSPX_OK;
+    }
     return alloc(n);
-  }
-  void swap(DevMem& o) {
-    std::swap(p, o.p);
-    std::swap(bytes, o.bytes);
-    std::swap(vmm_chunks, o.vmm_chunks);
-    std::swap(vmm_chunk, o.vmm_chunk);
-    std::swap(vmm_mult, o.vmm_mult);
-    std::swap(vmm_size, o.vmm_size);
   }
   template <typename T> T* as() const { return (T*)p; }
 };
@@ -206,25 +229,16 @@ struct Options {
   int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
   int64_t narrow_g_log2 = -1;  // -1 = auto (4 lanes per row in total)
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
-  int64_t interleave = 0;       // panel kernel: waves of a workgroup advance as one front
   int64_t newton_pair = 1;      // use the fused two-step kernel when the graph carries tiles
   int64_t pair_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
-  int64_t tile_dynamic = 0;     // 1: blocks handed out by per-XCD ticket counters; 0: static walk
-  int64_t tile_extra_every = 0; // static walk: extra half round for the first-dispatched workgroups every E rounds
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
-  int64_t placement_probe = 0;  // candidates tried when a large workspace is first allocated (0 / 1: none)
-  int64_t panel_gap = 0;        // bytes between the T_k slots of the workspace (placement experiments)
-  int64_t racc_shift = 0;       // byte offset of the accumulator inside its workspace (placement experiments)
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
   int64_t tile_nt = -1;         // k_step_tile non-temporal accesses: bit 0 matrix entries, bit 2 T_{k-2} loads (each
                                 // -1 % on panels beyond the 256 MB Infinity Cache, +5 % each on panels that fit in
                                 // it); bit 1 accumulator, bit 3 T_k stores (no effect).  -1: 5 for panels >= 192 MiB
-  int64_t tile_xcd_flip = 0;    // XCDs with odd parity of (id & mask) walk their block range in the opposite direction
-  int64_t tile_prio = 0;        // experiment: wave priorities of the younger workgroups
-  int64_t tile_stamps = 0;      // profiling: record per-workgroup entry/exit clocks of k_step_tile launches
   int64_t synthesis = 0;        // 0 vector-coefficient Clenshaw (K products), 1 per-filter loop
   int64_t alternate_sweep = 1;  // 1: odd steps sweep the rows backwards (Infinity-Cache reuse, -3..5 %)
   int64_t xcd_remap = 1;
@@ -243,16 +257,11 @@ struct gspx_ctx {
   DevMem ws_r;      // accumulators
   DevMem ws_w;      // per-step flush weights / combine coefficients
   DevMem io_x, io_y;  // staging for the host-pointer entry point
-  DevMem tickets;     // k_step_tile's ticket counters (zero between launches)
-  DevMem stamps;      // tile_stamps: [64 launches][workgroups][2] wall clocks
-  int64_t stamp_launches = 0;
-  unsigned stamp_nwg = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev_pool;
   double timing[5] = {0, 0, 0, 0, 0};
   // hipGraph replay of a repeated identical filter call (launch-bound small graphs)
   bool capturing = false;     // run_batch is being recorded: no copies, syncs or events inside
-  bool probing = false;       // probe_placement is timing candidate workspaces
   uint64_t seen_key = 0;      // key of the last eager call
   uint64_t graph_key = 0;     // key the instantiated graph was captured for
   hipGraphExec_t graph_exec = nullptr;
@@ -343,6 +352,8 @@ extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
   HIPCHK(hipSetDevice(device));
   gspx_ctx* ctx = new gspx_ctx();
   ctx->device = device;
+  ctx->ws_t.streamed = true;  // the two workspaces the recurrence streams every step
+  ctx->ws_r.streamed = true;
   if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device) !=
           hipSuccess ||
       ctx->cu_count < 1)
@@ -399,7 +410,6 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "rows_per_wave")) return &o.rows_per_wave;
   if (!strcmp(key, "narrow_g_log2")) return &o.narrow_g_log2;
   if (!strcmp(key, "waves_per_block")) return &o.waves_per_block;
-  if (!strcmp(key, "interleave")) return &o.interleave;
   if (!strcmp(key, "alternate_sweep")) return &o.alternate_sweep;
   if (!strcmp(key, "synthesis")) return &o.synthesis;
   if (!strcmp(key, "newton_pair")) return &o.newton_pair;
@@ -407,16 +417,8 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_gather")) return &o.tile_gather;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
-  if (!strcmp(key, "tile_stamps")) return &o.tile_stamps;
-  if (!strcmp(key, "tile_dynamic")) return &o.tile_dynamic;
-  if (!strcmp(key, "tile_extra_every")) return &o.tile_extra_every;
-  if (!strcmp(key, "tile_prio")) return &o.tile_prio;
-  if (!strcmp(key, "tile_xcd_flip")) return &o.tile_xcd_flip;
   if (!strcmp(key, "tile_nt")) return &o.tile_nt;
   if (!strcmp(key, "fuse_input")) return &o.fuse_input;
-  if (!strcmp(key, "panel_gap")) return &o.panel_gap;
-  if (!strcmp(key, "placement_probe")) return &o.placement_probe;
-  if (!strcmp(key, "racc_shift")) return &o.racc_shift;
   if (!strcmp(key, "edge_vertex_walk")) return &o.edge_vertex_walk;
   if (!strcmp(key, "xcd_remap")) return &o.xcd_remap;
   if (!strcmp(key, "combine")) return &o.combine;
@@ -460,7 +462,7 @@ extern "C" int gspx_buf_alloc(gspx_ctx* ctx, int64_t bytes, gspx_buf** out) {
   gspx_buf* b = new gspx_buf();
   b->ctx = ctx;
   b->bytes = bytes;
-  int rc = b->mem.alloc((size_t)bytes, true);  // caller-visible memory: one plain allocation (peer copies, interop)
+  int rc = b->mem.alloc((size_t)bytes);  // caller-visible memory: one plain allocation (peer copies, interop)
   if (rc != GSPX_OK) {
     delete b;
     return rc;
@@ -1361,7 +1363,6 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
   if (s.kernel == 4 && rpw > 32) rpw = 32;
   a.rows_per_wave = rpw;
   a.wpb = (s.kernel == 1) ? (int)opt.waves_per_block : 4;
-  a.interleave = (s.kernel == 1 && opt.interleave) ? 1 : 0;
   if (s.kernel == 1 || s.kernel >= 3)
     rows_per_chunk = a.wpb * rpw;
   else
@@ -1552,30 +1553,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)g->ctx->cu_count) / 8 * 8);
   if (opt.tile_workgroups > 0)
     nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
-  t.extra_every = opt.tile_dynamic ? 0 : (int)opt.tile_extra_every;  // the ticket walk has its own static prefix
-  t.prio_mode = (int)opt.tile_prio;
-  t.xcd_flip = (int)opt.tile_xcd_flip;
   t.nt = opt.tile_nt >= 0 ? (int)opt.tile_nt : ((size_t)g->N * ld * sizeof(T) >= ((size_t)192 << 20) ? 5 : 0);
-  t.tickets = nullptr;
-  if (opt.tile_dynamic) {
-    gspx_ctx* c = g->ctx;
-    if (!c->tickets.p) {
-      if (c->capturing) return set_err(GSPX_ERR_INVALID, "tile tickets must exist before a graph capture");
-      CHK(c->tickets.alloc(64));
-      HIPCHK(hipMemsetAsync(c->tickets.p, 0, 64, st));
-    }
-    t.tickets = c->tickets.as<int>();
-  }
-  t.stamps = nullptr;
-  if (opt.tile_stamps) {
-    gspx_ctx* c = g->ctx;
-    if (c->stamp_nwg != nwg) {
-      CHK(c->stamps.ensure((size_t)64 * nwg * 2 * sizeof(long long)));
-      c->stamp_nwg = nwg;
-      c->stamp_launches = 0;
-    }
-    t.stamps = c->stamps.as<long long>() + (size_t)(c->stamp_launches++ % 64) * nwg * 2;
-  }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), g->gt_lds, st, t);
   return GSPX_OK;
 }
@@ -1621,14 +1599,11 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   }
 
   const size_t nslots = deferred ? (size_t)M : 2;
-  // slot pitch / accumulator offset: U plus an optional gap (placement experiments, options panel_gap /
-  // racc_shift in bytes, multiples of 256)
-  const size_t SU = U + (size_t)(opt.panel_gap & ~(int64_t)255) / sizeof(T);
-  const size_t rshift = (size_t)(opt.racc_shift & ~(int64_t)255) / sizeof(T);
+  const size_t SU = U;  // slot pitch
   CHK(ctx->ws_t.ensure(nslots * SU * sizeof(T) + 256));
-  if (!deferred) CHK(ctx->ws_r.ensure(((size_t)nf * U + rshift) * sizeof(T) + 256));
+  if (!deferred) CHK(ctx->ws_r.ensure((size_t)nf * U * sizeof(T) + 256));
   T* slots = ctx->ws_t.as<T>();
-  T* racc = ctx->ws_r.as<T>() + rshift;
+  T* racc = ctx->ws_r.as<T>();
 
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   if (!cap) {
@@ -1766,66 +1741,6 @@ template <typename T>
 static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                         int64_t Nsig, const T* x, T* y, int mode);
 
-// Where the driver places a large workspace matters: the same recurrence runs 0.36 ms or 0.39 ms per
-// order (1M x 64 fp64) depending on the physical memory behind the two T_k slots - stable for the life
-// of the allocation, different from one allocation to the next, independent of the distances between the
-// panels (tools/experiments/exp_layout*.py).  So a large workspace is not taken as it comes: a few
-// candidates are allocated side by side, each runs a short filter (six orders on a zero panel), the
-// fastest stays and the others are freed.  Costs a few milliseconds, once per workspace size.
-template <typename T>
-static int probe_placement(gspx_graph* g, double lmax, int64_t Nsig, size_t need_t, size_t need_r) {
-  gspx_ctx* ctx = g->ctx;
-  const int tries = (int)std::min<int64_t>(ctx->opt.placement_probe, 8);
-  struct Guard {
-    gspx_ctx* c;
-    ~Guard() { c->probing = false; }
-  } guard{ctx};
-  ctx->probing = true;
-  const size_t pb = (size_t)g->N * (size_t)Nsig * sizeof(T);
-  DevMem px, py;
-  CHK(px.alloc(pb));
-  CHK(py.alloc(pb));
-  HIPCHK(hipMemsetAsync(px.p, 0, pb, ctx->stream));
-  const double cf[7] = {1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125, 0.015625};
-  std::vector<std::unique_ptr<DevMem>> cand;
-  int best = -1;
-  double best_ms = 0;
-  for (int i = 0; i < tries; ++i) {
-    cand.emplace_back(new DevMem());
-    cand.emplace_back(new DevMem());
-    DevMem& ct = *cand[(size_t)2 * i];
-    DevMem& cr = *cand[(size_t)2 * i + 1];
-    if (ct.alloc(need_t) != GSPX_OK || cr.alloc(need_r) != GSPX_OK) {  // out of memory: use what there is
-      (void)hipGetLastError();
-      ct.release();
-      cr.release();
-      break;
-    }
-    HIPCHK(hipMemsetAsync(ct.p, 0, need_t, ctx->stream));
-    HIPCHK(hipMemsetAsync(cr.p, 0, need_r, ctx->stream));
-    ctx->ws_t.swap(ct);
-    ctx->ws_r.swap(cr);
-    double ms = 0;
-    int rc = GSPX_OK;
-    for (int rep = 0; rep < 2 && rc == GSPX_OK; ++rep) {  // the second run is the measurement
-      rc = filter_dev_t<T>(g, lmax, 1, 7, cf, Nsig, px.as<T>(), py.as<T>(), GSPX_ANALYSIS);
-      ms = ctx->timing[1];
-    }
-    ctx->ws_t.swap(ct);
-    ctx->ws_r.swap(cr);
-    if (rc != GSPX_OK) return rc;
-    if (best < 0 || ms < best_ms) {
-      best = i;
-      best_ms = ms;
-    }
-  }
-  if (best >= 0) {
-    ctx->ws_t.swap(*cand[(size_t)2 * best]);
-    ctx->ws_r.swap(*cand[(size_t)2 * best + 1]);
-  }
-  return GSPX_OK;
-}
-
 template <typename T>
 static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                         int64_t Nsig, const T* x, T* y, int mode) {
@@ -1835,17 +1750,6 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
   for (int i = 0; i < 5; ++i) ctx->timing[i] = 0;
   if (N == 0 || Nsig == 0) return GSPX_OK;
   CHK(ensure_factor<T>(g, lmax));
-  {  // a large single-filter workspace about to be (re)allocated: choose its placement by measurement
-    const size_t U1 = (size_t)N * (size_t)Nsig * sizeof(T);
-    const size_t need_t = 2 * U1 + 256, need_r = U1 + 256;
-    if (opt.placement_probe > 1 && !ctx->probing && !ctx->capturing && Nf == 1 && mode == GSPX_ANALYSIS &&
-        U1 >= ((size_t)128 << 20) && U1 < ((size_t)1 << 31) - 65536 && ctx->ws_t.bytes < need_t &&
-        3 * U1 <= ((size_t)std::max<int64_t>(opt.ws_limit_mb, 1) << 20)) {
-      CHK(probe_placement<T>(g, lmax, Nsig, need_t, need_r));
-      for (int i = 0; i < 5; ++i) ctx->timing[i] = 0;
-    }
-  }
-
   std::vector<double> cp;
   halve_c0(Nf, M, coeffs, cp);
 
@@ -2607,35 +2511,6 @@ extern "C" int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double
 // calibration: streaming copy with the engine's own 16-byte-per-lane copy kernel (k_permute_in
 // without a permutation) - the measured HBM ceiling quoted beside every roofline fraction.
 // ------------------------------------------------------------------------------------------------
-// placement experiments: device addresses of the context's workspaces (T_k slots, accumulators, weights)
-extern "C" int gspx_debug_workspace(gspx_ctx* ctx, void* out[3], int64_t bytes[3]) {
-  if (!ctx || !out || !bytes) return set_err(GSPX_ERR_INVALID, "gspx_debug_workspace: null argument");
-  out[0] = ctx->ws_t.p; out[1] = ctx->ws_r.p; out[2] = ctx->ws_w.p;
-  bytes[0] = (int64_t)ctx->ws_t.bytes; bytes[1] = (int64_t)ctx->ws_r.bytes;
-  bytes[2] = ctx->ws_t.vmm_size ? 1 : 0;  // 1: the slots are a VMM mapping
-  return GSPX_OK;
-}
-
-// profiling hook: clocks recorded by the last (at most 64) k_step_tile launches under option
-// "tile_stamps"; out[launch][workgroup][2] (100 MHz wall clock at entry, exit)
-extern "C" int gspx_debug_tile_stamps(gspx_ctx* ctx, int64_t* out, int64_t capacity, int64_t* launches,
-                                      int* workgroups) {
-  if (!ctx || !launches || !workgroups) return set_err(GSPX_ERR_INVALID, "gspx_debug_tile_stamps: null argument");
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  const int64_t n = std::min<int64_t>(ctx->stamp_launches, 64);
-  *launches = n;
-  *workgroups = (int)ctx->stamp_nwg;
-  const int64_t want = n * ctx->stamp_nwg * 2;
-  if (out && want > 0) {
-    if (capacity < want) return set_err(GSPX_ERR_INVALID, "gspx_debug_tile_stamps: buffer too small");
-    if (ctx->stamp_launches > 64) return set_err(GSPX_ERR_INVALID, "gspx_debug_tile_stamps: more than 64 launches recorded");
-    HIPCHK(hipMemcpy(out, ctx->stamps.p, (size_t)want * sizeof(long long), hipMemcpyDeviceToHost));
-  }
-  ctx->stamp_launches = 0;
-  return GSPX_OK;
-}
-
 extern "C" int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps) {
   if (!ctx || !gbps || bytes < 4096 || iters < 1)
     return set_err(GSPX_ERR_INVALID, "gspx_bench_copy: bad argument");

@@ -156,9 +156,6 @@ template <typename T> struct StepArgs {
   // row -> workgroup mapping
   int rows_per_wave;
   int wpb;          // waves per workgroup (panel kernel: 4, 8 or 16)
-  int interleave;   // panel kernel: 1 = the workgroup's waves advance through its rows as one
-                    // front (wave w takes row sets w, w+wpb, ...), 0 = each wave owns a
-                    // contiguous run of rows
   int nchunks;      // number of (wpb*rows_per_wave)-row chunks
   int cpx;          // chunks per XCD (xcd_remap) or 0 for plain order
   int reverse;      // 1: sweep the rows from the end (alternate steps: the tail of the previous
@@ -445,9 +442,8 @@ __global__ __launch_bounds__(1024) void k_step_panel(const int* __restrict__ row
   c.rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
   c.rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
   c.rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
-  c.row0 = a.interleave ? chunk * a.wpb * a.rows_per_wave + wave * R
-                        : (chunk * a.wpb + wave) * a.rows_per_wave;
-  c.set_stride = a.interleave ? a.wpb * R : R;
+  c.row0 = (chunk * a.wpb + wave) * a.rows_per_wave;  // each wave owns a contiguous run of rows
+  c.set_stride = R;
   c.nsets = a.rows_per_wave / R;
 
   if (c.row0 >= a.N) return;

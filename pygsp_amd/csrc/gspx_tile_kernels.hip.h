@@ -53,18 +53,10 @@ template <typename T> struct TileArgs {
   int nin;
   int flush;     // 0 none, 1 write, 2 accumulate
   int final;     // 1: the flush result goes to y (caller's order)
-  long long* stamps;  // profiling hook (nullable): per workgroup, wall clock at entry and exit
-  // dynamic block hand-out (nullable: static walk): [0..8) per-XCD ticket counters, [8] finished
-  // workgroups; all zero between launches (the last workgroup to finish resets them)
-  int* tickets;
-  // static walk: the first-dispatched half of the workgroups (one per CU; they win the CU's issue
-  // arbitration and run ~8 % faster) take an extra half-width round after every `extra_every` rounds
-  int extra_every;
   int reverse;    // 1: every XCD walks its block range from the end (odd steps: the tail of the previous
                   // step's panels is still in the Infinity Cache)
-  int nt;         // experiment: 1 = matrix entries loaded non-temporal (keep them out of the Infinity Cache)
-  int xcd_flip;   // mask over the XCD id: XCDs with odd parity of (id & mask) walk their range the other way
-  int prio_mode;  // experiment: 1 = younger workgroups raise their wave priority, 2 = alternate per block
+  int nt;         // non-temporal accesses: bit 0 matrix entries, bit 1 accumulator, bit 2 T_{k-2} rows,
+                  // bit 3 T_k stores (keeps streamed data out of the Infinity Cache)
 };
 
 constexpr int GSPX_TILE_BR = 64;      // rows per block
@@ -94,21 +86,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   int k1 = xlo + a.per_xcd;
   if (k1 > a.nb) k1 = a.nb;
   const int k0 = xlo + (int)(blockIdx.x >> 3);
-  __shared__ int s_ticket;
-  const int xcd = (int)(blockIdx.x & 7);
-  auto finish = [&]() {
-    if (a.tickets && tid == 0) {
-      if (atomicAdd(a.tickets + 8, 1) == (int)gridDim.x - 1) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) atomicExch(a.tickets + i, 0);
-      }
-    }
-  };
-  if (k0 >= k1) {
-    finish();
-    return;
-  }
-  if (a.stamps && tid == 0) a.stamps[2 * blockIdx.x] = wall_clock64();
+  if (k0 >= k1) return;
 
   constexpr u32 POISON = 0x80000000u;
   const rsrc_t rcur = __builtin_amdgcn_make_buffer_rsrc((void*)a.cur, 0, a.panel_bytes, 0x00020000);
@@ -121,7 +99,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   struct Meta { int rows[ST]; int rp[RPG + 1]; int orow[OLDNAT ? RPG : 1]; };
   // walk position -> block: the XCD's range front to back, or back to front
   const int xflip = xlo + k1 - 1;
-  const bool rev = (a.reverse != 0) != ((__builtin_popcount((int)(blockIdx.x & 7) & a.xcd_flip) & 1) != 0);
+  const bool rev = a.reverse != 0;
   auto phys = [&](int p) { return rev ? xflip - p : p; };
   auto load_hdr = [&](int p) { return *(const int4*)(a.hdr + (size_t)phys(p) * 4); };
   auto uniform = [](int4 h) {
@@ -163,22 +141,10 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
 
   int4 H = uniform(load_hdr(k0));
   Meta M = load_meta(k0, H);
-  // the workgroup's blocks: k now, kn next (row lists prefetched), knn after that (header prefetched).
-  // The first three are the static walk; with tickets the rest are handed out in order per XCD, which
-  // evens out the finish times of the persistent workgroups.
-  const int slot = (int)(blockIdx.x >> 3), E = a.extra_every;
-  const bool slow_half = slot >= (nwx >> 1);
-  auto blk = [&](int i) {  // the i-th block this workgroup visits (static walk)
-    if (E <= 0) return k0 + i * nwx;
-    const int r = slow_half ? i + i / E : i;  // the slow half skips the half-width rounds
-    return k0 + r * nwx - (r / (E + 1)) * (nwx >> 1);
-  };
-  int vi = 3;
-  int k = k0, kn = blk(1), knn = blk(2);
-  if (a.prio_mode == 1 && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
+  // the workgroup's blocks (a static, strided walk of its XCD's range): k now, kn next (row lists
+  // prefetched), knn after that (header prefetched)
+  int k = k0, kn = k0 + nwx, knn = k0 + 2 * nwx;
   int4 Hn = uniform(load_hdr(kn < k1 ? kn : k0));
-  int tkt = -1;  // thread 0: the ticket drawn one block ago (a returning atomic takes microseconds on a
-                 // loaded chip; it is consumed a whole block later and never waited for)
   if (H.y >= 0) stage(M, H.y, chunk_off(0));
 
   // one pass = column chunk c of block k; returns false after the workgroup's last pass
@@ -251,18 +217,9 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
         *(u32x4*)((unsigned char*)midx + i * 16) =
             __builtin_amdgcn_raw_buffer_load_b128(ri, (u32)rp0 + i * 16u, 0, 0);
     }
-    if (last && a.tickets && tid == 0) s_ticket = tkt;
     __syncthreads();  // tile and entries in place
     int4 Hnn = Hn;
-    int knnn = blk(vi);
-    if (last) {
-      Hnn = uniform(Hv);  // youngest load of the pass: everything prefetched has landed
-      if (a.tickets) {
-        const int tk = __builtin_amdgcn_readfirstlane(s_ticket);
-        if (tk >= 0) knnn = xlo + 4 * nwx + tk;  // rounds 0..3 are the static walk
-        if (tid == 0) tkt = atomicAdd(a.tickets + xcd, 1);
-      }
-    }
+    if (last) Hnn = uniform(Hv);  // youngest load of the pass: everything prefetched has landed
     V nv[RPG], cv[RPG];
     if (fast) {
 #pragma unroll
@@ -293,7 +250,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
       }
     }
     // everybody is done with the tile (their LDS reads were consumed above).  A bare barrier: the
-    // fence of __syncthreads() would wait for the ticket atomic still in flight.
+    // fence of __syncthreads() would also wait for the prefetches still in flight.
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
     __builtin_amdgcn_s_barrier();
     bool more = true;
@@ -332,12 +289,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     if (last) {
       k = kn;
       kn = knn;
-      knn = knnn;
-      ++vi;
-      if (a.prio_mode == 2) {
-        if ((vi + (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-      }
+      knn += nwx;
     }
     return more;
   };
@@ -353,8 +305,6 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
       if (!more) break;
     }
   }
-  if (a.stamps && tid == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();
-  finish();
 }
 
 }  // namespace gspx

@@ -1,0 +1,102 @@
+"""BASELINE.json configs 1-4 and the headline workload at (or near) their full sizes: oracle columns plus
+size-independent properties (linearity, the constant-signal identity p(L) 1 = p(0) 1, reorder invariance).
+Through the C-ABI on a real MI355X (`-m gpu`)."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import csr_from, rel_err
+from gpu_helpers import BAR, TOL, ctx, random_graph, upper_lmax  # noqa: F401 (ctx is a fixture)
+from oracle import cheby_oracle as orc
+from pygsp_amd import _capi, engine, filters, graphs
+
+pytestmark = pytest.mark.gpu
+
+
+def _constant_signal_gain(c):
+    """L 1 = 0  =>  T_k(L~) 1 = (-1)^k 1, so filtering a constant multiplies it by
+    0.5 c0 + sum_k (-1)^k c_k."""
+    k = np.arange(1, len(c))
+    return 0.5 * c[0] + np.sum(((-1.0) ** k) * c[1:])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_config1_sensor100k_single_signal(dtype):
+    """BASELINE.json configs[1]: Sensor(100000), combinatorial, Heat, K=30, 1 signal."""
+    G = graphs.Sensor(100000, seed=42, compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    h = filters.Heat(G, scale=50)
+    s = np.random.default_rng(0).standard_normal(G.N)
+    y = h.filter(s, order=30)
+    L = orc.laplacian(G.W)
+    ref = orc.filter_chebyshev(L, G.lmax, [orc.heat_kernel(50, G.lmax)], s, 30)
+    assert rel_err(y, ref) < BAR[np.dtype(dtype)] * 1e-2
+    assert abs(G.L - L).max() < (1e-13 if dtype == np.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_headline_size_properties(ctx, dtype):
+    """North-star size: 1M-vertex k=8 sensor graph (~10M stored entries), 64 signals, order 30.
+    Oracle on 2 sampled columns; linearity and the constant-signal identity on all 64."""
+    N, nsig, order = 1000000, 64, 30
+    W, coords = graphs.sensor_weights(N, k=8, seed=42)
+    G = graphs.Graph(W, coords=coords, compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    lmax = G.lmax
+    c = orc.compute_cheby_coeff(orc.heat_kernel(50, lmax), lmax, order)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((N, nsig)).astype(dtype)
+    x[:, 5] = 3.0  # a constant column
+    dev = G.device_graph()
+    y, ms = dev.cheby_filter(c, x, lmax)
+    y = y[0]
+    tol = BAR[np.dtype(dtype)]
+    # constant-signal identity
+    gain = _constant_signal_gain(c)
+    assert np.max(np.abs(y[:, 5] - 3.0 * gain)) < tol * abs(3.0 * gain)
+    # oracle on two columns
+    L = orc.laplacian(W)
+    cols = [0, 63]
+    ref = orc.cheby_op(L, lmax, c, x[:, cols].astype(np.float64))
+    assert rel_err(y[:, cols], ref) < tol * 1e-1
+    # linearity: f(2 x_a - x_b) = 2 f(x_a) - f(x_b), columnwise
+    x2 = (2 * x[:, :32] - x[:, 32:]).astype(dtype)
+    y2, _ = dev.cheby_filter(c, x2, lmax)
+    lin = 2 * y[:, :32].astype(np.float64) - y[:, 32:].astype(np.float64)
+    assert rel_err(y2[0], lin) < (1e-10 if dtype == np.float64 else 1e-3)
+    # vertex order is internal: the device graph without reordering gives the same answer
+    dev_plain = engine.DeviceGraph.from_w(W, dtype=dtype, perm=None, ctx=ctx)
+    y3, _ = dev_plain.cheby_filter(c, x[:, :4], lmax)
+    assert rel_err(y3[0], y[:, :4]) < (1e-11 if dtype == np.float64 else 1e-4)
+    dev_plain.destroy()
+
+
+def test_erdos_renyi_filterbank_fp32():
+    """Scaled-down BASELINE.json configs[2]: ER graph (isolated vertices occur), MexicanHat x6,
+    K=50, fp32 engine vs fp64 oracle at the 1e-3 bar."""
+    N = 200000
+    G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=np.float32)
+    G.estimate_lmax("bounds")
+    assert G.W.dtype == np.int64
+    mh = filters.MexicanHat(G, Nf=6)
+    x = np.random.default_rng(1).standard_normal((N, 16)).astype(np.float32)
+    y = mh.filter(x, order=50)
+    assert y.shape == (N, 16, 6)
+    L = orc.laplacian(G.W.astype(np.float64))
+    ref = orc.filter_chebyshev(L, G.lmax, orc.mexican_hat_kernels(G.lmax, 6), x[:, :2].astype(np.float64), 50)
+    assert rel_err(y[:, :2, :], ref) < 1e-3 * 1e-1
+
+
+def test_sbm_normalized_isolated_rule():
+    """Scaled-down BASELINE.json configs[3]: SBM, normalized Laplacian, 16 signals."""
+    N, k = 100000, 16
+    G = graphs.StochasticBlockModel(N, k=k, p=12.0 * k / N, q=4.0 * k / (N * (k - 1)), seed=0,
+                                    lap_type="normalized")
+    G.estimate_lmax("bounds")
+    assert G.lmax == 2
+    L = orc.laplacian(G.W.astype(np.float64), "normalized")
+    assert abs(G.L - L).max() < 1e-14 and G.L.nnz == L.nnz
+    x = np.random.default_rng(2).standard_normal((N, 16))
+    y = filters.Heat(G, 10).filter(x, order=30)
+    ref = orc.filter_chebyshev(L, 2.0, [orc.heat_kernel(10, 2.0)], x[:, :3], 30)
+    assert rel_err(y[:, :3], ref) < 1e-11

@@ -1,0 +1,49 @@
+"""estimate_lmax by Lanczos on the device (graph.py:858-931) and the
+cheby_rect / Jackson siblings (approximations.py:117-225) against reference goldens.  `-m gpu`."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import csr_from, rel_err
+from gpu_helpers import BAR, TOL, ctx, random_graph, upper_lmax  # noqa: F401 (ctx is a fixture)
+from oracle import cheby_oracle as orc
+from pygsp_amd import _capi, engine, filters, graphs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_device_lanczos_lmax(golden_logo, dtype):
+    from scipy.sparse import linalg as spl
+    cases = [graphs.Sensor(3000, seed=1, compute_dtype=dtype),
+             graphs.Graph(random_graph(2500, 7, seed=3, hub=True, isolated=3), compute_dtype=dtype),
+             graphs.Graph(csr_from(golden_logo, "W"), compute_dtype=dtype),
+             graphs.Sensor(20000, seed=2, lap_type="normalized", compute_dtype=dtype)]
+    for G in cases:
+        true = spl.eigsh(orc.laplacian(G.W.astype(np.float64), G.lap_type), k=1, tol=1e-10,
+                         return_eigenvectors=False)[0]
+        ritz, iters = G.device_graph().lanczos_lmax(max_iter=80, tol=5e-4)
+        assert iters <= 80
+        # a Ritz value: never above the true eigenvalue, and within the reference's tolerance
+        assert ritz <= true * (1 + (1e-9 if dtype == np.float64 else 1e-5))
+        assert ritz >= true * (1 - 5e-3)
+        G.estimate_lmax()  # default method 'lanczos' -> device
+        assert true <= G.lmax <= 1.0101 * true  # the 1 % margin makes it an upper bound
+        first = G.lmax
+        G._lmax_method = None
+        G.estimate_lmax("lanczos")
+        assert G.lmax == first  # deterministic, unlike ARPACK's random start
+    # the golden Logo value of graph.py:891-900: lambda_max = 13.78, Lanczos estimate 13.92
+    Gl = cases[2]
+    assert abs(Gl.lmax - 13.92) < 0.05
+    with pytest.raises(ValueError):
+        Gl.estimate_lmax("fancy")
+
+
+def test_cheby_rect_golden(golden_sensor123):
+    """approximations.py:117-163: ideal band-pass, same recurrence, closed-form coefficients."""
+    g = golden_sensor123
+    G = graphs.Graph(csr_from(g, "W"))
+    G._lmax = float(g["lmax"])
+    assert rel_err(filters.cheby_rect(G, list(g["rect_bounds"]), g["signal"], order=30), g["rect_y"]) < 1e-12
+    assert rel_err(filters.cheby_rect(G, g["rect_bounds"], g["signals5"], order=25), g["rect_y5"]) < 1e-12

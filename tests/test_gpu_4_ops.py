@@ -14,7 +14,7 @@ from scipy import sparse
 from conftest import csr_from, rel_err
 from oracle import ops_oracle as ops
 from pygsp_amd import engine, graphs, learning
-from test_gpu_parity import random_graph
+from gpu_helpers import random_graph
 
 pytestmark = pytest.mark.gpu
 

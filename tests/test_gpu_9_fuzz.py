@@ -7,7 +7,7 @@ import pytest
 
 from oracle import cheby_oracle as orc
 from pygsp_amd import _capi, engine, filters, graphs
-from test_gpu_parity import random_graph, upper_lmax
+from gpu_helpers import random_graph, upper_lmax
 
 pytestmark = pytest.mark.gpu
 

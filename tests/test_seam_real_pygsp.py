@@ -1,0 +1,68 @@
+"""The drop-in seam against the REAL reference: the reference's own
+`pygsp/tests/test_filters.py` is run, unmodified, in a subprocess with `pygsp_amd.plugin.install()`
+applied to the real `pygsp` package; every `Filter.filter(method='chebyshev')` in it then goes through
+`pygsp_amd.filters.cheby_op` (filter.py:305-322 -> approximations.cheby_op).  There is no GPU in the
+build container, so the device object is replaced by an oracle-backed stand-in (tests/seam_plugin.py,
+test infrastructure only); on the GPU box `/root/reference` does not exist and the test is skipped -
+there the same seam is exercised on hardware by tests/test_gpu_2_kernels.py::test_plugin_patches_a_pygsp_like_module."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pygsp", "tests")),
+                                reason="needs the reference checkout at /root/reference")
+
+
+def _run_reference_tests(tmp_path, test_file):
+    report = tmp_path / "seam.json"
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([REF, ROOT, os.path.join(ROOT, "tests")])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"  # nothing is written under /root/reference
+    env["GSPX_SEAM_REPORT"] = str(report)
+    env["MPLBACKEND"] = "Agg"
+    cmd = [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "-p", "seam_plugin", "-q", "--no-header",
+           "-o", "addopts=", "--rootdir", str(tmp_path), os.path.join(REF, "pygsp", "tests", test_file)]
+    res = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1500)
+    calls = json.loads(report.read_text()) if report.exists() else {}
+    return res, calls
+
+
+def test_reference_test_filters_passes_through_the_patched_seam(tmp_path):
+    res, calls = _run_reference_tests(tmp_path, "test_filters.py")
+    tail = res.stdout[-3000:] + res.stderr[-2000:]
+    assert res.returncode == 0, tail
+    assert " passed" in res.stdout and "failed" not in res.stdout, tail
+    # the reference's file holds 25 tests; all of them must have run
+    n_passed = int(res.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1])
+    assert n_passed >= 25, tail
+    # ... and the Chebyshev calls really went through the product's cheby_op
+    assert calls.get("cheby_op", 0) >= 50 and calls.get("graphs", 0) >= 1, calls
+
+
+def test_reference_doctest_value_through_the_seam(tmp_path):
+    """filter.py:255-256 (the doctest of Filter.filter): Sensor(30, seed=42), MexicanHat x 3 signals,
+    analysis then synthesis, 0.27649 - through the patched real pygsp."""
+    script = tmp_path / "doctest_case.py"
+    script.write_text(
+        "import numpy as np\n"
+        "from pygsp import graphs, filters\n"
+        "def test_case():\n"
+        "    G = graphs.Sensor(30, seed=42)\n"
+        "    G.compute_fourier_basis()  # reproducible lmax, as the doctest does\n"
+        "    s1 = np.zeros(G.N); s1[13] = 1\n"
+        "    s1 = filters.Heat(G, 3).filter(s1)\n"
+        "    g = filters.MexicanHat(G, Nf=4)\n"
+        "    s2 = g.analyze(s1)\n"
+        "    assert s2.shape == (30, 4)\n"
+        "    s3 = g.synthesize(s2)\n"
+        "    assert s3.shape == (30,)\n"
+        "    assert '{:.5f}'.format(np.linalg.norm(s1 - s3)) == '0.27649'\n")
+    res, calls = _run_reference_tests(tmp_path, str(script))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert calls.get("cheby_op", 0) >= 3, calls
