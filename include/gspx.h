@@ -291,8 +291,11 @@ int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, doubl
  * pygsp/graphs/graph.py:911-917).  Deterministic (fixed start vector).  Returns the largest Ritz
  * value (<= lambda_max); stops when the residual of the Ritz pair is below `tol` * value (an
  * eigenvalue of L lies within that distance; the reference asks ARPACK for 5e-3) or after
- * `max_iter` steps.  The caller applies the reference's 1 % margin (graph.py:920). */
-int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int* iterations);
+ * `max_iter` steps; *converged (nullable) tells which: 0 = the step budget ran out first, and the value
+ * may sit well below lambda_max - the reference raises ValueError in that case (ArpackNoConvergence,
+ * graph.py:918-919) and so must the caller.  The caller applies the reference's 1 % margin (graph.py:920). */
+int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax, int* iterations,
+                      int* converged);
 
 /* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two
  * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */

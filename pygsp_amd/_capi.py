@@ -101,7 +101,7 @@ SIGNATURES = {
     "gspx_last_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "gspx_plan_describe": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P]),
     "gspx_lanczos_lmax": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.POINTER(_c.c_double),
-                                     _c.POINTER(_c.c_int)]),
+                                     _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "gspx_bench_read": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),
     "gspx_gather": (_c.c_int, [_P, _c.c_int, _P, _P]),
     "gspx_bench_copy": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),

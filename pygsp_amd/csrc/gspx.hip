@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -262,8 +263,10 @@ struct gspx_ctx {
   double timing[5] = {0, 0, 0, 0, 0};
   // hipGraph replay of a repeated identical filter call (launch-bound small graphs)
   bool capturing = false;     // run_batch is being recorded: no copies, syncs or events inside
-  uint64_t seen_key = 0;      // key of the last eager call
-  uint64_t graph_key = 0;     // key the instantiated graph was captured for
+  // identity of a call = the full tuple of everything the recorded launches depend on, compared
+  // byte for byte (not a hash of it: a collision would replay the wrong graph silently)
+  std::vector<unsigned char> seen_key;   // key of the last eager call (empty: none)
+  std::vector<unsigned char> graph_key;  // key the instantiated graph was captured for
   hipGraphExec_t graph_exec = nullptr;
 };
 
@@ -271,8 +274,8 @@ struct gspx_ctx {
 // the cached gather offsets or the workspace the graph refers to)
 static void replay_reset(gspx_ctx* ctx) {
   if (!ctx) return;
-  ctx->seen_key = 0;
-  ctx->graph_key = 0;
+  ctx->seen_key.clear();
+  ctx->graph_key.clear();
   if (ctx->graph_exec) {
     (void)hipGraphExecDestroy(ctx->graph_exec);
     ctx->graph_exec = nullptr;
@@ -285,8 +288,11 @@ struct gspx_buf {
   int64_t bytes = 0;
 };
 
+static std::atomic<uint64_t> g_generation{1};  // handles are told apart by birth number, not by address
+
 struct gspx_graph {
   gspx_ctx* ctx = nullptr;
+  const uint64_t generation = g_generation.fetch_add(1);
   int64_t N = 0;
   int dtype = GSPX_F64;
   bool from_w = false;
@@ -1775,27 +1781,31 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
   // ---- hipGraph replay: an analysis call that repeats the previous one exactly (same graph, lmax,
   // coefficients, pointers, options) is recorded once and replayed as one graph launch - K + 1
   // kernel launches cost ~5 us each, which is the whole call on cache-resident graphs
-  uint64_t key = 0;
+  std::vector<unsigned char> key;
   const bool graph_mode =
       analysis && Nsig <= max_ld &&
       (opt.graph_launch == 1 || (opt.graph_launch == 2 && (size_t)N * Nsig * sizeof(T) <= ((size_t)32 << 20)));
   if (graph_mode) {
-    auto mix = [&](const void* p, size_t n) {
+    auto put = [&](const void* p, size_t n) {
       const unsigned char* b = (const unsigned char*)p;
-      for (size_t i = 0; i < n; ++i) key = (key ^ b[i]) * 1099511628211ull;
+      key.insert(key.end(), b, b + n);
     };
-    key = 1469598103934665603ull;
-    const void* ptrs[] = {g, x, y, ctx->ws_t.p, ctx->ws_r.p, ctx->ws_w.p, g->coff.p, g->gt_hdr.p, g->fval.p};
-    mix(ptrs, sizeof(ptrs));
-    mix(&lmax, sizeof(lmax));
-    mix(&Nf, sizeof(Nf));
-    mix(&M, sizeof(M));
-    mix(&Nsig, sizeof(Nsig));
-    mix(cp.data(), cp.size() * sizeof(double));
-    mix(&opt, sizeof(opt));
-    mix(&g->gt_rows, sizeof(g->gt_rows));
-    if (key == 0) key = 1;
-    if (ctx->graph_exec && ctx->graph_key == key) {
+    // the graph by birth number (a destroyed graph's address may be handed out again), every device
+    // address the launches carry, the scalars and options they were shaped by
+    put(&g->generation, sizeof(g->generation));
+    const void* ptrs[] = {x, y, ctx->ws_t.p, ctx->ws_r.p, ctx->ws_w.p, g->coff.p, g->gt_hdr.p, g->gt_s1nat.p,
+                          g->fval.p, g->perm.p};
+    put(ptrs, sizeof(ptrs));
+    put(&lmax, sizeof(lmax));
+    put(&g->fval_lmax, sizeof(g->fval_lmax));
+    put(&Nf, sizeof(Nf));
+    put(&M, sizeof(M));
+    put(&Nsig, sizeof(Nsig));
+    put(cp.data(), cp.size() * sizeof(double));
+    put(&opt, sizeof(opt));
+    put(&g->gt_rows, sizeof(g->gt_rows));
+    put(&g->gt_slow, sizeof(g->gt_slow));
+    if (ctx->graph_exec && !key.empty() && ctx->graph_key == key) {
       HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
       HIPCHK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
       HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1807,7 +1817,7 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
       ctx->timing[2] = (double)K;
       return GSPX_OK;
     }
-    if (ctx->seen_key == key) {  // second identical call: record it
+    if (!key.empty() && ctx->seen_key == key) {  // second identical call: record it
       if (ctx->graph_exec) {
         (void)hipGraphExecDestroy(ctx->graph_exec);
         ctx->graph_exec = nullptr;
@@ -1823,7 +1833,7 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
       if (rc != GSPX_OK || ce != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        ctx->seen_key = 0;  // fall through to the eager path below
+        ctx->seen_key.clear();  // fall through to the eager path below
       } else {
         const hipError_t ie = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
@@ -1837,7 +1847,7 @@ static int filter_dev_t(gspx_graph* g, double lmax, int Nf, int M, const double*
     }
   }
   if (ctx->graph_exec && ctx->graph_key != key) replay_reset(ctx);
-  ctx->seen_key = key;  // 0 when graph mode is off
+  ctx->seen_key = key;  // empty when graph mode is off
 
   size_t ev_idx = 0;
   HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -2394,12 +2404,13 @@ static double tridiag_max_eig(const std::vector<double>& al, const std::vector<d
 }
 
 template <typename T>
-static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* iters) {
+static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* iters, int* converged) {
   gspx_ctx* ctx = g->ctx;
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   *out = 0.0;
   if (iters) *iters = 0;
+  if (converged) *converged = 1;
   if (N == 0) return GSPX_OK;
   // L v = 0.5 * F v + v  with F = 2 (L - I), i.e. the factor matrix for lmax = 2
   CHK(ensure_factor<T>(g, 2.0));
@@ -2439,6 +2450,7 @@ static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* 
   a.beta = T(1);
   std::vector<double> al, be;
   double theta = 0, beta_prev = 0;
+  bool met = false;  // the residual criterion was met (or the Krylov space became invariant: theta is exact)
   int cur = 0, prev = 2;
   for (int j = 0; j < max_iter && j < N; ++j) {
     const int nxt = 3 - cur - prev;  // the third buffer
@@ -2459,7 +2471,10 @@ static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* 
     theta = tridiag_max_eig(al, be);
     if (iters) *iters = j + 1;
     const double beta = std::sqrt(std::max(b2, 0.0));
-    if (!(beta > 1e-300 * std::max(1.0, std::fabs(theta)))) break;  // invariant subspace
+    if (!(beta > 1e-300 * std::max(1.0, std::fabs(theta)))) {  // invariant subspace
+      met = true;
+      break;
+    }
     // residual of the Ritz pair: ||L y - theta y|| = beta_j |s_j|, s = unit eigenvector of the
     // tridiagonal matrix for theta; its components come from the backward recurrence (the stable
     // direction for the extreme eigenvalue).  There is an eigenvalue of L within that distance of
@@ -2482,7 +2497,10 @@ static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* 
         }
       }
       const double s_last = w_last / std::sqrt(nrm2w);
-      if (j >= 2 && beta * std::fabs(s_last) <= tol * std::fabs(theta)) break;
+      if (j >= 2 && beta * std::fabs(s_last) <= tol * std::fabs(theta)) {
+        met = true;
+        break;
+      }
     }
     be.push_back(beta);
     hipLaunchKernelGGL((k_axpby<T>), dim3(nb), dim3(256), 0, st, T(0), v[nxt], (T)(1.0 / beta),
@@ -2494,17 +2512,18 @@ static int lanczos_t(gspx_graph* g, int max_iter, double tol, double* out, int* 
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   *out = theta;
+  if (converged) *converged = (met || (int)al.size() >= N) ? 1 : 0;  // N steps span the whole space
   return GSPX_OK;
 }
 
 extern "C" int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double* lmax,
-                                 int* iterations) {
+                                 int* iterations, int* converged) {
   if (g) replay_reset(g->ctx);
   if (!g || !lmax) return set_err(GSPX_ERR_INVALID, "null argument");
   if (max_iter < 1 || !(tol > 0)) return set_err(GSPX_ERR_INVALID, "max_iter >= 1 and tol > 0");
   HIPCHK(hipSetDevice(g->ctx->device));
-  return g->dtype == GSPX_F32 ? lanczos_t<float>(g, max_iter, tol, lmax, iterations)
-                              : lanczos_t<double>(g, max_iter, tol, lmax, iterations);
+  return g->dtype == GSPX_F32 ? lanczos_t<float>(g, max_iter, tol, lmax, iterations, converged)
+                              : lanczos_t<double>(g, max_iter, tol, lmax, iterations, converged);
 }
 
 // ------------------------------------------------------------------------------------------------

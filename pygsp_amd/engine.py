@@ -146,6 +146,7 @@ def filter_batch(jobs, root_ctx=None):
     errs = []
 
     def work(i):
+        bx = by = None
         try:
             dev, c, x, lmax = jobs[i]
             c2 = np.atleast_2d(np.asarray(c, dtype=np.float64))
@@ -153,10 +154,14 @@ def filter_batch(jobs, root_ctx=None):
             bx = dev.ctx.upload(x)
             by = dev.ctx.alloc(x.nbytes * c2.shape[0])
             dev.cheby_filter_dev(c2, bx.ptr, by.ptr, x.shape[1], lmax)
-            bx.free()
             outs[i] = (by, (c2.shape[0],) + x.shape, dev.dtype)
+            by = None  # owned by outs from here on
         except Exception as e:  # surfaced on the caller's thread
             errs.append(e)
+        finally:
+            for b in (bx, by):
+                if b is not None:
+                    b.free()
 
     by_ctx = {}
     for i, j in enumerate(jobs):
@@ -166,19 +171,25 @@ def filter_batch(jobs, root_ctx=None):
         t.start()
     for t in threads:
         t.join()
-    if errs:
-        raise errs[0]
-    total = sum(b.nbytes for b, _, _ in outs)
-    root = root_ctx.alloc(total)
-    gather([b for b, _, _ in outs], root)
-    flat = root.download((total,), np.uint8)
-    res, off = [], 0
-    for b, shape, dt in outs:
-        res.append(flat[off:off + b.nbytes].view(dt).reshape(shape))
-        off += b.nbytes
-        b.free()
-    root.free()
-    return res
+    root = None
+    try:
+        if errs:
+            raise errs[0]
+        total = sum(b.nbytes for b, _, _ in outs)
+        root = root_ctx.alloc(total)
+        gather([b for b, _, _ in outs], root)
+        flat = root.download((total,), np.uint8)
+        res, off = [], 0
+        for b, shape, dt in outs:
+            res.append(flat[off:off + b.nbytes].view(dt).reshape(shape))
+            off += b.nbytes
+        return res
+    finally:  # every device buffer of the batch is released, also when a job failed
+        for o in outs:
+            if o is not None:
+                o[0].free()
+        if root is not None:
+            root.free()
 
 
 def _canonical_csr(M):
@@ -391,11 +402,17 @@ class DeviceGraph:
         return dw
 
     def lanczos_lmax(self, max_iter=60, tol=5e-4):
-        """Largest Ritz value of L after a device Lanczos run: (value, iterations)."""
+        """Largest Ritz value of L after a device Lanczos run: (value, iterations).  Raises ValueError
+        when the step budget runs out before the residual criterion is met, as Graph.estimate_lmax
+        does on ArpackNoConvergence (graph.py:918-919): a value from below lambda_max would put part of
+        the spectrum outside [-1, 1], where the Chebyshev recurrence diverges."""
         v = ctypes.c_double(0)
         it = ctypes.c_int(0)
-        _capi.check(_capi.load().gspx_lanczos_lmax(self._h, int(max_iter), float(tol),
-                                                   ctypes.byref(v), ctypes.byref(it)))
+        ok = ctypes.c_int(0)
+        _capi.check(_capi.load().gspx_lanczos_lmax(self._h, int(max_iter), float(tol), ctypes.byref(v),
+                                                   ctypes.byref(it), ctypes.byref(ok)))
+        if not ok.value:
+            raise ValueError("The Lanczos method did not converge. Try to use bounds.")
         return v.value, it.value
 
     # ---- the hot path -------------------------------------------------------------------------

@@ -18,18 +18,33 @@ _saved = {}
 _config = {"laplacian": "device", "dtype": np.float64, "device": 0, "reorder": "auto", "tiles": "auto"}
 
 
+def _finite_coords(G):
+    coords = getattr(G, "coords", None)
+    try:
+        coords = np.asarray(coords, dtype=np.float64)
+    except (TypeError, ValueError):
+        return None
+    if coords.ndim != 2 or coords.shape[0] != G.N or not np.isfinite(coords).all():
+        return None  # plotting layouts may hold NaN / inf: fall back to the pattern-based order
+    return coords
+
+
 def device_graph_for(G):
-    """libgspx graph attached to a reference ``pygsp.graphs.Graph`` (cached on the object, rebuilt
-    when ``G.compute_laplacian`` replaced ``G.L``, mirroring graph.py:602-609)."""
-    key = (id(G.L), G.lap_type, np.dtype(_config["dtype"]).str, _config["laplacian"])
+    """libgspx graph attached to a reference ``pygsp.graphs.Graph``: cached on the object next to the
+    very ``G.L`` (and ``G.W``) it was built from, and rebuilt when ``G.compute_laplacian`` replaced
+    them, mirroring graph.py:602-609.  The cache entry holds the matrices themselves and compares with
+    ``is`` - an ``id()`` alone could be recycled by a later matrix."""
+    conf = (G.lap_type, np.dtype(_config["dtype"]).str, _config["laplacian"], _config["reorder"],
+            bool(_config.get("tiles", "auto")), _config["device"])
     cached = getattr(G, "_gspx_dev", None)
-    if cached is not None and cached[0] == key:
-        return cached[1]
+    if cached is not None and cached[0] is G.L and cached[1] is G.W and cached[2] == conf:
+        return cached[3]
+    if cached is not None:
+        cached[3].destroy()
     ctx = engine.default_context(_config["device"])
     perm = None
-    coords = getattr(G, "coords", None)
     if _config["reorder"] == "auto" and G.N >= 4096:
-        perm = engine.auto_order(G.W, coords, _config["device"])
+        perm = engine.auto_order(G.W, _finite_coords(G), _config["device"])
     elif _config["reorder"] == "rcm":
         perm = engine.locality_order(G.W, None)
     if _config["laplacian"] == "device":
@@ -39,7 +54,7 @@ def device_graph_for(G):
         dev = engine.DeviceGraph.from_l(G.L, dtype=_config["dtype"], perm=perm, ctx=ctx)
     if _config.get("tiles", "auto"):
         dev.auto_gather_tiles()
-    G._gspx_dev = (key, dev)
+    G._gspx_dev = (G.L, G.W, conf, dev)
     return dev
 
 
@@ -71,3 +86,28 @@ def uninstall(pygsp_module=None):
     alias = _saved.pop("alias")
     if alias is not None:
         pygsp_module.filters.cheby_op = alias
+
+
+def use_backend(name, pygsp_module=None, **install_options):
+    """Select who evaluates ``Filter.filter(method='chebyshev')`` of the real pygsp: 'gspx' (this
+    engine, = install()) or 'reference' (scipy on the host, = uninstall())."""
+    if name == "gspx":
+        return install(pygsp_module, **install_options)
+    if name == "reference":
+        return uninstall(pygsp_module)
+    raise ValueError("backend must be 'gspx' or 'reference', got {!r}".format(name))
+
+
+def _backend_from_env():
+    """PYGSP_AMD_BACKEND=gspx in the environment installs the seam as soon as this module is imported
+    (e.g. from a sitecustomize / conftest line ``import pygsp_amd.plugin``); anything else: no-op."""
+    import os
+    if os.environ.get("PYGSP_AMD_BACKEND", "").strip().lower() == "gspx":
+        try:
+            import pygsp
+        except ImportError:
+            return
+        install(pygsp)
+
+
+_backend_from_env()

@@ -360,6 +360,32 @@ def test_graph_replay(ctx):
     dev.destroy()
 
 
+def test_graph_replay_tells_graphs_apart(ctx):
+    """A recorded call must not be replayed for a DIFFERENT graph that happens to receive the addresses
+    of a destroyed one (same sizes -> the allocator hands the same blocks out again): the replay
+    identity carries the graph's birth number, and gspx_graph_destroy drops the recording."""
+    rng = np.random.default_rng(78)
+    n, nsig = 20000, 8
+    x = rng.standard_normal((n, nsig))
+    bx, by = ctx.upload(x), ctx.alloc(x.nbytes)
+    ctx.set_option("graph_launch", 1)
+    try:
+        for seed in (1, 2, 3):  # same N, k: same array sizes, different weights
+            W, _ = graphs.sensor_weights(n, k=6, seed=seed)
+            lmax = 2.0 * float(np.ravel(W.sum(0)).max()) * 1.01  # a different lmax per graph, too
+            dev = engine.DeviceGraph.from_w(W, ctx=ctx)
+            c = orc.compute_cheby_coeff(orc.heat_kernel(10, 30.0), 30.0, 12)  # identical coefficients
+            ref = orc.cheby_op(orc.laplacian(W), lmax, c, x).reshape(n, nsig)
+            for rep in range(4):
+                dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, lmax)
+                assert rel_err(by.download((n, nsig), np.float64), ref) < 1e-11, (seed, rep)
+            dev.destroy()
+    finally:
+        ctx.set_option("graph_launch", 2)
+        bx.free()
+        by.free()
+
+
 def test_tile_block_walks(ctx):
     """The strided walk of k_step_tile's persistent workgroups visits every block exactly once whatever
     the workgroup count: results are bit-identical, also when most workgroups have no block."""

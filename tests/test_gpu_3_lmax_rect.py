@@ -38,6 +38,10 @@ def test_device_lanczos_lmax(golden_logo, dtype):
     assert abs(Gl.lmax - 13.92) < 0.05
     with pytest.raises(ValueError):
         Gl.estimate_lmax("fancy")
+    # a step budget too small to converge is an error, as ArpackNoConvergence is in the reference
+    # (graph.py:918-919), never a silently low estimate
+    with pytest.raises(ValueError, match="did not converge"):
+        cases[0].device_graph().lanczos_lmax(max_iter=3, tol=1e-12)
 
 
 def test_cheby_rect_golden(golden_sensor123):
