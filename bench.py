@@ -19,9 +19,14 @@ roofline: ALGORITHMIC bytes per recurrence-step launch (SURVEY.md 8d:
 B_alg = K*(CSR + 3U) + Nf*U, per launch B_alg/K) divided by the average launch duration measured
 with HIP events on the engine's own stream over the timed steps.
 
-cpu_baseline: the oracle (numpy/scipy restatement = the reference's algorithm, scipy's
-csr_matvecs kernel, single-threaded) on a bounded column sample of the same workload, rank 0 at
-N=1 only.
+cpu_baseline: the oracle PORT (numpy/scipy restatement = the reference's algorithm, scipy's
+csr_matvecs kernel, single-threaded like the reference) on a bounded column sample of the same
+workload, rank 0 at N=1 only; "all_cores" beside it is the same port run by one process per host
+core on disjoint signal columns (the reference itself uses one core).
+
+configs: the other BASELINE.json configurations that fit one GPU (configs[1..3] and one rank's share
+of configs[4]), each with its own time, algorithmic roofline fraction and parity against oracle
+columns, appended after the headline keys (N=1 only; --no-configs skips them).
 """
 import argparse
 import json
@@ -65,6 +70,16 @@ def parse():
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
     p.add_argument("--no-e2e", action="store_true", help="skip the numpy-in/numpy-out leg (profiling passes)")
+    p.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
+    p.add_argument("--no-headline", action="store_true",
+                   help="profiling passes of one config: skip the headline workload entirely")
+    p.add_argument("--only-config", default=None, help="run only the config whose key starts with this (c1..c4)")
+    p.add_argument("--config-reps", type=int, default=3, help="timed calls per config (best is reported)")
+    p.add_argument("--config-oracle-cols", type=int, default=2, help="oracle columns per config (0: no parity leg)")
+    p.add_argument("--calibrate-copy", action="store_true",
+                   help="also run the engine's streaming copy kernel once (byte-counter calibration for rocprofv3)")
+    p.add_argument("--cpu-all-cores", type=int, default=-1,
+                   help="processes of the multi-core CPU baseline (-1: one per host core, at most 64; 0: skip)")
     p.add_argument("--tiles", choices=["auto", "off"], default="auto",
                    help="auto = the product default (LDS-staged recurrence step when the graph's order "
                         "is local); off = the plain gather kernels")
@@ -77,6 +92,138 @@ def parse():
     return p.parse_args()
 
 
+# ---- CPU baseline on all host cores ---------------------------------------------------------------
+_POOL = {}
+
+
+def _pool_column(j):
+    """One worker = one process = one signal column through the oracle port (fork: L is shared)."""
+    from oracle import cheby_oracle as orc
+    L, lmax, c, x = _POOL["L"], _POOL["lmax"], _POOL["c"], _POOL["x"]
+    y = orc.cheby_op(L, lmax, c, x[:, j:j + 1])
+    return float(np.abs(y).max())
+
+
+def cpu_all_cores(N, knn, K, scale, procs):
+    """The oracle port on every host core at once: `procs` processes, one signal column each, same
+    graph / coefficients as the headline (built on the host, before any HIP call in this process - the
+    workers are forked).  Returns the cpu_baseline.all_cores object."""
+    import multiprocessing as mp
+
+    from oracle import cheby_oracle as orc
+    from pygsp_amd import graphs
+    W, _ = graphs.sensor_weights(N, k=knn, seed=42)
+    L = orc.laplacian(W).astype(np.float64)
+    lmax = 2.0 * float(np.ravel(W.sum(axis=0)).max())  # an upper bound (graph.py:947), as 'bounds' gives
+    c = orc.compute_cheby_coeff(orc.heat_kernel(scale, lmax), lmax, K)
+    x = np.random.default_rng(7).standard_normal((N, procs))
+    _POOL.update(L=L, lmax=lmax, c=c, x=x)
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_pool_column, range(min(procs, 4)))  # warm-up: page in, spin the workers up
+        t0 = time.perf_counter()
+        pool.map(_pool_column, range(procs), chunksize=1)
+        dt = time.perf_counter() - t0
+    _POOL.clear()
+    return {"value": N * procs * K / dt, "unit": "vertex*signal*order/s", "cores": procs, "kind": "port",
+            "sample": "same graph/coefficients, {} signal columns, one per process ({} host cores present), "
+                      "order {}, float64, {:.1f} s".format(procs, os.cpu_count(), K, dt)}
+
+
+# ---- the other BASELINE.json configs --------------------------------------------------------------
+def run_config(key, workload, G, bank, nsig, K, dtype, ctx, oracle_cols=2, reps=3):  # noqa: C901
+    """One BASELINE config, device resident: best-of-`reps` device time of the whole call (HIP events),
+    algorithmic bytes B_alg = K (CSR + 3U) + Nf U, parity of `oracle_cols` columns
+    against the oracle (its own Laplacian from the same W)."""
+    from oracle import cheby_oracle as orc
+    from pygsp_amd import filters
+    elt = np.dtype(dtype).itemsize
+    G.estimate_lmax("bounds")
+    lmax = float(G.lmax)
+    c = np.atleast_2d(np.array(filters.compute_cheby_coeff(bank, m=K)))
+    Nf, N = c.shape[0], G.N
+    dev = G.device_graph()
+    x = np.random.default_rng(0).standard_normal((N, nsig)).astype(dtype)
+    bx, by = ctx.upload(x), ctx.alloc(x.nbytes * Nf)
+    best, tm = None, None
+    for _ in range(reps + 1):  # the first call allocates the workspace
+        ms = dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, lmax)
+        if best is None or ms < best:
+            best, tm = ms, ctx.last_timing()
+    y = by.download((Nf, N, nsig), dtype)
+    bx.free()
+    by.free()
+    cols = list(range(min(oracle_cols, nsig)))
+    err = None
+    if cols:
+        L = orc.laplacian(G.W.astype(np.float64), G.lap_type)
+        ref = orc.cheby_op(L, lmax, c, x[:, cols].astype(np.float64)).reshape(Nf, N, len(cols))
+        err = float(np.max(np.abs(y[:, :, cols] - ref)) / np.max(np.abs(ref)))
+    nnz_l, nnz_int = dev.nnz_l, dev.nnz_internal
+    U = N * nsig * elt
+    csr = nnz_l * (elt + 4) + 4 * (N + 1)
+    b_alg = K * (csr + 3 * U) + Nf * U
+    step_ms = tm["steps_ms"] / max(tm["step_launches"], 1)
+    gather_bytes = nnz_l * nsig * elt  # one panel row per stored entry and recurrence step
+    tiled = bool(G.tile_stats and G.tile_stats.get("enabled"))
+    return {
+        "key": key, "workload": workload, "dtype": "f64" if elt == 8 else "f32", "N": N, "nnz_L": int(nnz_l),
+        "nnz_internal": int(nnz_int), "Nsig": nsig, "Nf": Nf, "order": K, "lap_type": G.lap_type,
+        "ms": best, "value": N * nsig * K / (best * 1e-3), "unit": "vertex*signal*order/s",
+        "steps_ms": tm["steps_ms"], "combine_ms": tm["combine_ms"], "permute_ms": tm["permute_ms"],
+        "step_launches": tm["step_launches"], "avg_step_ms": step_ms,
+        "roofline": {"bound": "hbm", "achieved": b_alg / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b_alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": b_alg},
+        # what a graph without vertex locality is really bound by: every stored entry fetches one panel
+        # row through the L2 -> Infinity Cache / HBM path (DESIGN.md section 7)
+        "gather": {"bytes_per_step": gather_bytes, "rate_GBps": gather_bytes / (step_ms * 1e-3) / 1e9},
+        "kernel": "k_step_tile (LDS-staged gathers)" if tiled else "plain gather kernels (no vertex locality: no tiles)",
+        "internal_order": "curve / RCM" if G._perm is not None else "none (graph's own order)",
+        "parity_vs_oracle": {"max_rel_err": err, "columns": len(cols), "tolerance": 1e-5 if elt == 8 else 1e-3},
+        "lmax": lmax,
+    }
+
+
+def run_configs(ctx, only=None, reps=3, oracle_cols=2):
+    """BASELINE.json configs[1..4] on one GPU.  ER / SBM graphs come from the device sampler (equal in
+    distribution to the reference's constructors); parity is always against the oracle on
+    the same W."""
+    from pygsp_amd import filters, graphs
+    res = []
+
+    def want(k):
+        return only is None or k.startswith(only)
+
+    if want("c1"):
+        G = graphs.Sensor(100000, seed=42, compute_dtype=np.float64)
+        res.append(run_config("c1", "configs[1]: Sensor(N=100000) combinatorial, Heat(50) order 30, 1 signal, f64 "
+                              "(cache-resident latency case; replayed as one hipGraph)", G, filters.Heat(G, 50), 1, 30,
+                              np.float64, ctx, oracle_cols=min(oracle_cols, 1), reps=max(reps, 12)))
+        del G
+    if want("c2"):
+        N = 1000000
+        G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=np.float32)
+        res.append(run_config("c2", "configs[2]: ErdosRenyi(N=1000000, p=1e-5), MexicanHat filterbank (6 filters) "
+                              "order 50, 64 signals, f32", G, filters.MexicanHat(G, Nf=6), 64, 50, np.float32, ctx,
+                              oracle_cols, reps))
+        del G
+    if want("c3"):
+        for dt in (np.float64, np.float32):
+            G = graphs.StochasticBlockModel(2000000, k=16, p=9.6e-5, q=2.13e-6, seed=0, lap_type="normalized",
+                                            compute_dtype=dt)
+            res.append(run_config("c3", "configs[3]: StochasticBlockModel(N=2000000, k=16, p=9.6e-5, q=2.13e-6) "
+                                  "normalized Laplacian, Heat(10) order 30, 16 signals", G, filters.Heat(G, 10), 16, 30,
+                                  dt, ctx, oracle_cols, reps))
+            del G
+    if want("c4"):
+        for dt in (np.float64, np.float32):
+            G = graphs.Sensor(500000, seed=0, compute_dtype=dt)
+            res.append(run_config("c4", "configs[4], one rank's share: Sensor(N=500000), Heat(50) order 30, 32 signals "
+                                  "(the batch of 8 such graphs is one per GPU; bench.py --gpus N is its scaling run)",
+                                  G, filters.Heat(G, 50), 32, 30, dt, ctx, oracle_cols, reps))
+            del G
+    return res
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -85,8 +232,29 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(a.gpus, world))
 
+    # all host cores first: its workers are forked, so it runs before this process touches HIP
+    cpu_all = None
+    if rank == 0 and world == 1 and not a.no_cpu and a.cpu_all_cores != 0 and not a.no_headline:
+        # (one process per core up to 64: the port is memory-bound, 256 processes on the 256-core host of
+        # the GPU box delivered 3.4x one core and took 50 s; the sample is sized to stay within ~10-15 s)
+        procs = a.cpu_all_cores if a.cpu_all_cores > 0 else min(os.cpu_count() or 1, 64)
+        try:
+            cpu_all = cpu_all_cores(a.n, a.knn, a.order, a.scale, procs)
+        except Exception as e:  # a reported baseline, never a reason to lose the measurement
+            cpu_all = {"error": repr(e)}
+
     from pygsp_amd import engine, graphs
     from pygsp_amd import dist as gdist
+
+    if a.no_headline:  # profiling passes of single configs
+        ctx0 = engine.default_context(local)
+        for kv in a.opt:
+            k, v = kv.split("=")
+            ctx0.set_option(k, int(v))
+        if a.calibrate_copy:
+            ctx0.bench_copy(1 << 29, 2)
+        print(json.dumps({"configs": run_configs(ctx0, a.only_config, a.config_reps, a.config_oracle_cols)}))
+        return
 
     torch = None
     tdev = None
@@ -158,6 +326,8 @@ def main():
             torch.cuda.synchronize(tdev)
             gdist.barrier()
 
+    if a.calibrate_copy:  # k_permute_in as a pure copy of 2 x 512 MiB: known bytes for the PMC passes
+        ctx.bench_copy(1 << 29, 2)
     for _ in range(a.warmup):
         step()
     fence()
@@ -206,16 +376,41 @@ def main():
         fence()
 
     # ---- the path's one collective, outside the timed region: outputs -> rank 0 ----------------
-    gather_ms = None
+    gather_ms, gather_impl = None, None
     if torch is not None and not a.no_gather:
         fence()
-        tg = time.perf_counter()
-        blocks = gdist.gather_to_root(ty if a.backend == "nccl" else ty.cpu(), dst=0)
-        torch.cuda.synchronize(tdev)
-        gather_ms = gdist.max_over_ranks((time.perf_counter() - tg) * 1e3, rdev)
-        if rank == 0:
-            assert len(blocks) == world
-        del blocks
+        # in the library: RCCL grouped send / recv (gspx_comm_gather); torch only carried the 128-byte id
+        lib_ok = 0.0
+        if a.backend == "nccl" and os.environ.get("GSPX_BENCH_LIB_GATHER", "1") != "0":
+            try:
+                comm = gdist.make_comm(ctx)
+                root_buf = ctx.alloc(world * x.nbytes) if rank == 0 else None
+                fence()
+                tg = time.perf_counter()
+                comm.gather(y_ptr, [x.nbytes] * world, 0, root_buf.ptr if rank == 0 else None)
+                fence()
+                t_lib = (time.perf_counter() - tg) * 1e3
+                if rank == 0:  # the root's own block, as it arrived through RCCL
+                    got = root_buf.download((world, N, nsig), dtype)[0]
+                    assert np.array_equal(got, ty.cpu().numpy()[0])
+                    root_buf.free()
+                comm.close()
+                lib_ok = 1.0
+            except Exception as e:  # agreed on below: every rank falls back together
+                sys.stderr.write("rank {}: in-library RCCL gather unavailable ({!r})\n".format(rank, e))
+        if gdist.sum_over_ranks(lib_ok, rdev) == float(world):
+            gather_ms = gdist.max_over_ranks(t_lib, rdev)
+            gather_impl = "libgspx gspx_comm_gather: RCCL grouped ncclSend/ncclRecv, one xGMI link per peer"
+        else:
+            fence()
+            tg = time.perf_counter()
+            blocks = gdist.gather_to_root(ty if a.backend == "nccl" else ty.cpu(), dst=0)
+            torch.cuda.synchronize(tdev)
+            gather_ms = gdist.max_over_ranks((time.perf_counter() - tg) * 1e3, rdev)
+            if rank == 0:
+                assert len(blocks) == world
+            del blocks
+            gather_impl = "torch.distributed ({}) send/recv".format("RCCL" if a.backend == "nccl" else a.backend)
 
     tiled = bool(G.tile_stats and G.tile_stats.get("enabled"))
 
@@ -245,9 +440,13 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "traffic_{}.json".format(a.dtype))
     # the committed PMC measurement is of the default workload only
     default_workload = (N, nsig, K, a.knn, a.evaluation, a.tiles) == (1000000, 64, 30, 8, "recurrence", "auto")
+    traffic_source = None
     if default_workload and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/traffic_{}.json: (2*FETCH_SIZE + WRITE_SIZE) per k_step_tile launch from "
+                              "separate rocprofv3 --pmc passes of this same command (tools/gpu_prof.sh); PMC counters "
+                              "cannot be read from inside this process").format(a.dtype)
         except Exception:
             traffic = None
 
@@ -282,7 +481,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": ("k_step_tile (one recurrence order per launch, gathered panel staged in LDS)"
                            if tiled else "k_step_panel / k_step_lds (one recurrence order per launch)"),
                 "algorithmic_bytes_per_launch": b_alg_launch,
@@ -292,7 +491,7 @@ def main():
             "newton_form_pair": None if newton_pair is None else newton_report(newton_pair, True),
             "device_ms_per_step": dev_ms / a.steps,
             "device_ms_recurrence_per_step": steps_ms_max / a.steps,
-            "gather_ms": gather_ms,
+            "gather_ms": gather_ms, "gather_impl": gather_impl,
             "setup_s": {"graph_generation_host": t_gen, "graph_generation_device_knn": t_gen_dev,
                         "device_knn_build_ms": knn_info["build_ms"], "device_knn_max_abs_diff_vs_host": knn_diff,
                         "graph_object_incl_device_laplacian": t_graph,
@@ -331,12 +530,25 @@ def main():
         out["cpu_baseline"] = {
             "value": N * cols * K / t_cpu, "unit": "vertex*signal*order/s", "cores": 1,
             "kind": "port",
-            "sample": "same graph/coefficients, first {} of {} signal columns, order {}, float64, "
-                      "scipy csr_matvecs single-threaded ({} host cores present), {:.1f} s".format(
-                          cols, nsig, K, os.cpu_count(), t_cpu),
+            "sample": "oracle port of the reference (scipy csr_matvecs, single-threaded like the reference): same "
+                      "graph/coefficients, first {} of {} signal columns, order {}, float64 ({} host cores "
+                      "present), {:.1f} s".format(cols, nsig, K, os.cpu_count(), t_cpu),
+            "multi_core": cpu_all,
         }
         out["parity_vs_oracle"] = {"max_rel_err": err, "columns": cols,
                                    "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
+    # ---- the other BASELINE configs (N=1 only), appended after the headline keys ---------------------
+    if rank == 0 and world == 1 and not a.no_configs:
+        bx.free()
+        if by is not None:
+            by.free()
+        for g_ in list(G._dev.values()):
+            g_.destroy()
+        G._dev = {}
+        try:
+            out["configs"] = run_configs(ctx, a.only_config, a.config_reps, a.config_oracle_cols)
+        except Exception as e:
+            out["configs"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     if torch is not None:

@@ -96,15 +96,37 @@ int gspx_buf_download(gspx_buf* buf, void* host, int64_t bytes);
 int gspx_buf_ptr(gspx_buf* buf, void** device_ptr); /* raw device pointer (interop) */
 int gspx_buf_bytes(gspx_buf* buf, int64_t* bytes);
 
-/* The path's one collective, single-process form (one process driving several contexts / GPUs from
- * threads): concatenates parts[0..n) - each a buffer of its own context - into root_out, in argument
- * order.  Copies are queued on the source contexts' streams (behind the filtering that produced the
- * parts) and run concurrently, peer-to-peer over xGMI, one link per source; returns when all have
- * landed.  ctxs may be null (or ctxs[i] == the context parts[i] was allocated on).  In the
- * one-process-per-GPU launch (bench.py --gpus N under torch.distributed.run) the same gather is RCCL
- * send/recv through torch.distributed (pygsp_amd/dist.py).  Replaces nothing in the reference (it
- * has no multi-device path); SURVEY section 8(b)/(e). */
+/* ---- the path's one collective: gather of the ranks' outputs to a root, RCCL over xGMI ----------------
+ * (the reference has no multi-device path, nothing is replaced).  The recurrence
+ * never communicates: independent graphs / signal columns per GPU.  Every block travels as one grouped
+ * ncclSend / ncclRecv pair, so each peer uses its own xGMI link.  RCCL is loaded on first use (dlopen).
+ *
+ * Single-process form (one process driving several contexts / GPUs from threads): concatenates
+ * parts[0..n) - each a buffer of its own context - into root_out, in argument order; returns when all
+ * have landed.  ctxs may be null (or ctxs[i] == the context parts[i] was allocated on).  Option
+ * "gather_rccl" of the ROOT's context: 1 (default) RCCL between devices, peer copies (hipMemcpyPeerAsync
+ * on the source streams) if RCCL is unavailable; 0 peer copies only; 2 every block through RCCL, also
+ * same-device ones (self send / recv). */
 int gspx_gather(gspx_ctx** ctxs, int n, gspx_buf** parts, gspx_buf* root_out);
+/* One-process-per-GPU form.  The launcher (torch.distributed.run, mpirun, ...) only moves the 128-byte id
+ * from rank 0 to the other ranks; everything else is RCCL inside the library.
+ *   gspx_comm_available  1 when RCCL could be loaded
+ *   gspx_comm_unique_id  rank 0: a fresh id (ncclGetUniqueId)
+ *   gspx_comm_create     every rank, collectively: the communicator of `nranks` ranks on ctx's device
+ *   gspx_comm_gather     every rank, collectively, with the same bytes[nranks] table: rank r's block
+ *                        part_dev (bytes[r] bytes, device memory) lands at offset sum(bytes[0..r)) of
+ *                        root_out_dev on rank `root` (NULL elsewhere).  Queued on the context's stream,
+ *                        behind the filter that produced the block; returns when this rank's transfers are
+ *                        complete.  ms (nullable): device time of the exchange on this rank. */
+typedef struct gspx_comm gspx_comm;
+#define GSPX_COMM_ID_BYTES 128
+int gspx_comm_available(void);
+int gspx_comm_unique_id(unsigned char id[GSPX_COMM_ID_BYTES]);
+int gspx_comm_create(gspx_ctx* ctx, int nranks, int rank, const unsigned char id[GSPX_COMM_ID_BYTES],
+                     gspx_comm** out);
+int gspx_comm_destroy(gspx_comm* comm);
+int gspx_comm_gather(gspx_comm* comm, const void* part_dev, const int64_t* bytes, int root,
+                     void* root_out_dev, double* ms);
 
 /* ---- graphs ---------------------------------------------------------------------------- */
 /* Upload the (symmetric, canonical CSR: sorted indices, no duplicates, no explicit zeros)

@@ -246,6 +246,7 @@ struct Options {
   int64_t combine = 0;        // 0 auto, 1 fused flush, 2 deferred
   int64_t ws_limit_mb = 65536;  // workspace budget per filter call
   int64_t max_batch = 0;        // 0 = no extra cap on signals per batch
+  int64_t gather_rccl = 1;      // gspx_gather: 0 peer copies, 1 RCCL between devices (peer copies if it fails), 2 RCCL for every block
 };
 
 struct gspx_ctx {
@@ -430,6 +431,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "combine")) return &o.combine;
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
   if (!strcmp(key, "max_batch")) return &o.max_batch;
+  if (!strcmp(key, "gather_rccl")) return &o.gather_rccl;
   return nullptr;
 }
 
@@ -505,10 +507,13 @@ extern "C" int gspx_buf_download(gspx_buf* b, void* host, int64_t bytes) {
   return GSPX_OK;
 }
 
+#include "gspx_comm.hip.h"
+
 // The path's one collective in single-process form: every part (a buffer on its own context /
-// device) is pushed into root_out, one after the other in argument order.  Each copy is queued on
-// the SOURCE context's stream, behind whatever produced the part, so the n copies run concurrently,
-// each over its own xGMI link (peer DMA); same-device parts are plain device copies.
+// device) lands in root_out, one after the other in argument order.  Between devices the blocks travel
+// as grouped RCCL send / recv pairs (gather_rccl, gspx_comm.hip.h), each over its own xGMI link.  If RCCL
+// cannot be loaded or refuses the device set, the same gather is done with peer copies: each queued on
+// the SOURCE context's stream (hipMemcpyPeerAsync, DMA engines); same-device parts are device copies.
 extern "C" int gspx_gather(gspx_ctx** ctxs, int n, gspx_buf** parts, gspx_buf* root_out) {
   if (n < 0 || (n > 0 && !parts) || !root_out)
     return set_err(GSPX_ERR_INVALID, "gspx_gather: bad argument");
@@ -524,6 +529,15 @@ extern "C" int gspx_gather(gspx_ctx** ctxs, int n, gspx_buf** parts, gspx_buf* r
     return set_err(GSPX_ERR_INVALID, "gspx_gather: output holds %lld bytes, parts add up to %lld",
                    (long long)root_out->bytes, (long long)total);
   gspx_ctx* root = root_out->ctx;
+  if (root->opt.gather_rccl > 0) {
+    bool multi = false;
+    for (int i = 0; i < n; ++i) multi |= parts[i]->ctx->device != root->device;
+    if (multi || root->opt.gather_rccl == 2) {
+      if (gather_rccl(n, parts, root_out, root->opt.gather_rccl == 2) == GSPX_OK) return GSPX_OK;
+      if (root->opt.gather_rccl == 2) return GSPX_ERR_HIP;  // asked for RCCL explicitly: report why not
+      (void)hipGetLastError();  // otherwise: peer copies below
+    }
+  }
   HIPCHK(hipSetDevice(root->device));
   HIPCHK(hipStreamSynchronize(root->stream));  // earlier work on the output buffer
   int64_t off = 0;

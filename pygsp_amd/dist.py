@@ -91,3 +91,18 @@ def gather_to_root(tensor, dst=0):
     out = [torch.empty_like(tensor) for _ in range(world)] if rank == dst else None
     dist.gather(tensor, out, dst=dst)
     return out
+
+
+def make_comm(ctx):
+    """The in-library RCCL communicator of this rank (engine.Comm over gspx_comm_*): the 128-byte RCCL
+    id is made on rank 0 and handed to the other ranks through the launcher's process group - the only
+    thing torch.distributed carries here; the gather itself is RCCL inside libgspx.  Single process:
+    a one-rank communicator (its gather is a self send / recv)."""
+    from . import engine
+    rank, world, _ = env_world()
+    if world == 1:
+        return engine.Comm(ctx, 1, 0, engine.comm_unique_id())
+    import torch.distributed as dist
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return engine.Comm(ctx, world, rank, box[0])

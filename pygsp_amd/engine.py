@@ -133,6 +133,52 @@ def gather(parts, root_out):
     return root_out
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_available():
+    """True when RCCL could be loaded by libgspx (gspx_comm_available)."""
+    return bool(_capi.load().gspx_comm_available())
+
+
+def comm_unique_id():
+    """A fresh RCCL unique id (bytes): made on rank 0, handed to the other ranks by the launcher."""
+    buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+    _capi.check(_capi.load().gspx_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of one rank (gspx_comm): the one-process-per-GPU form of the path's only
+    collective, the gather of the ranks' output blocks to a root over xGMI."""
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be {} bytes".format(COMM_ID_BYTES))
+        buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.load().gspx_comm_create(ctx._h, int(nranks), int(rank), buf, ctypes.byref(h)))
+        self._h, self.ctx, self.nranks, self.rank = h, ctx, int(nranks), int(rank)
+
+    def gather(self, part_ptr, nbytes_per_rank, root=0, root_out_ptr=None):
+        """Collective: this rank's block (device pointer, nbytes_per_rank[rank] bytes) lands in the root's
+        buffer at the offset of its rank.  Returns the device milliseconds of the exchange on this rank."""
+        table = np.ascontiguousarray(nbytes_per_rank, dtype=np.int64)
+        if table.shape != (self.nranks,):
+            raise ValueError("nbytes_per_rank must have one entry per rank")
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_comm_gather(
+            self._h, ctypes.c_void_p(part_ptr), _capi.ptr(table), int(root),
+            ctypes.c_void_p(root_out_ptr) if root_out_ptr else None, ctypes.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):
+                _capi.load().gspx_comm_destroy(self._h)
+            self._h = None
+
+
 def filter_batch(jobs, root_ctx=None):
     """Independent (graph, coefficients, signals, lmax) jobs, one driver thread per context: job i
     runs on the context its DeviceGraph lives on (ctypes releases the GIL inside libgspx), the

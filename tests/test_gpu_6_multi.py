@@ -1,5 +1,13 @@
-"""the path's one collective.  gspx_gather across contexts in one process, and (below)
-two ranks under torch.distributed sharing this box's GPU.  `-m gpu`."""
+"""the path's one collective.  gspx_gather across contexts in one process (peer copies and
+the RCCL form), the one-process-per-GPU communicator (gspx_comm_*: RCCL inside the library), and two
+ranks under torch.distributed.run sharing this box's one GPU (bench.py's N > 1 code path with libgspx
+outputs; RCCL refuses two ranks on one device, so that launch gathers over gloo).  `-m gpu`."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -49,3 +57,81 @@ def test_gather_and_batch_across_contexts(ctx):
             buf.free()
     finally:
         ctx2.close()
+
+
+def test_gather_through_rccl_in_the_library(ctx):
+    """Option gather_rccl = 2 routes every block of gspx_gather through RCCL (ncclCommInitAll over the
+    parts' devices, grouped ncclSend / ncclRecv) - on this one-GPU box as self send / recv, which still
+    runs RCCL's communicator set-up, group launch and copy kernels on hardware."""
+    if not engine.comm_available():
+        pytest.skip("RCCL cannot be loaded on this box")
+    ctx2 = engine.Context(ctx.device)
+    try:
+        rng = np.random.default_rng(5)
+        a, b = rng.standard_normal(70000), rng.standard_normal(12345).astype(np.float32)
+        pa, pb = ctx.upload(a), ctx2.upload(b)
+        root = ctx.alloc(a.nbytes + b.nbytes)
+        ctx.set_option("gather_rccl", 2)
+        try:
+            engine.gather([pa, pb], root)
+        finally:
+            ctx.set_option("gather_rccl", 1)
+        flat = root.download((a.nbytes + b.nbytes,), np.uint8)
+        assert np.array_equal(flat[:a.nbytes].view(np.float64), a)
+        assert np.array_equal(flat[a.nbytes:].view(np.float32), b)
+        for buf in (pa, pb, root):
+            buf.free()
+    finally:
+        ctx2.close()
+
+
+def test_comm_gather_one_rank(ctx):
+    """gspx_comm_*: unique id -> ncclCommInitRank -> grouped send / recv.  One rank here (one GPU): the
+    block of a filter output travels to the root buffer through RCCL and arrives bit for bit."""
+    if not engine.comm_available():
+        pytest.skip("RCCL cannot be loaded on this box")
+    W, coords = graphs.sensor_weights(40000, k=6, seed=9)
+    lmax = upper_lmax(W)
+    dev = engine.DeviceGraph.from_w(W, dtype=np.float64, perm=engine.locality_order(W, coords), ctx=ctx)
+    c = orc.compute_cheby_coeff(orc.heat_kernel(10, lmax), lmax, 20)
+    x = np.random.default_rng(3).standard_normal((W.shape[0], 16))
+    bx, by, broot = ctx.upload(x), ctx.alloc(x.nbytes), ctx.alloc(x.nbytes)
+    comm = engine.Comm(ctx, 1, 0, engine.comm_unique_id())
+    try:
+        dev.cheby_filter_dev(c, bx.ptr, by.ptr, 16, lmax)
+        ms = comm.gather(by.ptr, [x.nbytes], 0, broot.ptr)
+        assert ms >= 0
+        y = broot.download(x.shape, np.float64)
+        assert np.array_equal(y, by.download(x.shape, np.float64))
+        assert rel_err(y, orc.cheby_op(orc.laplacian(W), lmax, c, x)) < 1e-12
+        with pytest.raises(ValueError):
+            comm.gather(by.ptr, [x.nbytes, 0], 0, broot.ptr)
+    finally:
+        comm.close()
+        dev.destroy()
+        for b in (bx, by, broot):
+            b.free()
+
+
+def test_two_ranks_on_this_gpu_through_bench():
+    """bench.py --gpus 2 under torch.distributed.run, both ranks on device 0 (gloo process group): the
+    N > 1 path - independent graph per rank, barrier-bracketed timing, MAX over ranks, final gather - runs
+    end to end with libgspx outputs; rank 0 prints one JSON line with n_gpus = 2 and a gather time."""
+    pytest.importorskip("torch")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSPX_ALL_RANKS_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--vertices", "100000", "--nsig", "16",
+           "--backend", "gloo", "--no-newton"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["gather_ms"] is not None and out["gather_ms"] > 0 and out["gather_impl"]
+    assert out["config"]["N"] == 100000 and out["roofline"]["frac"] > 0
