@@ -412,6 +412,16 @@ def main():
             del blocks
             gather_impl = "torch.distributed ({}) send/recv".format("RCCL" if a.backend == "nccl" else a.backend)
 
+    # N > 1: every rank checks two columns of its own output against the oracle (outside the timed region)
+    parity_multi = None
+    if torch is not None and not a.no_cpu:
+        from oracle import cheby_oracle as orc
+        ref = orc.cheby_op(G.L.astype(np.float64), lmax, c[0], x[:, :2].astype(np.float64))
+        y2 = ty.cpu().numpy()[0][:, :2]
+        err = float(np.max(np.abs(y2 - ref)) / np.max(np.abs(ref)))
+        parity_multi = {"max_rel_err": gdist.max_over_ranks(err, rdev), "columns": 2, "ranks": world,
+                        "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
+
     tiled = bool(G.tile_stats and G.tile_stats.get("enabled"))
 
     def newton_report(r, pair):
@@ -549,6 +559,8 @@ def main():
             out["configs"] = run_configs(ctx, a.only_config, a.config_reps, a.config_oracle_cols)
         except Exception as e:
             out["configs"] = {"error": repr(e)}
+    if rank == 0 and parity_multi is not None:
+        out["parity_vs_oracle"] = parity_multi
     if rank == 0:
         print(json.dumps(out))
     if torch is not None:

@@ -135,3 +135,4 @@ def test_two_ranks_on_this_gpu_through_bench():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["gather_ms"] is not None and out["gather_ms"] > 0 and out["gather_impl"]
     assert out["config"]["N"] == 100000 and out["roofline"]["frac"] > 0
+    assert out["parity_vs_oracle"]["ranks"] == 2 and out["parity_vs_oracle"]["max_rel_err"] < 1e-11
