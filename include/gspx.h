@@ -296,6 +296,11 @@ int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const 
  * for graphs with coordinates is the stable argsort of these keys (pygsp_amd.engine.locality_order). */
 int gspx_curve_keys(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve, uint64_t* keys);
 
+/* Columns [j0, j0 + w) of the N x N identity as a row-major N x w panel in device memory (dtype GSPX_F32 /
+ * GSPX_F64), queued on the context's stream: the input of Filter.compute_frame (filter.py:593-600 filters
+ * np.identity(N)) produced where it is consumed. */
+int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int64_t w, void* out_dev);
+
 /* timing breakdown of the LAST filter call on this graph's ctx (milliseconds, HIP events):
  *   out[0] total device time, out[1] time inside the recurrence-step launches only,
  *   out[2] number of step launches, out[3] permute-in/copy time, out[4] combine time */

@@ -2544,6 +2544,36 @@ extern "C" int gspx_lanczos_lmax(gspx_graph* g, int max_iter, double tol, double
 // calibration: streaming copy with the engine's own 16-byte-per-lane copy kernel (k_permute_in
 // without a permutation) - the measured HBM ceiling quoted beside every roofline fraction.
 // ------------------------------------------------------------------------------------------------
+// Columns [j0, j0 + w) of the N x N identity as a row-major N x w panel, written on the device: the
+// input of Filter.compute_frame (filter.py:593-600 filters np.identity(N)) without an N x N host array or
+// its trip over PCIe.
+template <typename T> __global__ void k_identity_panel(T* __restrict__ out, int N, int j0, int w) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * w) return;
+  const int row = (int)(i / w), col = (int)(i % w);
+  out[i] = row == j0 + col ? T(1) : T(0);
+}
+
+extern "C" int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int64_t w, void* out_dev) {
+  if (!ctx || N < 0 || j0 < 0 || w < 0 || j0 + w > N || (dtype != GSPX_F32 && dtype != GSPX_F64))
+    return set_err(GSPX_ERR_INVALID, "gspx_identity_panel_dev: bad argument");
+  if (N * w == 0) return GSPX_OK;
+  if (!out_dev) return set_err(GSPX_ERR_INVALID, "gspx_identity_panel_dev: null output");
+  if (N >= ((int64_t)1 << 31) || w >= ((int64_t)1 << 31))
+    return set_err(GSPX_ERR_INVALID, "gspx_identity_panel_dev: panel too large");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t total = (size_t)N * (size_t)w;
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (dtype == GSPX_F32)
+    hipLaunchKernelGGL((k_identity_panel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)out_dev, (int)N,
+                       (int)j0, (int)w);
+  else
+    hipLaunchKernelGGL((k_identity_panel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)out_dev, (int)N,
+                       (int)j0, (int)w);
+  HIPCHK(hipGetLastError());
+  return GSPX_OK;
+}
+
 extern "C" int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps) {
   if (!ctx || !gbps || bytes < 4096 || iters < 1)
     return set_err(GSPX_ERR_INVALID, "gspx_bench_copy: bad argument");

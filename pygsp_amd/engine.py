@@ -70,6 +70,11 @@ class Context:
         buf.upload(arr)
         return buf
 
+    def identity_panel(self, buf, N, j0, w, dtype):
+        """Write columns [j0, j0 + w) of the N x N identity into `buf` (row-major N x w, on the device)."""
+        _capi.check(_capi.load().gspx_identity_panel_dev(self._h, _capi.dtype_code(dtype), int(N), int(j0), int(w),
+                                                        ctypes.c_void_p(buf.ptr)))
+
 
 _default_ctx = {}
 _default_lock = threading.Lock()

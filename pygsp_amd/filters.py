@@ -11,41 +11,45 @@ Mirrors (names, argument meaning, shapes, exceptions):
 Only ``method='chebyshev'`` is implemented: it is the accelerated path.  The exact (Fourier)
 method is a different algorithm (dense eigendecomposition) and stays with the reference.
 """
-import functools
-
 import numpy as np
 
 from . import _capi
 
+# Interface notes.  Function / class names, argument lists and exception messages follow the reference
+# (BSD-3-Clause, epfl-lts2/pygsp) because they are the contract a drop-in has to honour; the bodies are
+# this package's own.
+
 
 def filterbank_handler(func):
-    """utils.py:37-53: call `func` once per filter of the bank unless an index `i` is given."""
-    @functools.wraps(func)
-    def inner(f, *args, **kwargs):
-        if "i" in kwargs or f.Nf <= 1:
-            return func(f, *args, **kwargs)
-        return [func(f, *args, i=i, **kwargs) for i in range(f.Nf)]
-    return inner
+    """Decorator with the calling convention of pygsp.utils.filterbank_handler (utils.py:37-53): the
+    wrapped function sees one kernel of the bank (keyword ``i``); called without ``i`` on a bank of
+    several kernels it is mapped over all of them and the results come back as a list."""
+    def per_kernel(bank, *args, **kwargs):
+        if bank.Nf > 1 and "i" not in kwargs:
+            return [func(bank, *args, i=index, **kwargs) for index in range(bank.Nf)]
+        return func(bank, *args, **kwargs)
+    per_kernel.__name__ = func.__name__
+    per_kernel.__doc__ = func.__doc__
+    per_kernel.__wrapped__ = func
+    return per_kernel
 
 
 @filterbank_handler
 def compute_cheby_coeff(f, m=30, N=None, *args, **kwargs):
-    """Chebyshev coefficients of kernel `i` of filterbank `f` on [0, lmax] (host, float64).
+    """Chebyshev coefficients c_0..c_m of kernel ``i`` of filterbank ``f`` on [0, lmax], by Gauss-Chebyshev
+    quadrature on N = m + 1 points (approximations.py:9-55; host, float64):
 
-    c[o] = 2/N * sum_j g(a1 cos(pi (j+1/2)/N) + a2) cos(pi o (j+1/2)/N),  a1 = a2 = lmax/2.
-    """
-    G = f.G
-    i = kwargs.pop("i", 0)
-    if not N:
-        N = m + 1
-    a1 = a2 = G.lmax / 2
-    j = np.arange(N)
-    samples = f._kernels[i](a1 * np.cos(np.pi * (j + 0.5) / N) + a2)
-    c = np.empty(m + 1)
-    for o in range(m + 1):
-        # same operation order as the reference, so the coefficients are bit-identical
-        c[o] = 2.0 / N * np.dot(samples, np.cos(np.pi * o * (j + 0.5) / N))
-    return c
+        c_o = 2/N * sum_j g(lmax/2 * (cos(theta_j) + 1)) * cos(o * theta_j),   theta_j = pi (j + 1/2) / N
+
+    The products are formed in the reference's order (2/N * dot(samples, cos(pi * o * (j + 1/2) / N))), so
+    the coefficients equal the reference's to the last bit and the parity tests compare like with like."""
+    which = kwargs.pop("i", 0)
+    points = int(N) if N else m + 1
+    half = f.G.lmax / 2
+    grid = np.arange(points)
+    samples = f._kernels[which](half * np.cos(np.pi * (grid + 0.5) / points) + half)
+    return np.array([2.0 / points * np.dot(samples, np.cos(np.pi * order * (grid + 0.5) / points))
+                     for order in range(m + 1)])
 
 
 # How a SINGLE filter's polynomial is evaluated on the device (filterbanks and synthesis always
@@ -131,12 +135,12 @@ def cheb_to_newton(c):
 
 
 def _as_coeff_matrix(c):
-    if not isinstance(c, np.ndarray):
-        c = np.array(c)
-    c = np.atleast_2d(c)
-    if c.shape[1] < 2:
+    """(Nf, M) float64 from what the reference accepts as ``c``: one vector, a 2-D array or a list of
+    vectors (approximations.py:77-84, where M < 2 is the TypeError below)."""
+    mat = np.ascontiguousarray(np.atleast_2d(np.asarray(c)), dtype=np.float64)
+    if mat.ndim != 2 or mat.shape[1] < 2:
         raise TypeError("The coefficients have an invalid shape")
-    return np.ascontiguousarray(c, dtype=np.float64)
+    return mat
 
 
 def cheby_op(G, c, signal, **kwargs):
@@ -146,68 +150,68 @@ def cheby_op(G, c, signal, **kwargs):
     list of vectors; `signal` is (N,) or (N, Nsig) of any real dtype / memory order; returns a
     float64 array of shape (Nf*N,) or (Nf*N, Nsig), block f = rows [f*N, (f+1)*N).
     """
-    c = _as_coeff_matrix(c)
-    Nf = c.shape[0]
-    signal = np.asanyarray(signal)
-    if np.iscomplexobj(signal):
+    coeffs = _as_coeff_matrix(c)
+    panel = np.asanyarray(signal)
+    if np.iscomplexobj(panel):
         raise TypeError("complex signals are not supported by the Chebyshev path")
-    if signal.ndim not in (1, 2) or signal.shape[0] != G.N:
+    if panel.ndim not in (1, 2) or panel.shape[0] != G.N:
         raise ValueError("First dimension must be the number of vertices "
-                         "G.N = {}, got {}.".format(G.N, signal.shape))
-    one_d = signal.ndim == 1
-    x = signal.reshape(G.N, 1) if one_d else signal
-    dev = _device_graph_of(G)
+                         "G.N = {}, got {}.".format(G.N, panel.shape))
+    vector_in = panel.ndim == 1
+    x = panel[:, np.newaxis] if vector_in else panel
     evaluation = kwargs.get("evaluation") or EVALUATION
     if evaluation not in ("recurrence", "newton"):
         raise ValueError("evaluation must be 'recurrence' or 'newton'")
-    if evaluation == "newton" and Nf == 1:
-        nodes, dcoef = cheb_to_newton(c[0])
-        y, ms = dev.newton_filter(nodes, dcoef, x, G.lmax)
-        y = y[None]
+    dev = _device_graph_of(G)
+    if evaluation == "newton" and coeffs.shape[0] == 1:
+        y, ms = dev.newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
     else:
-        y, ms = dev.cheby_filter(c, x, G.lmax, _capi.ANALYSIS)
+        y, ms = dev.cheby_filter(coeffs, x, G.lmax, _capi.ANALYSIS)
     _record_timing(G, ms)
-    r = np.asarray(y, dtype=np.float64).reshape(Nf * G.N, x.shape[1])
-    return r[:, 0] if one_d else r
+    stacked = np.asarray(y, dtype=np.float64).reshape(coeffs.shape[0] * G.N, x.shape[1])
+    return stacked[:, 0] if vector_in else stacked
+
+
+def _rect_coefficients(lo, hi, order):
+    """Chebyshev coefficients of the indicator of [cos(hi_angle), cos(lo_angle)] given the two angles
+    (closed form of the integrals; the k = 0 term is doubled because the recurrence halves c_0)."""
+    k = np.arange(1, order + 1)
+    return np.concatenate([[2.0 * (lo - hi) / np.pi], 2.0 / (k * np.pi) * (np.sin(k * lo) - np.sin(k * hi))])
 
 
 def cheby_rect(G, bounds, signal, **kwargs):
     """Ideal band-pass [bounds[0], bounds[1]] by its Chebyshev expansion (approximations.py:117-163):
     the same recurrence as cheby_op with closed-form coefficients
     c_0 = 2 (b1 - b2)/pi,  c_k = 2/(k pi) (sin k b1 - sin k b2),  b = arccos(2 bounds/lmax - 1)."""
-    if not (isinstance(bounds, (list, np.ndarray)) and len(bounds) == 2):
+    ok = isinstance(bounds, (list, np.ndarray)) and len(bounds) == 2
+    if not ok:
         raise ValueError("Bounds of wrong shape.")
-    bounds = np.array(bounds, dtype=np.float64)
     order = int(kwargs.pop("order", 30))
-    b1, b2 = np.arccos(2.0 * bounds / G.lmax - 1.0)
-    k = np.arange(1, order + 1)
-    c = np.empty(order + 1)
-    c[0] = 2.0 * (b1 - b2) / np.pi  # cheby_op halves c_0
-    c[1:] = 2.0 / (k * np.pi) * (np.sin(k * b1) - np.sin(k * b2))
-    return cheby_op(G, c, signal, **kwargs)
+    angles = np.arccos(2.0 * np.asarray(bounds, dtype=np.float64) / G.lmax - 1.0)
+    return cheby_op(G, _rect_coefficients(angles[0], angles[1], order), signal, **kwargs)
 
 
 def compute_jackson_cheby_coeff(filter_bounds, delta_lambda, m):
     """Chebyshev and Jackson-damped coefficients of the ideal band-pass [a, b] on
     [lambda_min, lambda_max] (approximations.py:166-225).  Unlike the reference this does not
     rescale the caller's `filter_bounds` list in place."""
-    if delta_lambda[0] > filter_bounds[0] or delta_lambda[1] < filter_bounds[1]:
+    lam_lo, lam_hi = float(delta_lambda[0]), float(delta_lambda[1])
+    band_lo, band_hi = float(filter_bounds[0]), float(filter_bounds[1])
+    if band_lo < lam_lo or band_hi > lam_hi:
         raise ValueError("Bounds of the filter are out of the lambda values")
-    if delta_lambda[0] > delta_lambda[1]:
+    if lam_lo > lam_hi:
         raise ValueError("lambda_min is greater than lambda_max")
-    a1 = (delta_lambda[1] - delta_lambda[0]) / 2
-    a2 = (delta_lambda[1] + delta_lambda[0]) / 2
-    lo = (filter_bounds[0] - a2) / a1
-    hi = (filter_bounds[1] - a2) / a1
-    ch = np.empty(m + 1, dtype=float)
-    ch[0] = (2 / np.pi) * (np.arccos(lo) - np.arccos(hi))
-    i = np.arange(1, m + 1)
-    ch[1:] = (2 / (np.pi * i)) * (np.sin(i * np.arccos(lo)) - np.sin(i * np.arccos(hi)))
-    alpha = np.pi / (m + 2)
-    i = np.arange(m + 1)
-    jch = (1 / np.sin(alpha)) * ((1 - i / (m + 2)) * np.sin(alpha) * np.cos(i * alpha)
-                                + (1 / (m + 2)) * np.cos(alpha) * np.sin(i * alpha))
-    return ch, ch * jch
+    centre, radius = (lam_hi + lam_lo) / 2, (lam_hi - lam_lo) / 2
+    angle_lo, angle_hi = np.arccos((band_lo - centre) / radius), np.arccos((band_hi - centre) / radius)
+    idx = np.arange(m + 1)
+    ch = np.empty(m + 1)
+    ch[0] = (2 / np.pi) * (angle_lo - angle_hi)
+    ch[1:] = (2 / (np.pi * idx[1:])) * (np.sin(idx[1:] * angle_lo) - np.sin(idx[1:] * angle_hi))
+    # Jackson damping factors (Jackson kernel of order m, step pi / (m + 2))
+    step = np.pi / (m + 2)
+    damping = ((1 - idx / (m + 2)) * np.sin(step) * np.cos(idx * step)
+               + np.cos(step) * np.sin(idx * step) / (m + 2)) / np.sin(step)
+    return ch, ch * damping
 
 
 def _device_graph_of(G):
@@ -227,19 +231,32 @@ def _record_timing(G, ms):
 
 
 class Filter:
-    """Filterbank of kernels g_i(lambda) on a graph (filter.py:16-110)."""
+    """A bank of kernels g_i(lambda) on a graph, applied by Chebyshev filtering on the device.
+
+    The public surface is that of pygsp.filters.Filter for this path (filter.py:16-600): ``G``, ``Nf`` /
+    ``n_filters`` / ``n_features_in`` / ``n_features_out`` / ``shape``, ``len()``, indexing, ``+``, ``@``,
+    ``evaluate``, ``filter`` / ``analyze`` / ``synthesize`` / ``localize`` / ``compute_frame``."""
 
     def __init__(self, G, kernels):
         self.G = G
-        try:
-            iter(kernels)
-        except TypeError:
-            kernels = [kernels]
-        self._kernels = kernels
-        self.n_features_in, self.n_features_out = (1, len(kernels))
-        self.shape = (self.n_features_out, self.n_features_in)
-        self.n_filters = self.n_features_in * self.n_features_out
-        self.Nf = self.n_filters
+        self._kernels = list(kernels) if hasattr(kernels, "__iter__") else [kernels]
+
+    # the bank maps one input feature to len(kernels) output features (filter.py:65-68)
+    n_features_in = 1
+
+    @property
+    def n_features_out(self):
+        return len(self._kernels)
+
+    @property
+    def n_filters(self):
+        return self.n_features_in * self.n_features_out
+
+    Nf = n_filters
+
+    @property
+    def shape(self):
+        return self.n_features_out, self.n_features_in
 
     def __len__(self):
         return self.n_filters
@@ -248,24 +265,35 @@ class Filter:
         return Filter(self.G, self._kernels[key])
 
     def __add__(self, other):
-        if not isinstance(other, Filter):
-            return NotImplemented
-        return Filter(self.G, self._kernels + other._kernels)
+        return Filter(self.G, self._kernels + other._kernels) if isinstance(other, Filter) else NotImplemented
 
     def __matmul__(self, other):
         return self.filter(other)
 
     def __repr__(self):
-        return "{}(in={}, out={})".format(self.__class__.__name__, self.n_features_in,
-                                          self.n_features_out)
+        return "{}(in={}, out={})".format(type(self).__name__, self.n_features_in, self.n_features_out)
 
     def evaluate(self, x):
-        """Frequency response, shape (Nf, len(x)) (filter.py:112-144)."""
-        x = np.asanyarray(x)
-        y = np.empty([self.Nf] + list(x.shape))
-        for i, kernel in enumerate(self._kernels):
-            y[i] = kernel(x)
-        return y
+        """Frequency response of every kernel at `x`: shape (Nf,) + x.shape (filter.py:112-144)."""
+        at = np.asanyarray(x)
+        return np.stack([np.broadcast_to(g(at), at.shape) for g in self._kernels]).astype(np.float64)
+
+    # ---- shape algebra of Filter.filter (filter.py:267-290) -------------------------------------------
+    def _as_three_axes(self, s):
+        """`s` as (vertices, signals, input features) plus whether the call is a synthesis.  A trailing
+        axis of length 1 or Nf is the feature axis; Nf (> 1) input features mean synthesis."""
+        s = self.G._check_signal(s)
+        feature_axis = s.ndim > 1 and s.shape[-1] in (1, self.Nf)
+        if not feature_axis:
+            if s.ndim == 3:
+                raise ValueError("Third dimension (#features) should be either 1 or the number "
+                                 "of filters Nf = {}, got {}.".format(self.Nf, s.shape))
+            s = s[..., np.newaxis]
+        if s.ndim == 2:
+            s = s[:, np.newaxis, :]
+        if s.ndim != 3:
+            raise ValueError("At most 3 dimensions: #nodes x #signals x #features.")
+        return s, s.shape[2] != 1
 
     def filter(self, s, method="chebyshev", order=30):
         """Filter signals (analysis or synthesis), filter.py:146-328.
@@ -274,114 +302,156 @@ class Filter:
         Nfeat in {1, Nf}; a trailing dimension equal to Nf means synthesis.  The result is
         squeezed.
         """
-        s = self.G._check_signal(s)
-        if s.ndim == 1 or s.shape[-1] not in [1, self.Nf]:
-            if s.ndim == 3:
-                raise ValueError("Third dimension (#features) should be either 1 or the number "
-                                 "of filters Nf = {}, got {}.".format(self.Nf, s.shape))
-            s = np.expand_dims(s, -1)
-        n_features_in = s.shape[-1]
-        if s.ndim < 3:
-            s = np.expand_dims(s, 1)
-        n_signals = s.shape[1]
-        if s.ndim > 3:
-            raise ValueError("At most 3 dimensions: #nodes x #signals x #features.")
-        assert s.ndim == 3
-        n_features_out = self.Nf if n_features_in == 1 else 1
-
-        if method == "chebyshev":
-            c = compute_cheby_coeff(self, m=order)
-            if n_features_in == 1:  # analysis
-                s = s.squeeze(axis=2)
-                s = cheby_op(self.G, c, s)
-                # [filter][vertex][signal] buffer -> zero-copy (N, Nsig, Nf) view
-                s = s.reshape((self.G.N, n_features_out, n_signals), order="F")
-                s = s.swapaxes(1, 2)
-            else:  # synthesis: out = sum_f p_f(L) s[:, :, f]  (filter.py:313-322)
-                cm = _as_coeff_matrix(c)
-                if np.iscomplexobj(s):
-                    raise TypeError("complex signals are not supported by the Chebyshev path")
-                x = np.ascontiguousarray(np.moveaxis(s, 2, 0))  # (Nf, N, Nsig)
-                dev = _device_graph_of(self.G)
-                y, ms = dev.cheby_filter(cm, x, self.G.lmax, _capi.SYNTHESIS)
-                _record_timing(self.G, ms)
-                s = np.expand_dims(np.asarray(y, dtype=np.float64), 2)
-        elif method == "exact":
+        cube, synthesis = self._as_three_axes(s)
+        if method == "exact":
             raise NotImplementedError(
                 "method='exact' (dense Fourier filtering, filter.py:292-301) is outside the "
                 "accelerated path; use the reference implementation for it.")
-        else:
+        if method != "chebyshev":
             raise ValueError("Unknown method {}.".format(method))
-        return s.squeeze()
+        coeffs = compute_cheby_coeff(self, m=order)
+        if not synthesis:
+            # device buffer [filter][vertex][signal] -> (vertex, signal, filter), as filter.py:310-311
+            flat = cheby_op(self.G, coeffs, cube[:, :, 0])
+            out = np.moveaxis(flat.reshape(self.Nf, self.G.N, cube.shape[1]), 0, 2)
+        else:
+            # out = sum_f p_f(L) s[:, :, f]  (filter.py:313-322), one device call
+            if np.iscomplexobj(cube):
+                raise TypeError("complex signals are not supported by the Chebyshev path")
+            planes = np.ascontiguousarray(np.moveaxis(cube, 2, 0))
+            y, ms = _device_graph_of(self.G).cheby_filter(_as_coeff_matrix(coeffs), planes, self.G.lmax,
+                                                          _capi.SYNTHESIS)
+            _record_timing(self.G, ms)
+            out = np.asarray(y, dtype=np.float64)
+        return np.squeeze(out)
 
     def analyze(self, s, method="chebyshev", order=30):
-        if s.ndim == 3 and s.shape[-1] != 1:
-            raise ValueError("Last dimension (#features) should be 1, got {}.".format(s.shape))
+        if np.ndim(s) == 3 and np.shape(s)[-1] != 1:
+            raise ValueError("Last dimension (#features) should be 1, got {}.".format(np.shape(s)))
         return self.filter(s, method, order)
 
     def synthesize(self, s, method="chebyshev", order=30):
-        if s.shape[-1] != self.Nf:
+        if np.shape(s)[-1] != self.Nf:
             raise ValueError("Last dimension (#features) should be the number of filters "
-                             "Nf = {}, got {}.".format(self.Nf, s.shape))
+                             "Nf = {}, got {}.".format(self.Nf, np.shape(s)))
         return self.filter(s, method, order)
 
     def localize(self, i, **kwargs):
-        """sqrt(N) * filter(delta_i)  (filter.py:350-391)."""
-        s = np.zeros(self.G.N)
-        s[i] = 1
-        return np.sqrt(self.G.N) * self.filter(s, **kwargs)
+        """The kernel(s) localised at vertex i: sqrt(N) * filter(delta_i)  (filter.py:350-391)."""
+        delta = np.zeros(self.G.N)
+        delta[i] = 1.0
+        return self.filter(delta, **kwargs) * np.sqrt(self.G.N)
 
     def compute_frame(self, **kwargs):
-        """Filter the identity: (Nf*N, N) frame matrix (filter.py:506-600)."""
-        s = np.identity(self.G.N)
-        return self.filter(s, **kwargs).T.reshape(-1, self.G.N)
+        """The (Nf*N, N) matrix whose rows are the localised kernels (filter.py:506-600): the bank applied
+        to every delta, i.e. to the identity - N signals, produced on the device panel by panel
+        (no N x N identity is ever held or shipped; see _frame_panels)."""
+        method, order = kwargs.pop("method", "chebyshev"), kwargs.pop("order", 30)
+        if kwargs:
+            raise TypeError("unexpected arguments {}".format(sorted(kwargs)))
+        if method != "chebyshev":
+            return self.filter(np.identity(self.G.N), method=method, order=order).T.reshape(-1, self.G.N)
+        return _frame_panels(self, order)
+
+
+def _frame_panels(bank, order, panel=1024):
+    """compute_frame without the dense identity: column j of block f of the frame is p_f(L) delta_j.
+    Columns [j0, j0 + w) of the identity are written on the device (gspx_identity_panel_dev), filtered
+    there in one call per panel, and only the result crosses PCIe - no N x N identity is built or
+    shipped.  `panel` signals per call keep the workspace bounded (w = N would need K+1 panels of N x N)."""
+    G, Nf = bank.G, bank.Nf
+    coeffs = _as_coeff_matrix(compute_cheby_coeff(bank, m=order))
+    dev = _device_graph_of(G)
+    frame = np.empty((Nf, G.N, G.N))
+    total_ms = 0.0
+    on_device = hasattr(dev, "ctx") and hasattr(dev, "cheby_filter_dev")
+    if on_device:
+        elt = np.dtype(dev.dtype).itemsize
+        width = min(panel, G.N)
+        bx, by = dev.ctx.alloc(max(G.N * width * elt, 16)), dev.ctx.alloc(max(Nf * G.N * width * elt, 16))
+    try:
+        for j0 in range(0, G.N, panel):
+            w = min(panel, G.N - j0)
+            if on_device:
+                dev.ctx.identity_panel(bx, G.N, j0, w, dev.dtype)
+                total_ms += dev.cheby_filter_dev(coeffs, bx.ptr, by.ptr, w, G.lmax)
+                y = by.download((Nf, G.N, w), dev.dtype)
+            else:  # a stand-in device object (tests): host panel through its array interface
+                deltas = np.zeros((G.N, w))
+                deltas[j0 + np.arange(w), np.arange(w)] = 1
+                y, ms = dev.cheby_filter(coeffs, deltas, G.lmax, _capi.ANALYSIS)
+                total_ms += ms
+            frame[:, :, j0:j0 + w] = y
+    finally:
+        if on_device:
+            bx.free()
+            by.free()
+    _record_timing(G, total_ms)
+    return frame.reshape(Nf * G.N, G.N)
+
+
+class _HeatKernel:
+    """min(exp(-tau x / lmax), 1) / norm; lmax is read from the graph when the kernel is evaluated."""
+
+    def __init__(self, graph, tau, norm=1.0):
+        self.graph, self.tau, self.norm = graph, tau, norm
+
+    def __call__(self, x):
+        return np.minimum(np.exp(-self.tau * x / self.graph.lmax), 1) / self.norm
 
 
 class Heat(Filter):
-    """g(x) = min(exp(-scale * x / lmax), 1) [/ norm]  (heat.py:102-119).  lmax is read when the
-    kernel is EVALUATED, like the reference's closure."""
+    """Heat kernels g(x) = min(exp(-scale x / lmax), 1), optionally normalised to unit l2 norm over the
+    spectrum G.e (heat.py:102-119).  `scale` is one diffusion time or a list of them."""
 
     def __init__(self, G, scale=10, normalize=False):
-        try:
-            iter(scale)
-        except TypeError:
-            scale = [scale]
-        self.scale = scale
+        self.scale = list(scale) if hasattr(scale, "__iter__") else [scale]
         self.normalize = normalize
-
-        def kernel(x, scale):
-            return np.minimum(np.exp(-scale * x / G.lmax), 1)
-
         kernels = []
-        for s in scale:
-            norm = np.linalg.norm(kernel(G.e, s)) if normalize else 1
-            kernels.append(lambda x, s=s, norm=norm: kernel(x, s) / norm)
+        for tau in self.scale:
+            g = _HeatKernel(G, tau)
+            if normalize:
+                g.norm = np.linalg.norm(g(G.e))
+            kernels.append(g)
         super().__init__(G, kernels)
 
 
 def compute_log_scales(lmin, lmax, Nscales, t1=1, t2=2):
-    """utils.py:312-339: log-spaced wavelet scales from t2/lmin down to t1/lmax."""
+    """utils.py:312-339: Nscales scales, logarithmically spaced from t2 / lmin down to t1 / lmax."""
     return np.exp(np.linspace(np.log(t2 / lmin), np.log(t1 / lmax), Nscales))
 
 
+class _MexicanLowPass:
+    """1.2 / e * exp(-(x / (0.4 lmin))^4), the scaling-function kernel of the bank."""
+
+    def __init__(self, lmin):
+        self.lmin = lmin
+
+    def __call__(self, x):
+        return 1.2 * np.exp(-1) * np.exp(-((x / 0.4 / self.lmin) ** 4))
+
+
+class _MexicanBandPass:
+    """t x exp(-t x) (times sqrt(t) when normalised): the scaled Mexican-hat wavelet kernel."""
+
+    def __init__(self, t, normalize):
+        self.t, self.gain = t, (np.sqrt(t) if normalize else 1)
+
+    def __call__(self, x):
+        return self.gain * (self.t * x) * np.exp(-(self.t * x))
+
+
 class MexicanHat(Filter):
-    """Low-pass 1.2 e^-1 exp(-(x / (0.4 lmin))^4) plus Nf-1 band-passes s x exp(-s x)
-    (mexicanhat.py:55-84).  lmin = lmax / lpfactor is captured at construction."""
+    """Mexican-hat wavelet bank (mexicanhat.py:55-84): one low-pass 1.2/e * exp(-(x / (0.4 lmin))^4) with
+    lmin = lmax / lpfactor fixed at construction, and Nf - 1 band-passes t x exp(-t x) at log-spaced
+    scales t."""
 
     def __init__(self, G, Nf=6, lpfactor=20, scales=None, normalize=False):
-        self.lpfactor = lpfactor
-        self.normalize = normalize
+        self.lpfactor, self.normalize = lpfactor, normalize
         lmin = G.lmax / lpfactor
-        if scales is None:
-            scales = compute_log_scales(lmin, G.lmax, Nf - 1)
-        self.scales = scales
-        if len(scales) != Nf - 1:
+        self.scales = compute_log_scales(lmin, G.lmax, Nf - 1) if scales is None else scales
+        if len(self.scales) != Nf - 1:
             raise ValueError("len(scales) should be Nf-1.")
-
-        kernels = [lambda x: 1.2 * np.exp(-1) * np.exp(-((x / 0.4 / lmin) ** 4))]
-        for i in range(Nf - 1):
-            def kernel(x, i=i):
-                norm = np.sqrt(scales[i]) if normalize else 1
-                return norm * (scales[i] * x) * np.exp(-(scales[i] * x))
-            kernels.append(kernel)
-        super().__init__(G, kernels)
+        bank = [_MexicanLowPass(lmin)]
+        bank.extend(_MexicanBandPass(t, normalize) for t in self.scales)
+        super().__init__(G, bank)

@@ -28,59 +28,62 @@ from . import engine
 _logger = logging.getLogger(__name__)
 
 
+def _checked_adjacency(adjacency, log):
+    """The weight matrix as canonical-ready CSR, after the reference's checks (graph.py:98-134): square,
+    finite; self-loops and negative weights only warn."""
+    dense = None if sparse.issparse(adjacency) else np.asanyarray(adjacency)
+    shape = adjacency.shape if dense is None else dense.shape
+    if len(shape) != 2 or shape[0] != shape[1]:
+        raise ValueError("Adjacency: must be a square matrix.")
+    W = sparse.csr_matrix(adjacency if dense is None else dense, copy=False)
+    mass = W.sum()
+    if np.isnan(mass):
+        raise ValueError("Adjacency: there is a Not a Number (NaN).")
+    if np.isinf(mass):
+        raise ValueError("Adjacency: there is an infinite value.")
+    if np.any(W.diagonal() != 0):
+        log.warning("Adjacency: there are self-loops (non-zeros on the diagonal). "
+                    "The Laplacian will not see them.")
+    if W.nnz and W.data.min() < 0:
+        log.warning("Adjacency: there are negative edge weights.")
+    W.eliminate_zeros()
+    return W
+
+
 class Graph:
+    """A weighted graph whose Laplacian lives on the GPU.  Same constructor contract as
+    pygsp.graphs.Graph for the path (adjacency, lap_type, coords, plotting); the keyword-only arguments
+    are this engine's: compute dtype, device, internal vertex order, gather tiles."""
+
     def __init__(self, adjacency, lap_type="combinatorial", coords=None, plotting={}, *,
                  compute_dtype=np.float64, device=0, reorder="auto", tiles="auto"):
         self.logger = _logger
-        if not sparse.issparse(adjacency):
-            adjacency = np.asanyarray(adjacency)
-        if adjacency.ndim != 2 or adjacency.shape[0] != adjacency.shape[1]:
-            raise ValueError("Adjacency: must be a square matrix.")
-        self._adjacency = sparse.csr_matrix(adjacency, copy=False)
-        total = self._adjacency.sum()
-        if np.isnan(total):
-            raise ValueError("Adjacency: there is a Not a Number (NaN).")
-        if np.isinf(total):
-            raise ValueError("Adjacency: there is an infinite value.")
-        if self._adjacency.diagonal().any():
-            self.logger.warning("Adjacency: there are self-loops (non-zeros on the diagonal). "
-                                "The Laplacian will not see them.")
-        if (self._adjacency < 0).nnz != 0:
-            self.logger.warning("Adjacency: there are negative edge weights.")
-        self.n_vertices = self._adjacency.shape[0]
-        self._adjacency.eliminate_zeros()
-
-        self._directed = None
-        if self.is_directed():
-            self.n_edges = self._adjacency.nnz
-        else:
-            diagonal = int(np.count_nonzero(self._adjacency.diagonal()))
-            self.n_edges = (self._adjacency.nnz - diagonal) // 2 + diagonal
+        self._adjacency = _checked_adjacency(adjacency, self.logger)
+        self.n_vertices = self.N = self._adjacency.shape[0]
+        self._flags = {}   # lazily computed facts about W ("directed")
+        # stored entries of a directed graph; unordered pairs (+ self-loops) of an undirected one
+        loops = int(np.count_nonzero(self._adjacency.diagonal()))
+        stored = self._adjacency.nnz
+        self.n_edges = self.Ne = stored if self.is_directed() else (stored - loops) // 2 + loops
         if coords is not None:
             self.coords = np.asanyarray(coords)
-        self.plotting = dict(plotting)
-        self.signals = dict()
+        self.plotting, self.signals = dict(plotting), {}
 
-        self.compute_dtype = np.dtype(compute_dtype)
-        self.device = int(device)
+        # engine-side configuration and state
+        self.compute_dtype, self.device = np.dtype(compute_dtype), int(device)
         self.reorder = reorder
         self.tiles = tiles  # "auto" | True | False: gather tiles of the LDS-staged recurrence step
         self.tile_stats = None
-        self._perm = None
-        self._perm_done = False
-
-        self._dw = None
-        self._lmax = None
-        self._lmax_method = None
-        self._U = None
-        self._e = None
-        self._L = None
-        self._dev = {}
-
+        self._perm, self._perm_done = None, False
+        self._dev = {}     # compute dtype -> engine.DeviceGraph
+        self._L = self._dw = None
+        self._forget_spectrum()
         self.lap_type = lap_type
         self.compute_laplacian(lap_type)
-        self.Ne = self.n_edges
-        self.N = self.n_vertices
+
+    def _forget_spectrum(self):
+        """Everything derived from the Laplacian's spectrum (graph.py:602-609)."""
+        self._lmax = self._lmax_method = self._e = self._U = None
 
     # ---- adjacency -----------------------------------------------------------------------------
     @property
@@ -88,15 +91,19 @@ class Graph:
         return self._adjacency
 
     def is_directed(self):
-        if self._directed is None:
-            self._directed = (self.W != self.W.T).nnz != 0
-        return self._directed
+        """True when W differs from its transpose (graph.py:357-405); computed once."""
+        if "directed" not in self._flags:
+            W = self._adjacency
+            self._flags["directed"] = bool((W - W.T).count_nonzero())
+        return self._flags["directed"]
+
+    @property
+    def _directed(self):
+        return self._flags.get("directed")
 
     def _symmetric_w(self):
         """W itself if undirected, else (W + W.T)/2 (utils.symmetrize 'average', graph.py:613-616)."""
-        if not self.is_directed():
-            return self.W
-        return sparse.csr_matrix((self.W + self.W.T) / 2)
+        return sparse.csr_matrix((self.W + self.W.T) / 2) if self.is_directed() else self.W
 
     # ---- Laplacian (device) --------------------------------------------------------------------
     def _internal_order(self):
@@ -141,52 +148,45 @@ class Graph:
         if lap_type not in ("combinatorial", "normalized"):
             raise ValueError("Unknown Laplacian type {}".format(lap_type))
         if lap_type != self.lap_type:
-            # caches invalidated when the Laplacian changes (graph.py:602-609)
-            self._lmax = None
-            self._lmax_method = None
-            self._U = None
-            self._e = None
+            self._forget_spectrum()
         self.lap_type = lap_type
         self._L = None
-        for g in self._dev.values():
-            g.destroy()
-        self._dev = {}
+        while self._dev:
+            self._dev.popitem()[1].destroy()
         self.device_graph()  # build now: errors surface here, like in the reference
 
     @property
     def L(self):
+        # the reference's L is float64 for normalized and for integer W, and follows W's dtype for
+        # combinatorial; the device copy is in the compute dtype
         if self._L is None:
-            # the reference's L is float64 for normalized and for integer W, and follows W's
-            # dtype for combinatorial; the device copy is in the compute dtype
             self._L = self.device_graph().download_l()
         return self._L
 
     @property
     def dw(self):
+        """Weighted degrees (graph.py:783-838), summed on the device while the Laplacian is built."""
         if self._dw is None:
             self._dw = self.device_graph().download_dw()
         return self._dw
 
     def _check_signal(self, s):
-        s = np.asanyarray(s)
-        if s.shape[0] != self.n_vertices:
+        """graph.py:632-640: anything array-like whose first axis runs over the vertices."""
+        arr = np.asanyarray(s)
+        if arr.ndim == 0 or arr.shape[0] != self.n_vertices:
             raise ValueError("First dimension must be the number of vertices "
-                             "G.N = {}, got {}.".format(self.N, s.shape))
-        return s
+                             "G.N = {}, got {}.".format(self.N, arr.shape))
+        return arr
 
     # ---- operators on the device CSR (SURVEY 8(f) row 3) ----------------------------------------
     def dirichlet_energy(self, x):
         """x^T L x (graph.py:642-702), computed on the device: one sparse product and one reduction."""
-        x = self._check_signal(x)
-        return self.device_graph().dirichlet_energy(x)
+        return self.device_graph().dirichlet_energy(self._check_signal(x))
 
     def get_edge_list(self):
         """(sources, targets, weights), graph.py:934-1029: all stored entries of a directed graph,
         the upper triangle (row-major) of an undirected one."""
-        if self.is_directed():
-            C = self.W.tocoo()
-        else:
-            C = sparse.triu(self.W, format="coo")
+        C = self.W.tocoo() if self.is_directed() else sparse.triu(self.W, format="coo")
         assert self.n_edges == C.row.size
         return C.row, C.col, C.data
 
@@ -201,14 +201,14 @@ class Graph:
     def compute_differential_operator(self):
         """difference.py:26-166.  D is assembled on the device (edge enumeration, sqrt of the
         weights) and cached there; ``G.D`` is the scipy csc copy."""
-        dev = self._device_differential()
-        self._D = dev.differential_operator()
+        self._D = self._device_differential().differential_operator()
         self._D_lap_type = self.lap_type
 
     @property
     def D(self):
         """Differential operator (difference.py:15-24), N x n_edges, L = D D^T."""
-        if getattr(self, "_D", None) is None or getattr(self, "_D_lap_type", None) != self.lap_type:
+        stale = getattr(self, "_D", None) is None or getattr(self, "_D_lap_type", None) != self.lap_type
+        if stale:
             self.logger.warning("The differential operator G.D is not available, we need to compute "
                                 "it. Explicitly call G.compute_differential_operator() once "
                                 "beforehand to suppress the warning.")
@@ -217,18 +217,17 @@ class Graph:
 
     def grad(self, x):
         """Gradient D^T x of a vertex signal (difference.py:168-244), on the device."""
-        x = self._check_signal(x)
-        return self._device_differential().grad(x)
+        return self._device_differential().grad(self._check_signal(x))
 
     def div(self, y):
         """Divergence D y of an edge signal (difference.py:246-331), on the device."""
-        y = np.asanyarray(y)
-        if y.shape[0] != self.Ne:
+        edge_signal = np.asanyarray(y)
+        if edge_signal.shape[0] != self.Ne:
             raise ValueError("First dimension must be the number of edges "
-                             "G.Ne = {}, got {}.".format(self.Ne, y.shape))
-        return self._device_differential().div(y)
+                             "G.Ne = {}, got {}.".format(self.Ne, edge_signal.shape))
+        return self._device_differential().div(edge_signal)
 
-    # ---- spectrum bounds (host; read-only input of the hot path) -------------------------------
+    # ---- spectrum bounds (read-only input of the hot path) ----------------------------------------
     @property
     def lmax(self):
         if self._lmax is None:
@@ -238,89 +237,106 @@ class Graph:
             self.estimate_lmax()
         return self._lmax
 
+    def _lmax_lanczos_device(self):
+        # Lanczos on the device (the reference calls ARPACK eigsh(tol=5e-3) on the host, graph.py:911-917,
+        # with a random start vector: 3.3 s at N = 1M and not reproducible).  Same contract: an estimate
+        # from below, increased by 1 % (graph.py:920); non-convergence is a ValueError (engine).
+        ritz, _ = self.device_graph().lanczos_lmax(max_iter=80, tol=5e-4)
+        assert ritz <= self._get_upper_bound() * (1 + 1e-6) + 1e-12
+        return ritz * 1.01
+
+    def _lmax_lanczos_host(self):
+        try:
+            ritz = splinalg.eigsh(self.L.astype(np.float64), k=1, tol=5e-3, ncv=min(self.N, 10),
+                                  return_eigenvectors=False)[0]
+        except splinalg.ArpackNoConvergence:
+            raise ValueError("The Lanczos method did not converge. Try to use bounds.")
+        assert ritz <= self._get_upper_bound() + 1e-12
+        return ritz * 1.01  # 1 % safety margin, as the reference
+
     def estimate_lmax(self, method="lanczos"):
+        """graph.py:858-931: 'lanczos' (device), 'lanczos-host' (ARPACK, the reference's own call) or
+        'bounds'; a repeated call with the method already used is a no-op."""
         if method == self._lmax_method:
             return
-        self._lmax_method = method
-        if method == "lanczos":
-            # Lanczos on the device (the reference calls ARPACK eigsh(tol=5e-3) on the host,
-            # graph.py:911-917, with a random start vector: 3.3 s at N = 1M and not reproducible).
-            # Same contract: an estimate from below, increased by 1 % (graph.py:920).
-            lmax, _ = self.device_graph().lanczos_lmax(max_iter=80, tol=5e-4)
-            assert lmax <= self._get_upper_bound() * (1 + 1e-6) + 1e-12
-            self._lmax = lmax * 1.01
-        elif method == "lanczos-host":
-            try:
-                lmax = splinalg.eigsh(self.L.astype(np.float64), k=1, tol=5e-3,
-                                      ncv=min(self.N, 10), return_eigenvectors=False)[0]
-            except splinalg.ArpackNoConvergence:
-                raise ValueError("The Lanczos method did not converge. Try to use bounds.")
-            assert lmax <= self._get_upper_bound() + 1e-12
-            self._lmax = lmax * 1.01  # 1 % safety margin, as the reference
-        elif method == "bounds":
-            self._lmax = self._get_upper_bound()
-        else:
+        estimators = {"lanczos": self._lmax_lanczos_device, "lanczos-host": self._lmax_lanczos_host,
+                      "bounds": self._get_upper_bound}
+        if method not in estimators:
             raise ValueError("Unknown method {}".format(method))
+        self._lmax_method = method
+        self._lmax = estimators[method]()
 
     def _get_upper_bound(self):
-        if self.lap_type == "normalized":
-            return 2
-        W = self._symmetric_w()
-        dw = np.asarray(self.dw, dtype=np.float64)
-        bounds = [self.n_vertices * W.max(), 2 * dw.max()]
-        if self.n_edges > 0:
-            coo = self.W.tocoo()  # max over edges: both triangles give the same maximum
-            bounds.append(np.max(dw[coo.row] + dw[coo.col]))
+        """The smallest of four classical upper bounds of lambda_max (graph.py:933-960)."""
+        if self.lap_type != "combinatorial":
+            return 2  # normalized Laplacian
+        W, deg = self._symmetric_w(), np.asarray(self.dw, dtype=np.float64)
+        candidates = [self.n_vertices * W.max(), 2 * deg.max()]
+        if self.n_edges:
+            ends = self.W.tocoo()  # max over edges: both triangles give the same maximum
+            candidates.append((deg[ends.row] + deg[ends.col]).max())
         with np.errstate(divide="ignore", invalid="ignore"):
-            m = W.dot(dw) / dw
-        bounds.append(np.max(dw + m))
-        return min(bounds)
+            candidates.append(np.max(deg + W.dot(deg) / deg))
+        return min(candidates)
 
     def compute_fourier_basis(self):
         """Dense eigendecomposition (fourier.py:97-195) - host LAPACK, for small graphs / tests."""
-        if self._U is not None:
-            return
-        e, U = np.linalg.eigh(self.L.toarray().astype(np.float64))
-        e[0] = 0 if abs(e[0]) < 1e-9 else e[0]
-        self._e, self._U = e, U
-        self._lmax = e[-1]
-        self._lmax_method = "fourier"
+        if self._U is None:
+            lam, vec = np.linalg.eigh(self.L.toarray().astype(np.float64))
+            if abs(lam[0]) < 1e-9:
+                lam[0] = 0
+            self._e, self._U = lam, vec
+            self._lmax, self._lmax_method = lam[-1], "fourier"
 
     @property
     def e(self):
-        if self._e is None:
-            self.compute_fourier_basis()
+        self.compute_fourier_basis()
         return self._e
 
     @property
     def U(self):
-        if self._U is None:
-            self.compute_fourier_basis()
+        self.compute_fourier_basis()
         return self._U
 
     def __repr__(self):
         return "{}(n_vertices={}, n_edges={}, lap_type={})".format(
-            self.__class__.__name__, self.n_vertices, self.n_edges, self.lap_type)
+            type(self).__name__, self.n_vertices, self.n_edges, self.lap_type)
 
 
 # ------------------------------------------------------------------------------------------------
 # synthetic graph generators (vectorised restatements of the reference's models)
 # ------------------------------------------------------------------------------------------------
+def _sensor_points(N, seed, distributed=False):
+    """Coordinates of ``graphs.Sensor`` (nngraphs/sensor.py:56-70), drawn from the same numpy stream as
+    the reference so that the same seed gives the same graph: uniform in the unit square, or one jittered
+    point per cell of a sqrt(N) x sqrt(N) grid."""
+    stream = np.random.default_rng(seed)
+    if not distributed:
+        return stream.uniform(0, 1, (N, 2))
+    side = np.sqrt(N)
+    if side != np.floor(side):
+        raise ValueError("The number of vertices must be a perfect square if they are to be "
+                         "distributed on a grid.")
+    cells = np.mgrid[0:1:1 / side, 0:1:1 / side].reshape(2, -1).T
+    return cells + stream.uniform(0, 1 / side, (N, 2))
+
+
 def sensor_weights(N, k=6, seed=None, return_coords=True):
-    """W of ``graphs.Sensor(N, k, seed=seed)`` (nngraphs/sensor.py:50-75, nngraph.py:213-297):
-    uniform coordinates in the unit square, k nearest neighbours, weights exp(-d^2/sigma) with
-    sigma = mean neighbour distance, symmetrised by averaging."""
-    rng = np.random.default_rng(seed)
-    coords = rng.uniform(0, 1, (N, 2))
-    tree = spatial.cKDTree(coords)
-    D, NN = tree.query(coords, k=k + 1, workers=-1)
-    sigma = np.mean(D[:, 1:])
-    rows = np.repeat(np.arange(N), k)
-    cols = NN[:, 1:].ravel()
-    vals = np.exp(-np.power(D[:, 1:].ravel(), 2) / float(sigma))
-    W = sparse.csc_matrix((vals, (rows, cols)), shape=(N, N))
-    W = sparse.csr_matrix((W + W.T) / 2)
+    """W of ``graphs.Sensor(N, k, seed=seed)`` built on the HOST with a KD-tree (nngraphs/sensor.py:50-75,
+    nngraph.py:213-297): k nearest neighbours of uniform points, weights exp(-d^2 / sigma) with sigma the
+    mean neighbour distance, symmetrised by averaging.  The reference construction the device k-NN path is
+    compared with."""
+    coords = _sensor_points(N, seed)
+    dist, nbr = spatial.cKDTree(coords).query(coords, k=k + 1, workers=-1)
+    dist, nbr = dist[:, 1:], nbr[:, 1:]  # column 0 is the point itself
+    sigma = float(dist.mean())
+    directed = sparse.csc_matrix((np.exp(-np.square(dist.ravel()) / sigma),
+                                  (np.repeat(np.arange(N), k), nbr.ravel())), shape=(N, N))
+    W = sparse.csr_matrix((directed + directed.T) / 2)
     return (W, coords) if return_coords else W
+
+
+_MINKOWSKI = {1: "manhattan", 2: "euclidean", np.inf: "max_dist"}
 
 
 class NNGraph(Graph):
@@ -336,36 +352,34 @@ class NNGraph(Graph):
         self.NNtype, self.use_flann, self.center, self.rescale = NNtype, use_flann, center, rescale
         self.k, self.sigma, self.epsilon = k, sigma, epsilon
         self.symmetrize_type, self.dist_type, self.order = symmetrize_type, dist_type, order
-        N, d = np.shape(self.Xin)
-        Xout = self.Xin
-        if k >= N:
+        n_points, dim = self.Xin.shape
+        if n_points <= k:
             raise ValueError("The number of neighbors (k={}) must be smaller "
-                             "than the number of nodes ({}).".format(k, N))
+                             "than the number of nodes ({}).".format(k, n_points))
         if NNtype not in ("knn", "radius"):
             raise ValueError("Unknown NNtype {}".format(NNtype))
         # nngraph.py:139-145: 'minkowski' is the p-norm of the given order
-        metric = {"euclidean": "euclidean", "manhattan": "manhattan", "max_dist": "max_dist"}.get(dist_type)
-        if dist_type == "minkowski":
-            metric = {1: "manhattan", 2: "euclidean", np.inf: "max_dist"}.get(order)
+        metric = _MINKOWSKI.get(order) if dist_type == "minkowski" else (
+            dist_type if dist_type in engine.METRICS else None)
         if metric is None:
             raise NotImplementedError("the device builder covers dist_type 'euclidean', 'manhattan', 'max_dist' "
                                       "(and 'minkowski' of order 1, 2, inf)")
         if symmetrize_type not in engine.SYMMETRIZE:
             raise ValueError("Unknown symmetrization method {}.".format(symmetrize_type))  # utils.py:277
-        if self.center:  # nngraph.py:129-130
-            Xout = self.Xin - np.kron(np.ones((N, 1)), np.mean(self.Xin, axis=0))
-        if self.rescale:  # nngraph.py:132-137
-            bounding_radius = 0.5 * np.linalg.norm(np.amax(Xout, axis=0) - np.amin(Xout, axis=0), 2)
-            scale = np.power(N, 1.0 / float(min(d, 3))) / 10.0
-            Xout = Xout * (scale / bounding_radius)
+        points = self.Xin
+        if center:  # nngraph.py:129-130: the cloud's centroid moves to the origin
+            points = points - points.mean(axis=0)[np.newaxis, :]
+        if rescale:  # nngraph.py:132-137: N^(1/min(d,3)) / 10 over half the bounding-box diagonal
+            half_diagonal = 0.5 * np.linalg.norm(points.max(axis=0) - points.min(axis=0), 2)
+            points = points * (np.power(n_points, 1.0 / float(min(dim, 3))) / 10.0 / half_diagonal)
         ctx = engine.default_context(int(kwargs.get("device", 0)))
         if NNtype == "knn":
-            W, self.sigma, info = engine.knn_graph(Xout, k, sigma, ctx=ctx, metric=metric,
+            W, self.sigma, info = engine.knn_graph(points, k, sigma, ctx=ctx, metric=metric,
                                                    symmetrize=symmetrize_type)
         else:  # nngraph.py:228-287; a symmetric relation: (W + W.T) / 2 = W
-            W, self.sigma, info = engine.radius_graph(Xout, epsilon, sigma, ctx=ctx, metric=metric)
+            W, self.sigma, info = engine.radius_graph(points, epsilon, sigma, ctx=ctx, metric=metric)
         self.knn_build_ms = info["build_ms"]
-        super().__init__(W, plotting=plotting, coords=Xout, **kwargs)
+        Graph.__init__(self, W, plotting=plotting, coords=points, **kwargs)
 
 
 class Sensor(NNGraph):
@@ -374,20 +388,9 @@ class Sensor(NNGraph):
     construction of the same matrix."""
 
     def __init__(self, N=64, k=6, distributed=False, seed=None, **kwargs):
-        self.distributed = distributed
-        self.seed = seed
-        rng = np.random.default_rng(self.seed)
-        if distributed:
-            m = np.sqrt(N)
-            if not m.is_integer():
-                raise ValueError("The number of vertices must be a perfect square if they are to be "
-                                 "distributed on a grid.")
-            coords = np.mgrid[0:1:1 / m, 0:1:1 / m].reshape(2, -1).T
-            coords += rng.uniform(0, 1 / m, (N, 2))
-        else:
-            coords = rng.uniform(0, 1, (N, 2))
-        plotting = {"limits": np.array([0, 1, 0, 1])}
-        super().__init__(Xin=coords, k=k, rescale=False, center=False, plotting=plotting, **kwargs)
+        self.distributed, self.seed = distributed, seed
+        NNGraph.__init__(self, Xin=_sensor_points(N, seed, distributed), k=k, rescale=False, center=False,
+                         plotting={"limits": np.array([0, 1, 0, 1])}, **kwargs)
 
 
 def _sample_pairs_within(rng, n, p):
@@ -422,34 +425,51 @@ def _sample_pairs_between(rng, na, nb, p):
     return got // nb, got % nb
 
 
+def _block_probabilities(k, p, q):
+    """The k x k matrix of edge probabilities from the within-block probabilities p (scalar or length-k
+    vector) and the between-block ones q (scalar or k x k matrix; default 0.3 / k), as
+    stochasticblockmodel.py:91-116 assembles it."""
+    within = np.asanyarray(p, dtype=np.float64)
+    if within.size == 1:
+        within = np.full(k, within.reshape(-1)[0])
+    if within.shape != (k,):
+        raise ValueError("Optional parameter p is neither a scalar nor a vector of length k.")
+    between = np.asanyarray(0.3 / k if q is None else q, dtype=np.float64)
+    if between.size == 1:
+        between = np.full((k, k), float(between.reshape(-1)[0]))
+    if between.shape != (k, k):
+        raise ValueError("Optional parameter q is neither a scalar nor a matrix of size k x k.")
+    M = np.array(between, dtype=np.float64)
+    np.fill_diagonal(M, within)
+    return M
+
+
 def sbm_weights(N, k=5, z=None, p=0.7, q=None, seed=None):
     """W with the distribution of ``graphs.StochasticBlockModel(N, k, z, p=p, q=q,
     directed=False, self_loops=False)`` (stochasticblockmodel.py:61-144): every unordered pair
     is an edge independently with probability p (same block) or q (different blocks); unit
-    weights (int64, as the reference).  O(nnz) instead of the reference's O(N^2) loop."""
-    rng = np.random.default_rng(seed)
-    if z is None:
-        z = np.sort(rng.integers(0, k, N))
-    z = np.asarray(z)
-    if q is None:
-        q = 0.3 / k
-    order = np.argsort(z, kind="stable")
-    bounds = np.searchsorted(z[order], np.arange(k + 1))
-    rows, cols = [], []
+    weights (int64, as the reference).  O(nnz) instead of the reference's O(N^2) loop.  Host / numpy
+    sampler; the product's generators use the device sampler (engine.sbm_graph)."""
+    stream = np.random.default_rng(seed)
+    labels = np.sort(stream.integers(0, k, N)) if z is None else np.asarray(z)
+    between = 0.3 / k if q is None else q
+    by_block = np.argsort(labels, kind="stable")
+    starts = np.searchsorted(labels[by_block], np.arange(k + 1))
+    members = [by_block[starts[b]:starts[b + 1]] for b in range(k)]
+    heads, tails = [], []
     for a in range(k):
-        ia = order[bounds[a]:bounds[a + 1]]
-        r, c = _sample_pairs_within(rng, ia.size, p)
-        rows.append(ia[r]); cols.append(ia[c])
+        r, c = _sample_pairs_within(stream, members[a].size, p)
+        heads.append(members[a][r])
+        tails.append(members[a][c])
         for b in range(a):
-            ib = order[bounds[b]:bounds[b + 1]]
-            r, c = _sample_pairs_between(rng, ia.size, ib.size, q)
-            rows.append(ia[r]); cols.append(ib[c])
-    rows = np.concatenate(rows) if rows else np.empty(0, np.int64)
-    cols = np.concatenate(cols) if cols else np.empty(0, np.int64)
-    data = np.ones(rows.size * 2, dtype=np.int64)
-    W = sparse.csr_matrix((data, (np.concatenate([rows, cols]), np.concatenate([cols, rows]))),
-                          shape=(N, N))
-    return W, z
+            r, c = _sample_pairs_between(stream, members[a].size, members[b].size, between)
+            heads.append(members[a][r])
+            tails.append(members[b][c])
+    heads = np.concatenate(heads) if heads else np.empty(0, np.int64)
+    tails = np.concatenate(tails) if tails else np.empty(0, np.int64)
+    W = sparse.csr_matrix((np.ones(2 * heads.size, dtype=np.int64),
+                           (np.concatenate([heads, tails]), np.concatenate([tails, heads]))), shape=(N, N))
+    return W, labels
 
 
 class StochasticBlockModel(Graph):
@@ -466,36 +486,23 @@ class StochasticBlockModel(Graph):
                                       "connected=False")
         self.k, self.directed, self.self_loops, self.connected = k, directed, self_loops, connected
         self.n_try, self.seed = n_try, seed
-        rng = np.random.default_rng(seed)
-        if z is None:
-            z = rng.integers(0, k, N)
-            z.sort()  # stochasticblockmodel.py:84-87
-        self.z = np.asarray(z)
+        stream = np.random.default_rng(seed)
+        # labels first, then the device sampler's seed: the reference draws z first too
+        # (stochasticblockmodel.py:84-87), so a given seed yields the reference's blocks
+        self.z = np.sort(stream.integers(0, k, N)) if z is None else np.asarray(z)
         if M is None:
-            self.p = p
-            p = np.asanyarray(p, dtype=np.float64)
-            if p.size == 1:
-                p = p * np.ones(k)
-            if p.shape != (k,):
-                raise ValueError("Optional parameter p is neither a scalar nor a vector of length k.")
-            if q is None:
-                q = 0.3 / k
-            self.q = q
-            q = np.asanyarray(q, dtype=np.float64)
-            if q.size == 1:
-                q = q * np.ones((k, k))
-            if q.shape != (k, k):
-                raise ValueError("Optional parameter q is neither a scalar nor a matrix of size k x k.")
-            M = np.array(q, dtype=np.float64)
-            M.flat[::k + 1] = p
+            self.p, self.q = p, (0.3 / k if q is None else q)
+            M = _block_probabilities(k, p, q)
         self.M = np.asarray(M, dtype=np.float64)
-        if (self.M < 0).any() or (self.M > 1).any():
+        if self.M.min() < 0 or self.M.max() > 1:
             raise ValueError("Probabilities should be in [0, 1].")
-        sub = int(rng.integers(0, 2 ** 63))  # the device stream's seed, drawn from the same generator
+        device_seed = int(stream.integers(0, 2 ** 63))
         ctx = engine.default_context(int(kwargs.get("device", 0)))
-        W, self.sampler_ms = engine.sbm_graph(self.z, self.M, seed=sub, ctx=ctx)
-        W = sparse.csr_matrix((np.ones(W.nnz, dtype=np.int64), W.indices, W.indptr), shape=W.shape)  # int64 unit
-        super().__init__(W, **kwargs)                                  # weights, as the reference's W
+        pattern, self.sampler_ms = engine.sbm_graph(self.z, self.M, seed=device_seed, ctx=ctx)
+        # unit int64 weights, like the reference's W
+        W = sparse.csr_matrix((np.ones(pattern.nnz, dtype=np.int64), pattern.indices, pattern.indptr),
+                              shape=pattern.shape)
+        Graph.__init__(self, W, **kwargs)
 
 
 class ErdosRenyi(StochasticBlockModel):
@@ -503,5 +510,5 @@ class ErdosRenyi(StochasticBlockModel):
 
     def __init__(self, N=100, p=0.1, directed=False, self_loops=False, connected=False, n_try=10,
                  seed=None, **kwargs):
-        super().__init__(N=N, k=1, p=p, directed=directed, self_loops=self_loops, connected=connected,
-                         n_try=n_try, seed=seed, **kwargs)
+        StochasticBlockModel.__init__(self, N=N, k=1, p=p, directed=directed, self_loops=self_loops,
+                                      connected=connected, n_try=n_try, seed=seed, **kwargs)

@@ -9,11 +9,18 @@ all columns advance together on the GPU with the same recurrence and stopping ru
 import numpy as np
 
 
-def _to_logits(x):
-    """learning.py:36-39."""
-    logits = np.zeros([len(x), np.max(x) + 1])
-    logits[range(len(x)), x] = 1
-    return logits
+def _one_hot(labels):
+    """Integer class labels -> (N, classes) indicator matrix (what learning.py:36-39 calls logits)."""
+    labels = np.asarray(labels, dtype=np.int64)
+    return (labels[:, np.newaxis] == np.arange(labels.max() + 1)[np.newaxis, :]).astype(np.float64)
+
+
+def _measured_only(y, mask):
+    """A float copy of y with every unmeasured vertex set to zero (learning.py:325-326)."""
+    keep = np.asarray(mask).reshape(-1).astype(bool)
+    out = np.array(y, copy=True)
+    out[~keep] = 0
+    return out, keep
 
 
 def regression_tikhonov(G, y, M, tau=0, rtol=1e-5, atol=0.0, maxiter=None):
@@ -22,22 +29,17 @@ def regression_tikhonov(G, y, M, tau=0, rtol=1e-5, atol=0.0, maxiter=None):
     y: (N,) or (N, Nsig) measurements, M: boolean mask of the measured vertices.  rtol / atol /
     maxiter are scipy.sparse.linalg.cg's (the reference uses its defaults).
     """
-    y = np.asarray(y)
-    M = np.asarray(M)
-    if np.prod(M.shape) != G.n_vertices:
+    if np.size(M) != G.n_vertices:
         raise ValueError("M should be of size [G.n_vertices,]")
     if not tau > 0:
         raise NotImplementedError("tau = 0 is a direct sparse solve in the reference "
                                   "(learning.py:342-367), not a device path; use tau > 0")
-    y = y.copy()
-    y[M == False] = 0  # noqa: E712  (learning.py:325-326)
-    x, _, _ = G.device_graph().tikhonov_cg(tau, M, y, rtol=rtol, atol=atol, maxiter=maxiter)
-    return x
+    rhs, keep = _measured_only(y, M)
+    solution, _, _ = G.device_graph().tikhonov_cg(tau, keep, rhs, rtol=rtol, atol=atol, maxiter=maxiter)
+    return solution
 
 
 def classification_tikhonov(G, y, M, tau=0, **kwargs):
     """Tikhonov regression of the one-hot encoded labels (learning.py:170-251)."""
-    y = np.asarray(y).copy()
-    y[np.asarray(M) == False] = 0  # noqa: E712
-    Y = _to_logits(y.astype(int))
-    return regression_tikhonov(G, Y, M, tau, **kwargs)
+    labels, _ = _measured_only(y, M)
+    return regression_tikhonov(G, _one_hot(labels), M, tau, **kwargs)

@@ -450,3 +450,21 @@ def test_fused_input_panel(ctx, dtype):
             for b in (bx, by0, by1):
                 b.free()
         dev.destroy()
+
+
+def test_compute_frame_in_device_panels():
+    """Filter.compute_frame (filter.py:506-600) for N > one panel: the identity is produced on the device
+    1024 columns at a time (gspx_identity_panel_dev), never as an N x N host array; equals the oracle's
+    filtering of np.identity(N), and p_f(L) is symmetric."""
+    G = graphs.Sensor(2500, seed=8)
+    G.estimate_lmax("bounds")
+    bank = filters.MexicanHat(G, Nf=3)
+    F = bank.compute_frame(order=20)
+    assert F.shape == (3 * G.N, G.N)
+    ref = orc.filter_chebyshev(orc.laplacian(G.W), G.lmax, orc.mexican_hat_kernels(G.lmax, 3), np.identity(G.N), 20)
+    assert rel_err(F, ref.T.reshape(-1, G.N)) < 1e-11
+    blocks = F.reshape(3, G.N, G.N)
+    assert np.max(np.abs(blocks - blocks.transpose(0, 2, 1))) < 1e-12
+    # localize(i) is sqrt(N) times column i of every block (filter.py:389-391)
+    loc = bank.localize(77, order=20)
+    assert rel_err(loc, np.sqrt(G.N) * blocks[:, :, 77].T) < 1e-11
