@@ -1,4 +1,4 @@
-"""ctypes binding of libgspx (C-ABI declared in include/gspx.h).
+"""ctypes binding of libgspx (C-ABI declared in include/gspx.h and include/gspx_ext.h).
 
 The library is built in-tree (pygsp_amd/_lib/libgspx.so) by ``pygsp_amd.build.build()`` /
 ``make -C pygsp_amd/csrc``.  There is NO CPU fallback: if the shared object is missing, or no
@@ -39,7 +39,7 @@ def np_dtype(code):
 
 
 # every exported symbol: name -> (restype, argtypes).  tests/test_capi.py checks this table
-# against include/gspx.h so the header, the library and the binding cannot drift apart.
+# against include/gspx.h + gspx_ext.h so the headers, the library and the binding cannot drift apart.
 _c = ctypes
 _P = _c.c_void_p
 SIGNATURES = {

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/gspx.h"
+#include "../../include/gspx_ext.h"
 
 using namespace gspx;
 

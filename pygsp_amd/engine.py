@@ -614,7 +614,7 @@ _newton_methods()
 
 
 def _ops_methods():
-    """Operators that reuse the device CSR next to the Chebyshev path (include/gspx.h, SURVEY 8(f)
+    """Operators that reuse the device CSR next to the Chebyshev path (include/gspx_ext.h, SURVEY 8(f)
     row 3).  Host arrays in / out; the *_dev variants take device pointers."""
 
     def _panel(self, x, rows, what):
