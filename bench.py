@@ -438,6 +438,14 @@ def main():
             out["tiles"] = r[2]
         return out
 
+    # the streaming-copy rate of THIS box and process, right after the timed region: the recurrence runs at
+    # a fixed fraction of it, and it moves by several percent between boxes
+    copy_now = None
+    try:
+        copy_now = ctx.bench_copy(1 << 30, 5)
+    except Exception:
+        pass
+
     # ---- roofline of the dominant kernel (the recurrence step) ---------------------------------
     nnz_l = dev.nnz_l
     U = N * nsig * elt
@@ -491,6 +499,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
+                "copy_GBps_this_run": copy_now,
+                "frac_of_copy_this_run": (achieved / copy_now) if copy_now else None,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": ("k_step_tile (one recurrence order per launch, gathered panel staged in LDS)"
                            if tiled else "k_step_panel / k_step_lds (one recurrence order per launch)"),
