@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libgspx.so")
+# (GSPX_LIB_PATH: load another build of the same library instead, e.g. the sanitizer build of `make asan`)
+LIB_PATH = os.environ.get("GSPX_LIB_PATH") or os.path.join(_HERE, "_lib", "libgspx.so")
 
 F32, F64 = 0, 1
 LAP_COMBINATORIAL, LAP_NORMALIZED = 0, 1
