@@ -1277,7 +1277,7 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
   }
   if (opt.kernel == 5 && ld > 4) kernel = 5;
   // auto: fp32 panels and fp64 panels of up to 32 signals -> LDS-staged kernel; wide fp64 panels ->
-  // scalar-metadata lane-group kernel.  Measured (tools/experiments/exp_mid_width.py, headline graph):
+  // scalar-metadata lane-group kernel.  Measured (round 1, headline graph):
   // fp32 the LDS kernel is 25 % faster; fp64 x 8 / 16 / 32 signals 0.18 / 0.21 / 0.26 ms per order
   // against 0.28 / 0.31 / 0.37 (many rows per row set make the scalar blends expensive); fp64 x 64
   // the scalar-metadata kernel wins by 4 %.

@@ -1,3 +1,5 @@
+"""Calibration: read-only GB/s by footprint (L2 / Infinity Cache / HBM) and streaming-copy GB/s of this
+box, with the engine's own kernels (gspx_bench_read / gspx_bench_copy).  GPU box only."""
 import sys; sys.path.insert(0,'.')
 from pygsp_amd import engine
 ctx = engine.default_context(0)

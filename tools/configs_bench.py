@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measure every BASELINE.json config that fits one GPU (configs[1..3] + one rank of configs[4]'s
-batch), device-resident.  Parity of the same configurations is asserted in tests/test_gpu_parity.py
+batch), device-resident.  Parity of the same configurations is asserted in tests/test_gpu_1_configs.py and in bench.py's `configs`
 (this tool never touches oracle/); here the result is only cross-checked through the
 constant-signal identity  p(L) 1 = (c0/2 + sum (-1)^k c_k) 1.  Writes gpurun_out/configs.json."""
 import json

@@ -1,4 +1,4 @@
-# end-of-iteration GPU job: tests, bench (both dtypes), rocprofv3 evidence
+# end-of-iteration GPU job: smoke, tests, rocprofv3 evidence (headline both dtypes, configs 2/3), bench
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $R/gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
@@ -7,6 +7,8 @@ bash tools/gpu_prof.sh f64 --dtype f64 > /dev/null 2>&1
 bash tools/gpu_prof.sh f32 --dtype f32 > /dev/null 2>&1
 cp $R/gpurun_out/prof_f64/traffic.json $R/profiles/traffic_f64.json 2>/dev/null
 cp $R/gpurun_out/prof_f32/traffic.json $R/profiles/traffic_f32.json 2>/dev/null
+bash tools/gpu_prof_configs.sh c2 > /dev/null 2>&1
+bash tools/gpu_prof_configs.sh c3 > /dev/null 2>&1
 cd $R
 timeout 600 python bench.py --steps 10 --warmup 3 --dtype f64 > gpurun_out/bench_f64.json 2> gpurun_out/bench_f64.err; echo "bench f64 rc=$?"
 timeout 600 python bench.py --steps 10 --warmup 3 --dtype f32 > gpurun_out/bench_f32.json 2> gpurun_out/bench_f32.err; echo "bench f32 rc=$?"
