@@ -78,6 +78,8 @@ def parse():
     p.add_argument("--config-oracle-cols", type=int, default=2, help="oracle columns per config (0: no parity leg)")
     p.add_argument("--calibrate-copy", action="store_true",
                    help="also run the engine's streaming copy kernel once (byte-counter calibration for rocprofv3)")
+    p.add_argument("--no-live-traffic", action="store_true",
+                   help="do not re-run one step under rocprofv3 --pmc to measure roofline.traffic in this run")
     p.add_argument("--cpu-all-cores", type=int, default=-1,
                    help="processes of the multi-core CPU baseline (-1: one per host core, at most 64; 0: skip)")
     p.add_argument("--tiles", choices=["auto", "off"], default="auto",
@@ -90,6 +92,53 @@ def parse():
                    help="recurrence = the reference's three-term Chebyshev recurrence (headline); "
                         "newton = same polynomial, Newton form (extra line 'newton_form')")
     return p.parse_args()
+
+
+# ---- HBM bytes per launch, measured in THIS run ---------------------------------------------------
+def live_traffic(dtype_flag, timeout_s=150):
+    """roofline.traffic measured now, on this box: one call of the headline workload re-run under
+    `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes, no trace domain - the
+    HBM section of MI355X_MICROARCH.md: FETCH_SIZE costs 3 of the 4 TCC slots and counts half the bytes of
+    wide reads on gfx950, hence 2 x), summed over the recurrence-step launches.  Returns
+    (bytes per launch, launches, calibration) or None when rocprofv3 is missing / fails / times out."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--dtype", dtype_flag,
+             "--no-cpu", "--no-newton", "--no-e2e", "--no-configs", "--no-live-traffic", "--calibrate-copy"]
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="gspx_pmc_", dir="/tmp")
+        try:
+            subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child,
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            step, copy = [], []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") != counter:
+                        continue
+                    (step if "k_step" in r["Kernel_Name"] else copy if "k_permute_in" in r["Kernel_Name"] else []
+                     ).append(float(r["Counter_Value"]))
+            got[counter] = (step, copy)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    fs, ws = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    n = min(len(fs), len(ws))
+    if n == 0:
+        return None
+    cal = None
+    if got["FETCH_SIZE"][1] and got["WRITE_SIZE"][1]:  # the copy kernel reads and writes 512 MiB = 524288 KiB
+        cal = {"copy_kernel_fetch_KiB": got["FETCH_SIZE"][1][-1], "copy_kernel_write_KiB": got["WRITE_SIZE"][1][-1],
+               "copy_kernel_bytes_each_way_KiB": 524288}
+    return (2.0 * sum(fs[:n]) + sum(ws[:n])) * 1024.0 / n, n, cal
 
 
 # ---- CPU baseline on all host cores ---------------------------------------------------------------
@@ -459,7 +508,16 @@ def main():
     # the committed PMC measurement is of the default workload only
     default_workload = (N, nsig, K, a.knn, a.evaluation, a.tiles) == (1000000, 64, 30, 8, "recurrence", "auto")
     traffic_source = None
-    if default_workload and os.path.exists(tfile):
+    live = None
+    if default_workload and rank == 0 and world == 1 and not a.no_live_traffic:
+        ctx.sync()
+        live = live_traffic(a.dtype)
+    if live is not None:
+        traffic = live[0]
+        traffic_source = {"how": "measured in this run: the same call under rocprofv3 --pmc FETCH_SIZE and --pmc "
+                                 "WRITE_SIZE (two separate child runs), (2*FETCH_SIZE + WRITE_SIZE) per k_step_tile launch",
+                          "launches": live[1], "calibration": live[2]}
+    elif default_workload and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             traffic_source = ("profiles/traffic_{}.json: (2*FETCH_SIZE + WRITE_SIZE) per k_step_tile launch from "
