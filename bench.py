@@ -135,9 +135,11 @@ def live_traffic(dtype_flag, timeout_s=150):
     if n == 0:
         return None
     cal = None
-    if got["FETCH_SIZE"][1] and got["WRITE_SIZE"][1]:  # the copy kernel reads and writes 512 MiB = 524288 KiB
+    if got["FETCH_SIZE"][1] and got["WRITE_SIZE"][1]:
+        # the child's last launch of the engine's copy kernel (k_permute_in) reads and writes 1 GiB: WRITE_SIZE
+        # counts it in full, FETCH_SIZE counts half - the factor 2 above, re-checked in the same passes
         cal = {"copy_kernel_fetch_KiB": got["FETCH_SIZE"][1][-1], "copy_kernel_write_KiB": got["WRITE_SIZE"][1][-1],
-               "copy_kernel_bytes_each_way_KiB": 524288}
+               "copy_kernel_bytes_each_way_KiB": 1 << 20}
     return (2.0 * sum(fs[:n]) + sum(ws[:n])) * 1024.0 / n, n, cal
 
 
