@@ -275,6 +275,71 @@ def run_configs(ctx, only=None, reps=3, oracle_cols=2):
     return res
 
 
+def run_batch_config(local, rank, world, ctx, gdist, rdev, fence, comm):
+    """BASELINE.json configs[4]: a batch of 8 independent Sensor(N=500000) graphs x 32 signals, Heat order
+    30, sharded over the ranks (8 / world graphs each, no data-path collective); one gather of the 8 output
+    blocks to rank 0 at the end (in-library RCCL when the run has a communicator).  Strong scaling of a
+    fixed batch: `bench.py --gpus N` for N = 1, 2, 4, 8 gives its curve.  Timed like the headline: barrier +
+    device sync on both sides, MAX over ranks; one column of every rank's first graph is checked against
+    the oracle."""
+    from oracle import cheby_oracle as orc
+    from pygsp_amd import filters, graphs
+    n_graphs, N5, nsig, K = 8, 500000, 32, 30
+    mine = list(gdist.shard_units(n_graphs, rank, world))
+    block = N5 * nsig * 8
+    by_all = ctx.alloc(max(len(mine), 1) * block)
+    jobs = []
+    for slot, g in enumerate(mine):
+        G = graphs.Sensor(N5, seed=g, compute_dtype=np.float64, device=local)
+        G.estimate_lmax("bounds")
+        c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, 50), m=K))
+        x = np.random.default_rng(100 + g).standard_normal((N5, nsig))
+        jobs.append((G, c, x, ctx.upload(x), by_all.ptr + slot * block))
+
+    def run_all():
+        for G, c, _, bx, y_ptr in jobs:
+            G.device_graph().cheby_filter_dev(c, bx.ptr, y_ptr, nsig, float(G.lmax))
+
+    run_all()  # warm-up: workspaces, tiles
+    fence()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run_all()
+    fence()
+    wall = gdist.max_over_ranks((time.perf_counter() - t0) / reps, rdev)
+    gather_ms = None
+    if comm is not None:
+        table = [len(list(gdist.shard_units(n_graphs, r, world))) * block for r in range(world)]
+        root = ctx.alloc(sum(table)) if rank == 0 else None
+        fence()
+        tg = time.perf_counter()
+        comm.gather(by_all.ptr, table, 0, root.ptr if rank == 0 else None)
+        fence()
+        gather_ms = gdist.max_over_ranks((time.perf_counter() - tg) * 1e3, rdev)
+        if rank == 0:
+            root.free()
+    err = 0.0
+    if jobs:
+        G, c, x, _, _ = jobs[0]
+        y = by_all.download((len(mine), N5, nsig), np.float64)[0]
+        ref = orc.cheby_op(orc.laplacian(G.W), float(G.lmax), c[0], x[:, :1])
+        err = float(np.max(np.abs(y[:, :1] - ref.reshape(N5, 1))) / np.max(np.abs(ref)))
+    err = gdist.max_over_ranks(err, rdev)
+    for G, _, _, bx, _ in jobs:
+        bx.free()
+        for g_ in list(G._dev.values()):
+            g_.destroy()
+        G._dev = {}
+    by_all.free()
+    return {"workload": "configs[4]: 8 x Sensor(N=500000), Heat(50) order 30, 32 signals each, f64, sharded {} per rank "
+                        "(strong scaling of a fixed batch)".format("/".join(str(len(list(gdist.shard_units(n_graphs, r, world))))
+                                                                             for r in range(world))),
+            "n_graphs": n_graphs, "n_gpus": world, "ms": wall * 1e3, "value": n_graphs * N5 * nsig * K / wall,
+            "unit": "vertex*signal*order/s", "gather_ms": gather_ms,
+            "parity_vs_oracle": {"max_rel_err": err, "columns": 1, "tolerance": 1e-5}}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -428,6 +493,7 @@ def main():
 
     # ---- the path's one collective, outside the timed region: outputs -> rank 0 ----------------
     gather_ms, gather_impl = None, None
+    comm = None
     if torch is not None and not a.no_gather:
         fence()
         # in the library: RCCL grouped send / recv (gspx_comm_gather); torch only carried the 128-byte id
@@ -445,11 +511,13 @@ def main():
                     got = root_buf.download((world, N, nsig), dtype)[0]
                     assert np.array_equal(got, ty.cpu().numpy()[0])
                     root_buf.free()
-                comm.close()
                 lib_ok = 1.0
             except Exception as e:  # agreed on below: every rank falls back together
                 sys.stderr.write("rank {}: in-library RCCL gather unavailable ({!r})\n".format(rank, e))
-        if gdist.sum_over_ranks(lib_ok, rdev) == float(world):
+        if gdist.sum_over_ranks(lib_ok, rdev) != float(world) and comm is not None:
+            comm.close()
+            comm = None
+        if comm is not None:
             gather_ms = gdist.max_over_ranks(t_lib, rdev)
             gather_impl = "libgspx gspx_comm_gather: RCCL grouped ncclSend/ncclRecv, one xGMI link per peer"
         else:
@@ -462,6 +530,13 @@ def main():
                 assert len(blocks) == world
             del blocks
             gather_impl = "torch.distributed ({}) send/recv".format("RCCL" if a.backend == "nccl" else a.backend)
+
+    # ---- BASELINE configs[4]: a batch of 8 independent graphs sharded over the ranks ------------------
+    batch5 = None
+    if not a.no_configs and not a.no_cpu:
+        batch5 = run_batch_config(local, rank, world, ctx, gdist, rdev, fence, comm)
+    if comm is not None:
+        comm.close()
 
     # N > 1: every rank checks two columns of its own output against the oracle (outside the timed region)
     parity_multi = None
@@ -631,6 +706,8 @@ def main():
             out["configs"] = {"error": repr(e)}
     if rank == 0 and parity_multi is not None:
         out["parity_vs_oracle"] = parity_multi
+    if rank == 0 and batch5 is not None:
+        out["batch_config4"] = batch5
     if rank == 0:
         print(json.dumps(out))
     if torch is not None:

@@ -136,3 +136,6 @@ def test_two_ranks_on_this_gpu_through_bench():
     assert out["gather_ms"] is not None and out["gather_ms"] > 0 and out["gather_impl"]
     assert out["config"]["N"] == 100000 and out["roofline"]["frac"] > 0
     assert out["parity_vs_oracle"]["ranks"] == 2 and out["parity_vs_oracle"]["max_rel_err"] < 1e-11
+    b5 = out["batch_config4"]  # BASELINE configs[4]: 8 graphs sharded 4 + 4
+    assert b5["n_gpus"] == 2 and b5["n_graphs"] == 8 and b5["value"] > 0 and "4/4" in b5["workload"]
+    assert b5["parity_vs_oracle"]["max_rel_err"] < 1e-11
