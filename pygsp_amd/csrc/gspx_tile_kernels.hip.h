@@ -66,8 +66,35 @@ constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group
 // narrow panels; 64 groups x 1 row).  NCOL = 1, 2: that many column chunks per row; 0: a.ncol chunks
 // OLDNAT: T_{k-2} rows are read through a.old_rows (step 2 of a filter whose input panel was not
 // copied into the internal order first)
+// Software pipelining of a pass (round 2; measured per panel shape on one box against the previous build,
+// profiles/r02_tile_variants*.log - the kernel sits at the 128-VGPR budget of two workgroups per CU, so what
+// wins is also a question of which order does not spill):
+//   PF          the pass's T_{k-2} / accumulator rows and a new block's matrix entries are loaded one pass
+//               ahead, next to its tile; the previous pass's stores are issued before them and the tile's
+//               LDS-DMA loads LAST, so at the first barrier of a pass the youngest thing a wave can be waiting
+//               for is its own tile;
+//   META_AFTER  the next block's row lists and header are loaded after the first barrier instead of before
+//               it (the 4-chunk build only: before the barrier it spills);
+//   otherwise they are loaded before the barrier and the wait in front of it skips exactly them
+//               (s_waitcnt vmcnt(NMETA): VMEM retires in order, they are the NMETA youngest operations).
+// fp64 x 64 signals +1.6 ... +2.8 % against the previous build, fp64 x 128 +9 %, narrow / single-chunk panels
+// -0.8 ... -1.4 %: the previous build did not wait for a wave's own tile at all (see the first barrier below).
+// The OLDNAT builds (one launch per call) keep the plain order and a full wait.
+// Narrow panels (8-lane groups) issue the tile first and wait for everything: measured better there.
+template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
+  static constexpr bool PF = !OLDNAT;
+  static constexpr bool TILE_LAST = PF && LG == 16;
+  // one-chunk fp64 panels: the entries stay with their own pass (prefetched they push the build into scratch)
+  static constexpr bool PF_ENTRIES = PF && !(LG == 16 && NCOL == 1 && sizeof(T) == 8);
+  static constexpr bool META_AFTER = !OLDNAT && LG == 16 && NCOL == 0;
+};
+
 template <typename T, int NCOL, int LG = 16, bool OLDNAT = false>
 __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
+  constexpr bool PF = TileSchedule<T, NCOL, LG, OLDNAT>::PF;
+  constexpr bool META_AFTER = TileSchedule<T, NCOL, LG, OLDNAT>::META_AFTER;
+  constexpr bool TILE_LAST = TileSchedule<T, NCOL, LG, OLDNAT>::TILE_LAST;
+  constexpr bool PF_ENTRIES = TileSchedule<T, NCOL, LG, OLDNAT>::PF_ENTRIES;
   constexpr int VEC = 16 / (int)sizeof(T);
   typedef typename VT<T, VEC>::t V;
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -139,13 +166,58 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
   };
 
+  // Loads that a pass consumes are issued one pass ahead, together with its tile: T_{k-2} (and the
+  // accumulator) of the group's rows, and - for the first pass of a block - the block's slice of matrix
+  // entries.  By the time the pass reaches its first barrier they are as old as the tile loads, so the
+  // barrier does not expose a fresh memory round trip every pass.
+  V ov[RPG], ra[RPG];
+  u32x4 ev = 0, ei = 0;
+  auto prefetch_rows = [&](const Meta& m, int blk, int c) {
+    const int r0 = phys(blk) * GSPX_TILE_BR + grp * RPG;
+    const u32 cb = chunk_off(c);
+#pragma unroll
+    for (int t = 0; t < RPG; ++t) {
+      const u32 off = (r0 + t < a.N && cb != POISON) ? (u32)(r0 + t) * ldb + cb : POISON;
+      u32 oo = a.gamma != T(0) ? off : POISON;
+      if constexpr (OLDNAT) oo = (off != POISON && a.gamma != T(0)) ? (u32)m.orow[t] * ldb + cb : POISON;
+      if (a.nt & 4) ov[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rold, oo, 0, 2));
+      else ov[t] = VT<T, VEC>::bload(rold, oo);
+      const u32 ro = a.flush == 2 ? off : POISON;
+      if (a.nt & 2) ra[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rra, ro, 0, 2));
+      else ra[t] = VT<T, VEC>::bload(rra, ro);
+    }
+  };
+  auto prefetch_entries = [&](const int4& h) {  // the block's slice of matrix entries, coalesced 16-byte pieces
+    const int nv16 = (h.w * (int)sizeof(T) + 15) >> 4, ni16 = (h.w + 15) >> 4;
+    const u32 vo = tid < nv16 ? (u32)h.z * (u32)sizeof(T) + tid * 16u : POISON;
+    const u32 io = tid < ni16 ? (u32)h.z + tid * 16u : POISON;
+    if (a.nt & 1) {
+      ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 2);
+      ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 2);
+    } else {
+      ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0);
+      ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 0);
+    }
+  };
+
   int4 H = uniform(load_hdr(k0));
   Meta M = load_meta(k0, H);
   // the workgroup's blocks (a static, strided walk of its XCD's range): k now, kn next (row lists
   // prefetched), knn after that (header prefetched)
   int k = k0, kn = k0 + nwx, knn = k0 + 2 * nwx;
   int4 Hn = uniform(load_hdr(kn < k1 ? kn : k0));
-  if (H.y >= 0) stage(M, H.y, chunk_off(0));
+  if constexpr (!TILE_LAST) {
+    if (H.y >= 0) stage(M, H.y, chunk_off(0));
+  }
+  if constexpr (PF) prefetch_rows(M, k0, 0);
+  if constexpr (PF_ENTRIES) {
+    if (H.y >= 0) prefetch_entries(H);
+  }
+  if constexpr (TILE_LAST) {  // the tile last, as inside the loop
+    __builtin_amdgcn_sched_barrier(0);
+    if (H.y >= 0) stage(M, H.y, chunk_off(0));
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // one pass = column chunk c of block k; returns false after the workgroup's last pass
   auto pass = [&](const int c, const bool first, const bool last) __attribute__((always_inline)) {
@@ -160,19 +232,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     const u32 col0 = (c * LG + lane16) * VEC;
     const bool on = col0 < a.ld;
     const u32 cb = on ? col0 * (u32)sizeof(T) : POISON;
-    // T_{k-2} (and the accumulator) of the group's two rows
-    V ov[RPG], ra[RPG];
-#pragma unroll
-    for (int t = 0; t < RPG; ++t) {
-      const u32 off = (row0 + t < a.N) ? (u32)(row0 + t) * ldb + cb : POISON;
-      u32 oo = a.gamma != T(0) ? off : POISON;
-      if constexpr (OLDNAT) oo = (row0 + t < a.N && a.gamma != T(0)) ? (u32)M.orow[t] * ldb + cb : POISON;
-      if (a.nt & 4) ov[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rold, oo, 0, 2));
-      else ov[t] = VT<T, VEC>::bload(rold, oo);
-      const u32 ro = a.flush == 2 ? off : POISON;
-      if (a.nt & 2) ra[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rra, ro, 0, 2));
-      else ra[t] = VT<T, VEC>::bload(rra, ro);
-    }
+    if constexpr (!PF) prefetch_rows(M, k, c);
     V ins[RPG];
 #pragma unroll
     for (int t = 0; t < RPG; ++t) ins[t] = 0;
@@ -187,27 +247,19 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
         }
       }
     }
-    // the block's slice of matrix entries, coalesced (values: 16-byte pieces, positions likewise)
-    u32x4 ev = 0, ei = 0;
-    const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent + 15) >> 4;
-    if (first && fast) {
-      const u32 vo = tid < nv16 ? (u32)rp0 * (u32)sizeof(T) + tid * 16u : POISON;
-      const u32 io = tid < ni16 ? (u32)rp0 + tid * 16u : POISON;
-      if (a.nt & 1) {
-        ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 2);
-        ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 2);
-      } else {
-        ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0);
-        ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 0);
-      }
+    if constexpr (!PF_ENTRIES) {
+      if (first && fast) prefetch_entries(H);
     }
     int4 Hv = Hn;
-    if (last) {  // the next block's row lists, the header after that
-      M = load_meta(kn < k1 ? kn : k, Hn);
-      Hv = load_hdr(knn < k1 ? knn : k);
+    if constexpr (!META_AFTER) {
+      if (last) {  // the next block's row lists, the header after that
+        M = load_meta(kn < k1 ? kn : k, Hn);
+        Hv = load_hdr(knn < k1 ? knn : k);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (first && fast) {
+    if (first && fast) {  // the entries (fetched one pass ahead) go to LDS, once for all chunks of the block
+      const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent + 15) >> 4;
       if (tid < nv16) *(u32x4*)((unsigned char*)mval + tid * 16) = ev;
       if (tid < ni16) *(u32x4*)((unsigned char*)midx + tid * 16) = ei;
       for (int i = tid + 512; i < nv16; i += 512)  // slices longer than 8 KiB of values: rare
@@ -217,37 +269,52 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
         *(u32x4*)((unsigned char*)midx + i * 16) =
             __builtin_amdgcn_raw_buffer_load_b128(ri, (u32)rp0 + i * 16u, 0, 0);
     }
-    __syncthreads();  // tile and entries in place
-    int4 Hnn = Hn;
-    if (last) Hnn = uniform(Hv);  // youngest load of the pass: everything prefetched has landed
-    V nv[RPG], cv[RPG];
-    if (fast) {
-#pragma unroll
-      for (int t = 0; t < RPG; ++t) {
-        const int s = rs[t], e = rs[t + 1];
-        V self;
-        const V acc = lds_row_dot<T, V, LG, u8>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile,
-                                        lane16, self);
-        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
-        cv[t] = self;
-      }
+    // Every wave waits for ITS OWN tile loads before the barrier: `buffer_load ... lds` is tracked by vmcnt only,
+    // and __syncthreads() lowers to `s_waitcnt lgkmcnt(0); s_barrier` - it does not wait for them.  (Until
+    // round 2 the only vmcnt wait before this barrier came from the entry writes above, which waves without
+    // an entry to write skip: their tile rows could be read by the other waves while still in flight.)
+    // Everything outstanding here was issued one pass ago and is needed now, so vmcnt(0) costs no extra wait.
+    if constexpr (TILE_LAST && !META_AFTER) {
+      // the tile DMA was the last thing issued one pass ago; the only VMEM operations younger than it are the
+      // NMETA loads of the next block's row lists / header issued above in a block's last pass (and the extra
+      // input panels of a synthesis step, which make the count data dependent: full wait then)
+      constexpr int NMETA = ST + RPG + 1 + 1;
+      static_assert(NMETA < 16, "vmcnt immediate");
+      // (entries loaded in this pass were issued before the row lists: they are older, hence covered)
+      if (last && a.nin == 0) __builtin_amdgcn_s_waitcnt(0x0070 | NMETA);  // vmcnt(NMETA) lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(0x0070);
     } else {
-      // plain gathers from global memory (tile too large for LDS)
-#pragma unroll
-      for (int t = 0; t < RPG; ++t) {
-        const int s = rs[t], e = rs[t + 1];
-        V acc = 0, self = 0;
-        if (row0 + t < a.N) {
-          for (int j = s; j < e; ++j) {
-            const int cc = a.col[j];
-            const V xv = VT<T, VEC>::bload(rcur, cc < a.N ? (u32)cc * ldb + cb : POISON);
-            if (j == s) self = xv;  // entry 0 is the diagonal slot
-            acc += a.val[j] * xv;
-          }
-        }
-        nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
-        cv[t] = self;
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    }
+    __syncthreads();  // tile and entries in place, T_{k-2} / accumulator rows in registers
+    if constexpr (META_AFTER) {
+      if (last) {  // the next block's row lists and the header after that: in flight during the row products
+        M = load_meta(kn < k1 ? kn : k, Hn);
+        Hv = load_hdr(knn < k1 ? knn : k);
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    V nv[RPG], res[RPG];
+#pragma unroll
+    for (int t = 0; t < RPG; ++t) {
+      const int s = rs[t], e = rs[t + 1];
+      V acc = 0, self = 0;
+      if (fast) {
+        acc = lds_row_dot<T, V, LG, u8>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile, lane16,
+                                        self);
+      } else if (row0 + t < a.N) {  // plain gathers from global memory (tile too large for LDS)
+        for (int j = s; j < e; ++j) {
+          const int cc = a.col[j];
+          const V xv = VT<T, VEC>::bload(rcur, cc < a.N ? (u32)cc * ldb + cb : POISON);
+          if (j == s) self = xv;  // entry 0 is the diagonal slot
+          acc += a.val[j] * xv;
+        }
+      }
+      nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
+      // the flush is formed here, while T_{k-1} (self) and T_{k-2} (ov) are at hand: after the barrier
+      // their registers receive the next pass's rows
+      res[t] = a.wn * nv[t] + a.wc * self + a.wo * ov[t];
+      if (a.flush == 2) res[t] += ra[t];
     }
     // everybody is done with the tile (their LDS reads were consumed above).  A bare barrier: the
     // fence of __syncthreads() would also wait for the prefetches still in flight.
@@ -255,13 +322,17 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     __builtin_amdgcn_s_barrier();
     bool more = true;
     if (last) {
+      const int4 Hnn = uniform(Hv);  // youngest load so far: the row lists before it have landed too
       H = Hn;
       Hn = Hnn;
       more = kn < k1;
     }
     __builtin_amdgcn_sched_barrier(0);
-    // next pass's tile: the next chunk of this block, or chunk 0 of the next block
-    if (more && H.y >= 0) stage(M, H.y, chunk_off(last ? 0 : c + 1));
+    if constexpr (!PF) {  // next pass's tile: the next chunk of this block, or chunk 0 of the next block
+      if (more && H.y >= 0) stage(M, H.y, chunk_off(last ? 0 : c + 1));
+    }
+    // this pass's results (with PF: before the loads below, so that they are out of the way of the next
+    // barrier's wait), ...
 #pragma unroll
     for (int t = 0; t < RPG; ++t) {
       const int row = row0 + t;
@@ -274,15 +345,33 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
         if (a.nt & 8) __builtin_nontemporal_store(nv[t], (V*)(a.out + (size_t)row * a.ld + col0));
         else *(V*)(a.out + (size_t)row * a.ld + col0) = nv[t];
         if (a.flush) {
-          V res = a.wn * nv[t] + a.wc * cv[t] + a.wo * ov[t];
-          if (a.flush == 2) res += ra[t];
           if (a.final) {
             const size_t orow = a.perm ? (size_t)a.perm[row] : (size_t)row;
-            *(V*)(a.y + orow * a.ldy + col0) = res;
+            *(V*)(a.y + orow * a.ldy + col0) = res[t];
           } else {
-            if (a.nt & 2) __builtin_nontemporal_store(res, (V*)(a.racc + (size_t)row * a.ld + col0));
-            else *(V*)(a.racc + (size_t)row * a.ld + col0) = res;
+            if (a.nt & 2) __builtin_nontemporal_store(res[t], (V*)(a.racc + (size_t)row * a.ld + col0));
+            else *(V*)(a.racc + (size_t)row * a.ld + col0) = res[t];
           }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ... then everything the next pass consumes: its tile (the next chunk of this block, or chunk 0 of the
+    // next block), its T_{k-2} / accumulator rows, and a new block's matrix entries
+    if constexpr (PF) {
+      if (more) {
+        const int nc = last ? 0 : c + 1;
+        if constexpr (!TILE_LAST) {
+          if (H.y >= 0) stage(M, H.y, chunk_off(nc));
+        }
+        prefetch_rows(M, last ? kn : k, nc);
+        if constexpr (PF_ENTRIES) {
+          if (last && H.y >= 0) prefetch_entries(H);
+        }
+        if constexpr (TILE_LAST) {  // the tile last: see the first barrier
+          __builtin_amdgcn_sched_barrier(0);
+          if (H.y >= 0) stage(M, H.y, chunk_off(nc));
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
