@@ -1324,6 +1324,9 @@ __global__ __launch_bounds__(512, 4) void k_newton_pair(const PairArgs<T> a) {
           *(u16*)(gspx_smem + ai) = ei[t][q] == GSPX_PAD16 ? (u16)0 : ei[t][q];
         }
     }
+    // every wave waits for its own tile loads: __syncthreads() lowers to `s_waitcnt lgkmcnt(0); s_barrier`
+    // and does not wait for `buffer_load ... lds` (vmcnt); see k_step_tile
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
     __syncthreads();  // h tile and S1 entries in place; everybody is done with the previous phase 2
     // the header is the youngest load issued above and the entries (older) have landed: this wait is
     // short, and no wait of the next pass will have to reach past the tile loads issued further down
