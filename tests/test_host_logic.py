@@ -192,3 +192,46 @@ def test_auto_order_keeps_already_local_graphs():
     Wm = W[perm][:, perm].tocsr()                            # already Morton-ordered graph
     assert engine.auto_order(Wm, None) is None               # RCM would not improve it
     assert engine.locality_score(Wm) > 0.95 > engine.locality_score(W) + 0.3
+
+
+def test_use_backend_patches_and_restores_both_lookup_sites(monkeypatch):
+    """plugin.use_backend / install / uninstall on a pygsp-shaped module: the function looked up at call time
+    (filter.py:309, 319 -> approximations.cheby_op) and the import-time alias (filters/__init__.py:115) are
+    both replaced and both restored; PYGSP_AMD_BACKEND is honoured at import.  No device is touched."""
+    import importlib
+    import sys
+    import types
+
+    from pygsp_amd import plugin
+
+    def make():
+        mod = types.ModuleType("pygsp")
+        mod.filters = types.ModuleType("pygsp.filters")
+        mod.filters.approximations = types.ModuleType("pygsp.filters.approximations")
+        orig = lambda G, c, s, **kw: "reference"  # noqa: E731
+        mod.filters.approximations.cheby_op = orig
+        mod.filters.cheby_op = orig
+        return mod, orig
+
+    mod, orig = make()
+    plugin.use_backend("gspx", mod)
+    assert mod.filters.approximations.cheby_op is filters.cheby_op and mod.filters.cheby_op is filters.cheby_op
+    plugin.use_backend("reference", mod)
+    assert mod.filters.approximations.cheby_op is orig and mod.filters.cheby_op is orig
+    plugin.use_backend("reference", mod)  # idempotent
+    with pytest.raises(ValueError):
+        plugin.use_backend("scipy", mod)
+    with pytest.raises(ValueError):
+        plugin.install(mod, laplacian="elsewhere")
+    # environment switch, read when the module is imported
+    mod2, orig2 = make()
+    monkeypatch.setitem(sys.modules, "pygsp", mod2)
+    monkeypatch.setenv("PYGSP_AMD_BACKEND", "gspx")
+    importlib.reload(plugin)
+    try:
+        assert mod2.filters.approximations.cheby_op is filters.cheby_op
+    finally:
+        plugin.uninstall(mod2)
+        monkeypatch.delenv("PYGSP_AMD_BACKEND")
+        importlib.reload(plugin)
+    assert mod2.filters.cheby_op is orig2
