@@ -1545,6 +1545,11 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
            : ncol == 1 ? k_step_tile<T, 1, 16, true>
            : ncol == 2 ? k_step_tile<T, 2, 16, true>
                        : k_step_tile<T, 0, 16, true>;
+  if (t.nin > 0)  // extra input panels (synthesis): never together with old_rows
+    kern = narrow      ? k_step_tile<T, 1, 8, false, true>
+           : ncol == 1 ? k_step_tile<T, 1, 16, false, true>
+           : ncol == 2 ? k_step_tile<T, 2, 16, false, true>
+                       : k_step_tile<T, 0, 16, false, true>;
   {  // once per kernel build and device (a driver call per launch would cost microseconds each)
     static std::map<std::pair<const void*, int>, size_t> lds_set;
     static std::mutex lds_mu;

@@ -88,7 +88,9 @@ template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
   static constexpr bool META_AFTER = !OLDNAT && LG == 16 && NCOL == 0;
 };
 
-template <typename T, int NCOL, int LG = 16, bool OLDNAT = false>
+// INS: the step adds extra input panels to the row (synthesis by Clenshaw, a.nin > 0) - its own build, so
+// that the analysis path does not carry their registers across the row products
+template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false>
 __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   constexpr bool PF = TileSchedule<T, NCOL, LG, OLDNAT>::PF;
   constexpr bool META_AFTER = TileSchedule<T, NCOL, LG, OLDNAT>::META_AFTER;
@@ -232,10 +234,10 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     const bool on = col0 < a.ld;
     const u32 cb = on ? col0 * (u32)sizeof(T) : POISON;
     if constexpr (!PF) prefetch_rows(M, k, c);
-    V ins[RPG];
+    V ins[INS ? RPG : 1];
 #pragma unroll
-    for (int t = 0; t < RPG; ++t) ins[t] = 0;
-    if (a.nin > 0) {
+    for (int t = 0; t < (INS ? RPG : 1); ++t) ins[t] = 0;
+    if constexpr (INS) {
       const rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.inp, 0, a.panel_bytes * (u32)a.nin, 0x00020000);
       for (int f = 0; f < a.nin; ++f) {
         const T w = a.wts[f];
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
       constexpr int NMETA = ST + RPG + 1 + 1;
       static_assert(NMETA < 16, "vmcnt immediate");
       // (entries loaded in this pass were issued before the row lists: they are older, hence covered)
-      if (last && a.nin == 0) __builtin_amdgcn_s_waitcnt(0x0070 | NMETA);  // vmcnt(NMETA) lgkmcnt(0)
+      if (last && !INS) __builtin_amdgcn_s_waitcnt(0x0070 | NMETA);  // vmcnt(NMETA) lgkmcnt(0)
       else __builtin_amdgcn_s_waitcnt(0x0070);
     } else {
       __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
           acc += a.val[j] * xv;
         }
       }
-      nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self + ins[t];
+      nv[t] = a.scale * acc + a.gamma * ov[t] + a.beta * self;
+      if constexpr (INS) nv[t] += ins[t];
       // the flush is formed here, while T_{k-1} (self) and T_{k-2} (ov) are at hand: after the barrier
       // their registers receive the next pass's rows
       res[t] = a.wn * nv[t] + a.wc * self + a.wo * ov[t];
