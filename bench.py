@@ -246,6 +246,7 @@ def run_configs(ctx, only=None, reps=3, oracle_cols=2):
 
     if want("c1"):
         G = graphs.Sensor(100000, seed=42, compute_dtype=np.float64)
+        G.estimate_lmax("bounds")  # before the bank is designed: the kernels read / capture G.lmax
         res.append(run_config("c1", "configs[1]: Sensor(N=100000) combinatorial, Heat(50) order 30, 1 signal, f64 "
                               "(cache-resident latency case; replayed as one hipGraph)", G, filters.Heat(G, 50), 1, 30,
                               np.float64, ctx, oracle_cols=min(oracle_cols, 1), reps=max(reps, 12)))
@@ -253,6 +254,7 @@ def run_configs(ctx, only=None, reps=3, oracle_cols=2):
     if want("c2"):
         N = 1000000
         G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=np.float32)
+        G.estimate_lmax("bounds")
         res.append(run_config("c2", "configs[2]: ErdosRenyi(N=1000000, p=1e-5), MexicanHat filterbank (6 filters) "
                               "order 50, 64 signals, f32", G, filters.MexicanHat(G, Nf=6), 64, 50, np.float32, ctx,
                               oracle_cols, reps))
@@ -261,6 +263,7 @@ def run_configs(ctx, only=None, reps=3, oracle_cols=2):
         for dt in (np.float64, np.float32):
             G = graphs.StochasticBlockModel(2000000, k=16, p=9.6e-5, q=2.13e-6, seed=0, lap_type="normalized",
                                             compute_dtype=dt)
+            G.estimate_lmax("bounds")
             res.append(run_config("c3", "configs[3]: StochasticBlockModel(N=2000000, k=16, p=9.6e-5, q=2.13e-6) "
                                   "normalized Laplacian, Heat(10) order 30, 16 signals", G, filters.Heat(G, 10), 16, 30,
                                   dt, ctx, oracle_cols, reps))
@@ -268,6 +271,7 @@ def run_configs(ctx, only=None, reps=3, oracle_cols=2):
     if want("c4"):
         for dt in (np.float64, np.float32):
             G = graphs.Sensor(500000, seed=0, compute_dtype=dt)
+            G.estimate_lmax("bounds")
             res.append(run_config("c4", "configs[4], one rank's share: Sensor(N=500000), Heat(50) order 30, 32 signals "
                                   "(the batch of 8 such graphs is one per GPU; bench.py --gpus N is its scaling run)",
                                   G, filters.Heat(G, 50), 32, 30, dt, ctx, oracle_cols, reps))

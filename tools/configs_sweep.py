@@ -48,11 +48,13 @@ def sweep(name, G, bank, nsig, K, dtype, batches, kernels):
 
 N = 1000000
 G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=np.float32)
+G.estimate_lmax("bounds")  # before the bank is designed
 sweep("c2 ER(1e6) MexicanHat x6 K=50 64 signals", G, filters.MexicanHat(G, Nf=6), 64, 50, np.float32,
       (0, 32, 16, 8), (0, 1, 5))
 del G
 for dt in (np.float64, np.float32):
     G = graphs.StochasticBlockModel(2000000, k=16, p=9.6e-5, q=2.13e-6, seed=0, lap_type="normalized", compute_dtype=dt)
+    G.estimate_lmax("bounds")
     sweep("c3 SBM(2e6, k=16) normalized Heat K=30 16 signals", G, filters.Heat(G, 10), 16, 30, dt, (0, 8, 4), (0, 1, 5))
     del G
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
