@@ -1,10 +1,15 @@
-"""Multi-GPU batch driver: one process per GPU, independent graphs / signal panels per rank.
+"""Multi-GPU batch driver for the one-process-per-GPU launch (`torch.distributed.run`): independent graphs /
+signal panels per rank.
 
-The Chebyshev recurrence needs no exchange between graphs (or between signal columns of one
-graph), so the units of a batch are sharded across ranks with NO data-path collective; the only
-collective is the final gather of the outputs to the root (RCCL over xGMI when the backend is
-"nccl", gloo on CPU for the tests).  torch.distributed is plumbing here (rendezvous, barrier,
-gather); all filtering goes through libgspx.
+The Chebyshev recurrence needs no exchange between graphs (or between signal columns of one graph), so the
+units of a batch are sharded across ranks with NO data-path collective (`shard_units`); the only collective
+is the final gather of the outputs to the root.  That gather is RCCL inside libgspx (`make_comm` ->
+engine.Comm -> gspx_comm_gather: grouped ncclSend / ncclRecv over xGMI).  torch.distributed is the launcher's
+plumbing here and nothing more: rendezvous, barrier, scalar reductions of the timings, and carrying the
+128-byte RCCL id from rank 0 to the other ranks.  `gather_to_root` is the same exchange through
+torch.distributed - the fallback of bench.py when the in-library communicator cannot be built (e.g. two
+ranks sharing one GPU in the tests, or gloo on CPU).  The single-process multi-GPU path (engine.gather,
+engine.filter_batch) does not import torch at all.
 """
 import os
 
