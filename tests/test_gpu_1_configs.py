@@ -100,3 +100,33 @@ def test_sbm_normalized_isolated_rule():
     y = filters.Heat(G, 10).filter(x, order=30)
     ref = orc.filter_chebyshev(L, 2.0, [orc.heat_kernel(10, 2.0)], x[:, :3], 30)
     assert rel_err(y[:, :3], ref) < 1e-11
+
+
+def test_panel_beyond_the_2gib_descriptor_window(ctx):
+    """A signal panel larger than the 2 GiB window of a buffer descriptor (600k vertices x 500 fp64 signals =
+    2.4 GB in, 2.4 GB out) is split into column batches inside the call; every batch must land in its own
+    columns of the caller's panels.  Oracle on columns of the first, a middle and the last batch, plus the
+    constant-signal identity on a column of every batch (p(L) 1 = p(0) 1 for the combinatorial Laplacian)."""
+    N, nsig, order = 600000, 500, 6
+    W, coords = graphs.sensor_weights(N, k=6, seed=21)
+    G = graphs.Graph(W, coords=coords, compute_dtype=np.float64)
+    G.estimate_lmax("bounds")
+    lmax = G.lmax
+    c = orc.compute_cheby_coeff(orc.heat_kernel(30, lmax), lmax, order)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, nsig))
+    const_cols = list(range(7, nsig, 50))
+    x[:, const_cols] = 2.0
+    assert x.nbytes > (1 << 31)
+    dev = G.device_graph()
+    y, _ = dev.cheby_filter(c, x, lmax)
+    assert ctx.last_timing()["step_launches"] >= 2 * order  # at least two column batches
+    y = y[0]
+    gain = _constant_signal_gain(c)
+    assert np.max(np.abs(y[:, const_cols] - 2.0 * gain)) < 1e-12 * abs(2.0 * gain) + 1e-13
+    cols = [0, 1, 249, 250, 498, 499]
+    ref = orc.cheby_op(orc.laplacian(W), lmax, c, x[:, cols])
+    assert rel_err(y[:, cols], ref) < 1e-12
+    # untouched by the batching: a column's result does not depend on which batch it travels in
+    y2, _ = dev.cheby_filter(c, np.ascontiguousarray(x[:, 240:260]), lmax)
+    assert rel_err(y2[0][:, [9, 10]], y[:, [249, 250]]) < 1e-14
