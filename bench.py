@@ -712,8 +712,15 @@ def main():
         out["parity_vs_oracle"] = parity_multi
     if rank == 0 and batch5 is not None:
         out["batch_config4"] = batch5
+    # C-level stdio first (RCCL prints a version banner through printf when a communicator is created; on a
+    # pipe it would otherwise come out at process exit, after the result): the JSON line is the last line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if torch is not None:
         torch.distributed.destroy_process_group()
 

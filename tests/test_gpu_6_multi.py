@@ -20,6 +20,15 @@ from pygsp_amd import _capi, engine, filters, graphs
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _flush_c_stdio():
+    """RCCL prints a version banner through printf when a communicator is created; flush it inside the test
+    that caused it (pytest captures it there) instead of at process exit, after pytest's summary line."""
+    yield
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+
+
 def test_gather_and_batch_across_contexts(ctx):
     """gspx_gather: buffers of several contexts concatenated on the root (single-process form of the
     final gather; two contexts on this box's one GPU), and engine.filter_batch on top of it."""
