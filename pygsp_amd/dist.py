@@ -98,16 +98,28 @@ def gather_to_root(tensor, dst=0):
     return out
 
 
-def make_comm(ctx):
-    """The in-library RCCL communicator of this rank (engine.Comm over gspx_comm_*): the 128-byte RCCL
-    id is made on rank 0 and handed to the other ranks through the launcher's process group - the only
-    thing torch.distributed carries here; the gather itself is RCCL inside libgspx.  Single process:
-    a one-rank communicator (its gather is a self send / recv)."""
+def exchange_comm_id():
+    """The 128-byte RCCL id of a new communicator: made on rank 0 (gspx_comm_unique_id) and handed to the other
+    ranks through the launcher's process group - the only thing torch.distributed carries for the gather.
+    None on every rank when rank 0 cannot make one (RCCL not loadable)."""
     from . import engine
     rank, world, _ = env_world()
     if world == 1:
-        return engine.Comm(ctx, 1, 0, engine.comm_unique_id())
+        return engine.comm_unique_id()
     import torch.distributed as dist
-    box = [engine.comm_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = engine.comm_unique_id()
+        except Exception:  # RCCL not loadable: every rank learns it (None) instead of waiting for rank 0
+            box[0] = None
     dist.broadcast_object_list(box, src=0)
-    return engine.Comm(ctx, world, rank, box[0])
+    return box[0]
+
+
+def make_comm(ctx, unique_id=None):
+    """The in-library RCCL communicator of this rank (engine.Comm over gspx_comm_*); the gather itself is RCCL
+    inside libgspx.  Single process: a one-rank communicator (its gather is a self send / recv)."""
+    from . import engine
+    rank, world, _ = env_world()
+    return engine.Comm(ctx, world, rank, unique_id if unique_id is not None else exchange_comm_id())
