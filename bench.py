@@ -502,7 +502,8 @@ def main():
         fence()
         # in the library: RCCL grouped send / recv (gspx_comm_gather); torch only carried the 128-byte id
         lib_ok = 0.0
-        if a.backend == "nccl" and os.environ.get("GSPX_BENCH_LIB_GATHER", "1") != "0":
+        lib_mode = os.environ.get("GSPX_BENCH_LIB_GATHER", "1")  # "0": never, "force": also under gloo (tests)
+        if (a.backend == "nccl" and lib_mode != "0") or lib_mode == "force":
             # run under a watchdog: a communicator that never forms (or a send that never completes) must not
             # cost the measurement that is already taken - after 240 s rank 0 prints what it has and every
             # rank leaves

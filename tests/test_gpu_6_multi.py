@@ -132,7 +132,10 @@ def test_two_ranks_on_this_gpu_through_bench():
     port = s.getsockname()[1]
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GSPX_ALL_RANKS_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # GSPX_BENCH_LIB_GATHER=force: the in-library RCCL gather is attempted although RCCL must refuse two ranks
+    # on one device - the attempt (id exchange, communicator creation under the watchdog), the agreement of the
+    # ranks on its failure and the fall-back to the launcher's gather all run
+    env = dict(os.environ, GSPX_ALL_RANKS_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GSPX_BENCH_LIB_GATHER="force")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--vertices", "100000", "--nsig", "16",
@@ -142,7 +145,7 @@ def test_two_ranks_on_this_gpu_through_bench():
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["gather_ms"] is not None and out["gather_ms"] > 0 and out["gather_impl"]
+    assert out["gather_ms"] is not None and out["gather_ms"] > 0 and "torch.distributed (gloo)" in out["gather_impl"]
     assert out["config"]["N"] == 100000 and out["roofline"]["frac"] > 0
     assert out["parity_vs_oracle"]["ranks"] == 2 and out["parity_vs_oracle"]["max_rel_err"] < 1e-11
     b5 = out["batch_config4"]  # BASELINE configs[4]: 8 graphs sharded 4 + 4
