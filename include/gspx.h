@@ -65,8 +65,8 @@ int gspx_ctx_destroy(gspx_ctx* ctx);
 int gspx_ctx_sync(gspx_ctx* ctx);
 /* Integer options of a context.  Unknown key -> GSPX_ERR_INVALID.  The defaults are what the engine
  * is measured with; the others exist so that every kernel variant stays testable against the oracle.
- *   "kernel"        0 auto; 1 lane-group panel kernel; 2 narrow (sub-wave rows, 1-4 signals);
- *                   3 / 4 wave-row kernels; 5 LDS-staged CSR slice.  Ignored when gather tiles apply
+ *   "kernel"        plain gather kernels (graphs without gather tiles): 0 auto; 1 lane-group panel kernel
+ *                   with scalar metadata; 2 narrow (sub-wave rows, 1-4 signals); 5 LDS-staged CSR slice
  *   "tile_gather"   1 (default): recurrence steps stage the gathered panel in LDS when the graph carries
  *                   gather tiles (k_step_tile); 0: plain gather kernels
  *   "fuse_input"    1 (default): with gather tiles, steps 1-2 of a single-filter call read the caller's

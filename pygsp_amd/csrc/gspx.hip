@@ -305,7 +305,6 @@ struct gspx_graph {
   int64_t nnz_int = 0;
   DevMem rptr, rcol, rval, fval, coff;
   unsigned coff_ldb = 0;  // panel row bytes the cached byte offsets were built for
-  int coff_pad_self = -1;
   DevMem perm, iperm;
   bool has_perm = false;
   // two-level row tiles of the fused Newton-pair kernel (optional; pygsp_amd/tiling.py)
@@ -447,6 +446,8 @@ extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value
     return set_err(GSPX_ERR_INVALID, "narrow_g_log2 must be in [-1, 6] (-1 = auto)");
   if (!strcmp(key, "waves_per_block") && !(value == 4 || value == 8 || value == 16))
     return set_err(GSPX_ERR_INVALID, "waves_per_block must be 4, 8 or 16");
+  if (!strcmp(key, "kernel") && !(value == 0 || value == 1 || value == 2 || value == 5))
+    return set_err(GSPX_ERR_INVALID, "kernel must be 0 (auto), 1 (panel), 2 (narrow) or 5 (LDS-staged)");
   if (!strcmp(key, "vec") && !(value == 0 || value == 1 || value == 2 || value == 4))
     return set_err(GSPX_ERR_INVALID, "vec must be 0, 1, 2 or 4");
   *s = value;
@@ -1262,19 +1263,6 @@ static Shape choose_shape(const Options& opt, size_t elt, int64_t ld, int veccap
   int kernel = (ld <= 4) ? 2 : 1;
   if (opt.kernel == 2 && ld <= 64) kernel = 2;
   if (opt.kernel == 1 && ld > 4) kernel = 1;
-  // wave-row kernels (one row per wave, all 64 lanes on its signals): explicit choice only.
-  // Measured on MI355X (profiles/): the lane-group kernels with 16-byte gathers win.
-  if (opt.kernel == 3 || opt.kernel == 4) {
-    int v = 1;
-    while (v < maxvec && ld % (2 * v) == 0 && ld / v > 64) v *= 2;
-    if (opt.vec != 0 && opt.vec <= maxvec && ld % opt.vec == 0) v = (int)opt.vec;
-    s.kernel = opt.kernel == 4 ? 4 : 3;
-    s.vec = v;
-    s.wlog2 = 6;
-    s.glog2 = 0;
-    s.gridy = (int)((ld / v + 63) / 64);
-    return s;
-  }
   if (opt.kernel == 5 && ld > 4) kernel = 5;
   // auto: fp32 panels and fp64 panels of up to 32 signals -> LDS-staged kernel; wide fp64 panels ->
   // scalar-metadata lane-group kernel.  Measured (round 1, headline graph):
@@ -1348,32 +1336,12 @@ static void launch_lds(const StepArgs<T>& a, const unsigned* coff, const Shape& 
   return launch_lds_w<T, 1, MODE>(a, coff, s.wlog2, grid, st);
 }
 
-template <typename T, bool FLUSH>
-static void launch_wrow(const StepArgs<T>& a, const unsigned* coff, const Shape& s, dim3 grid,
-                        hipStream_t st) {
-#define GSPX_LW(V)                                                                              \
-  do {                                                                                          \
-    if (s.kernel == 4)                                                                          \
-      hipLaunchKernelGGL((k_step_wrow2<T, V, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff,   \
-                         a.val, a.cur, a.wts, a.perm, a);                                       \
-    else                                                                                        \
-      hipLaunchKernelGGL((k_step_wrow<T, V, FLUSH>), grid, dim3(256), 0, st, a.rowptr, coff,    \
-                         a.val, a.cur, a.wts, a.perm, a);                                       \
-  } while (0)
-  if constexpr (sizeof(T) == 4) {
-    if (s.vec == 4) { GSPX_LW(4); return; }
-  }
-  if (s.vec == 2) { GSPX_LW(2); return; }
-  GSPX_LW(1);
-#undef GSPX_LW
-}
-
 template <typename T>
 static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipStream_t st,
                         const unsigned* coff) {
   int rpw = (int)opt.rows_per_wave;
   if (rpw <= 0)
-    rpw = (s.kernel == 5) ? (sizeof(T) == 4 ? 16 : 8) : (s.kernel == 4 ? 8 : (s.kernel == 2 ? 1 : 4));
+    rpw = (s.kernel == 5) ? (sizeof(T) == 4 ? 16 : 8) : (s.kernel == 2 ? 1 : 4);
   if (s.kernel == 1 || s.kernel == 5) {
     const int R = 64 >> s.wlog2;  // rows per row set
     rpw = ((rpw + R - 1) / R) * R;
@@ -1381,10 +1349,9 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
   }
   a.rows_per_wave = rpw;
   int rows_per_chunk;
-  if (s.kernel == 4 && rpw > 32) rpw = 32;
   a.rows_per_wave = rpw;
   a.wpb = (s.kernel == 1) ? (int)opt.waves_per_block : 4;
-  if (s.kernel == 1 || s.kernel >= 3)
+  if (s.kernel == 1 || s.kernel == 5)
     rows_per_chunk = a.wpb * rpw;
   else
     rows_per_chunk = rpw * (4 << (6 - s.wlog2 - s.glog2));
@@ -1401,9 +1368,6 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
     if (mode == 1) launch_lds<T, 1>(a, coff, s, grid, st);
     else if (mode == 2) launch_lds<T, 2>(a, coff, s, grid, st);
     else launch_lds<T, 0>(a, coff, s, grid, st);
-  } else if (s.kernel >= 3) {
-    if (a.flush) launch_wrow<T, true>(a, coff, s, grid, st);
-    else launch_wrow<T, false>(a, coff, s, grid, st);
   } else if (s.kernel == 1) {
     if (mode == 1) launch_panel<T, 1>(a, s, grid, st);
     else if (mode == 2) launch_panel<T, 2>(a, s, grid, st);
@@ -1584,6 +1548,20 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   return GSPX_OK;
 }
 
+// byte offsets col*ld*sizeof(T) of the stored entries for this panel width (cached on the graph; the
+// LDS-staged plain kernel reads them)
+template <typename T>
+static int prepare_coff(gspx_graph* g, const Shape& shape, unsigned ld, hipStream_t st) {
+  if (shape.kernel == 5 && g->coff_ldb != ld * (unsigned)sizeof(T)) {
+    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
+    const int nb = std::max(1, (int)((g->N + 255) / 256));
+    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), (int)g->N,
+                       ld * (unsigned)sizeof(T), g->coff.as<unsigned>());
+    g->coff_ldb = ld * (unsigned)sizeof(T);
+  }
+  return GSPX_OK;
+}
+
 template <typename T>
 static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp, const T* x,
                      unsigned ldx, T* y, unsigned ldy, unsigned ld, bool deferred,
@@ -1663,18 +1641,7 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   }
   if (!cap) HIPCHK(hipEventRecord(e1, st));
 
-  const int pad_self = (shape.kernel == 3 || shape.kernel == 4) ? 1 : 0;
-  if (shape.kernel >= 3 &&
-      (g->coff_ldb != ld * (unsigned)sizeof(T) || g->coff_pad_self != pad_self)) {
-    // byte offsets col*ld*sizeof(T) for this panel width (cached on the graph)
-    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
-    const int nb = std::max(1, (N + 255) / 256);
-    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
-                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), pad_self,
-                       g->coff.as<unsigned>());
-    g->coff_ldb = ld * (unsigned)sizeof(T);
-    g->coff_pad_self = pad_self;
-  }
+  CHK(prepare_coff<T>(g, shape, ld, st));
   StepArgs<T> a{};
   a.rowptr = g->rptr.as<int>();
   a.col = g->rcol.as<int>();
@@ -1930,7 +1897,6 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
                                unsigned ld, size_t& ev_idx) {
   gspx_ctx* ctx = g->ctx;
   Options opt = ctx->opt;
-  if (opt.kernel == 3 || opt.kernel == 4) opt.kernel = 0;  // wave-row kernels lack the input sum
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const int K = M - 1;
@@ -1965,17 +1931,7 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
   }
   HIPCHK(hipEventRecord(e1, st));
 
-  const int pad_self = 0;
-  if (shape.kernel == 5 &&
-      (g->coff_ldb != ld * (unsigned)sizeof(T) || g->coff_pad_self != pad_self)) {
-    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
-    const int nb = std::max(1, (N + 255) / 256);
-    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
-                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), pad_self,
-                       g->coff.as<unsigned>());
-    g->coff_ldb = ld * (unsigned)sizeof(T);
-    g->coff_pad_self = pad_self;
-  }
+  CHK(prepare_coff<T>(g, shape, ld, st));
   StepArgs<T> a{};
   a.rowptr = g->rptr.as<int>();
   a.col = g->rcol.as<int>();
@@ -2056,7 +2012,6 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
                             unsigned ldx, T* y, unsigned ldy, unsigned ld, size_t& ev_idx) {
   gspx_ctx* ctx = g->ctx;
   Options opt = ctx->opt;
-  if (opt.kernel == 3 || opt.kernel == 4) opt.kernel = 0;  // wave-row kernels have no beta term
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const size_t U = (size_t)N * ld;
@@ -2083,17 +2038,7 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   launch_permute_in<T>(x, ldx, X, ld, N, perm, pvec, st);
   HIPCHK(hipEventRecord(e1, st));
 
-  const int pad_self = 0;
-  if (shape.kernel == 5 &&
-      (g->coff_ldb != ld * (unsigned)sizeof(T) || g->coff_pad_self != pad_self)) {
-    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
-    const int nb = std::max(1, (N + 255) / 256);
-    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
-                       g->rcol.as<int>(), N, ld * (unsigned)sizeof(T), pad_self,
-                       g->coff.as<unsigned>());
-    g->coff_ldb = ld * (unsigned)sizeof(T);
-    g->coff_pad_self = pad_self;
-  }
+  CHK(prepare_coff<T>(g, shape, ld, st));
   StepArgs<T> a{};
   a.rowptr = g->rptr.as<int>();
   a.col = g->rcol.as<int>();

@@ -464,322 +464,18 @@ __global__ __launch_bounds__(1024) void k_step_panel(const int* __restrict__ row
 }
 
 // ---------------------------------------------------------------------------------------------
-// WAVE-ROW kernel: one wave works on ONE row at a time, its 64 lanes spanning the signals.
-// Everything about the row is wave-uniform and lives in SGPRs:
-//   * row start / chunk count / pad count from rowptr (s_load),
-//   * per entry a precomputed BYTE offset col*ld*sizeof(T) ("coff", cached per panel width) and
-//     the factor value: s_load_dwordx4 / x8 per 4-entry chunk,
-//   * the gather is  buffer_load v, v_lane, s[rsrc], s_coff offen : the scalar byte offset goes
-//     straight into the instruction's soffset field, and the FMA takes the value as an SGPR
-//     operand.  Per stored entry the wave issues exactly one VMEM and VEC VALU instructions and
-//     no scalar ALU work: the MI355X SIMD issues about one instruction per 4-5 cycles whatever
-//     its type (measured, profiles/), so instructions per row - not bytes - bound the previous
-//     lane-group design.
-// Pads never reach the memory pipeline: the last chunk issues only its real entries (pad count
-// in the low bits of rowptr).  Lanes past the panel width carry an out-of-range voffset.
+// byte offsets col*ldb of the stored entries for one panel width (cached on the graph; read by the
+// LDS-staged kernel below).  Pads get 0x80000000: the gather fails the descriptor's bounds check once the
+// lane offset is added - no traffic.
 // ---------------------------------------------------------------------------------------------
-// byte offsets col*ldb.  Pads: `pad_self` = offset of the row itself (a dummy, L1-resident gather
-// for kernels that pass the offset as the unchecked soffset), else 0x80000000 (fails the bounds
-// check once the lane offset is added: no traffic).
 template <typename T>
 __global__ void k_coff(const int* __restrict__ rptr, const int* __restrict__ rcol, int N, u32 ldb,
-                       int pad_self, u32* __restrict__ coff) {
+                       u32* __restrict__ coff) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   for (int j = rptr[i] & ~3; j < (rptr[i + 1] & ~3); ++j) {
     const int c = rcol[j];
-    coff[j] = (c == N) ? (pad_self ? (u32)i * ldb : GSPX_POISON) : (u32)c * ldb;
-  }
-}
-
-template <typename T, int VEC> struct VS {  // buffer load with a scalar byte offset
-  typedef VT<T, VEC> X;
-  typedef typename X::t V;
-  static __device__ __forceinline__ V ld(rsrc_t r, u32 voff, u32 soff) {
-    if constexpr (sizeof(V) == 4)
-      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-    else if constexpr (sizeof(V) == 8)
-      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-    else
-      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-  }
-};
-
-template <typename T, int VEC, bool FLUSH>
-__global__ __launch_bounds__(256) void k_step_wrow(const int* __restrict__ rowptr,
-                                                   const u32* __restrict__ coff,
-                                                   const T* __restrict__ val,
-                                                   const T* __restrict__ cur,
-                                                   const T* __restrict__ wts,
-                                                   const int* __restrict__ perm,
-                                                   const StepArgs<T> a) {
-  typedef VT<T, VEC> X;
-  typedef typename X::t V;
-  typedef VS<T, VEC> S;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-  int chunk = blockIdx.x;
-  if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);  // contiguous row range per XCD
-  if (chunk >= a.nchunks) return;
-
-  const u32 colel = (blockIdx.y * 64 + lane) * VEC;
-  const bool lane_on = colel < a.ld;
-  const u32 ldb = a.ld * (u32)sizeof(T);
-  const u32 voff = lane_on ? colel * (u32)sizeof(T) : GSPX_POISON;
-  const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cur, 0, a.curbytes, 0x00020000);
-  const rsrc_t rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
-  const rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
-  const rsrc_t rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
-
-  const int row0 = (chunk * 4 + wave) * a.rows_per_wave;
-#pragma unroll 1
-  for (int i = 0; i < a.rows_per_wave; ++i) {
-    const int row = __builtin_amdgcn_readfirstlane(row0 + i);
-    if (row >= a.N) break;
-    const int rp0 = rowptr[row], rp1 = rowptr[row + 1];
-    const int s = rp0 & ~3;
-    const int npad = rp0 & 3;
-    const int nfull = (((rp1 & ~3) - s) >> 2) - 1;  // chunks whose 4 entries are all real
-    const u32* cp = coff + s;
-    const T* vp = val + s;
-    const u32 rowoff = (u32)row * ldb;
-
-    V acc = 0;
-#pragma unroll 2
-    for (int k = 0; k < nfull; ++k) {
-      u32 co[4];
-      T vv[4];
-      V x[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        co[u] = cp[4 * k + u];
-        vv[u] = vp[4 * k + u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = S::ld(rc, voff, co[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc += vv[u] * x[u];
-    }
-    // closing chunk: 4 - npad real entries (at least one: every row owns a diagonal slot)
-    {
-      u32 co[4];
-      T vv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        co[u] = cp[4 * nfull + u];
-        vv[u] = vp[4 * nfull + u];
-      }
-      // pin the four offsets in SGPRs here: otherwise the loads are sunk into the conditionals
-      // below and issued one dword at a time, each behind its own wait
-      asm volatile("" : "+s"(co[0]), "+s"(co[1]), "+s"(co[2]), "+s"(co[3]));
-      V x0 = S::ld(rc, voff, co[0]);
-      V x1 = 0, x2 = 0, x3 = 0;
-      if (npad < 3) x1 = S::ld(rc, voff, co[1]);
-      if (npad < 2) x2 = S::ld(rc, voff, co[2]);
-      if (npad < 1) x3 = S::ld(rc, voff, co[3]);
-      // streaming reads of this row, issued after (= younger than) its gathers
-      const V ov = S::ld(rold, voff, rowoff);
-      V curv = 0, ra = 0;
-      if constexpr (FLUSH) {
-        curv = S::ld(rc, voff, rowoff);
-        ra = S::ld(rra, voff, rowoff);
-      }
-      acc += vv[0] * x0;
-      acc += vv[1] * x1;  // pad values are 0
-      acc += vv[2] * x2;
-      acc += vv[3] * x3;
-
-      V nv = a.scale * acc;
-      nv += a.gamma * ov;  // gamma == 0: the host points `old` at `cur`, the product vanishes
-      X::bstore(rout, voff + rowoff, nv);  // lanes past the panel: POISON + rowoff stays out of range
-      if constexpr (FLUSH) {
-        if (lane_on) {
-          const size_t o = (size_t)row * a.ld + colel;
-          size_t orow = (size_t)row;
-          if (a.final && perm) orow = (size_t)perm[row];
-          const size_t plane_r = (size_t)a.N * a.ld;
-          const size_t plane_y = (size_t)a.N * a.ldy;
-          for (int f = 0; f < a.nf; ++f) {
-            const T wn = wts[3 * f + 0], wc = wts[3 * f + 1], wo = wts[3 * f + 2];
-            V res = wn * nv + wc * curv + wo * ov;
-            if (a.flush == 2) res += (f == 0) ? ra : *(const V*)(a.racc + f * plane_r + o);
-            if (a.final)
-              *(V*)(a.y + f * plane_y + orow * a.ldy + colel) = res;
-            else
-              *(V*)(a.racc + f * plane_r + o) = res;
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// PIPELINED wave-row kernel.  Same data path as k_step_wrow, but the per-row chain of dependent
-// memory round trips (rowptr -> offsets -> gathers -> T_{k-2}), which bounds that kernel at
-// ~6 us per row per wave under load, is cut to ONE round trip:
-//   * the wave's rowptr block is fetched once into a VGPR (lane l = row l of the wave) and read
-//     with v_readlane - no per-row rowptr load;
-//   * the byte offsets of row i+1 (first 3 chunks) are fetched into a second SGPR set while row
-//     i's gathers are in flight; the two sets alternate (loop unrolled by two: no copies);
-//   * T_{k-2} (and the accumulator on flush steps) of row i+1 is requested right after row i's
-//     gathers, so it is younger than them in the in-order vmcnt queue and a full row old when
-//     row i+1's gathers are waited for.
-// Pads are dummy (offset of the row itself, value 0): all gathers of a chunk are unconditional.
-// ---------------------------------------------------------------------------------------------
-struct Coff12 {
-  u32 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11;
-};
-__device__ __forceinline__ void load_coff12(const u32* __restrict__ p, Coff12& o) {
-  o.c0 = p[0]; o.c1 = p[1]; o.c2 = p[2]; o.c3 = p[3];
-  o.c4 = p[4]; o.c5 = p[5]; o.c6 = p[6]; o.c7 = p[7];
-  o.c8 = p[8]; o.c9 = p[9]; o.c10 = p[10]; o.c11 = p[11];
-}
-
-template <typename T, int VEC> struct WrowCtx {
-  const u32* __restrict__ coff;
-  const T* __restrict__ val;
-  const T* __restrict__ wts;
-  const int* __restrict__ perm;
-  rsrc_t rc, rold, rout, rra;
-  u32 ldb, voff, colel;
-  int row0, nrows;  // rows of this wave
-  int v_rp;         // lane l: rowptr[row0 + l]
-  bool lane_on;
-};
-
-template <typename T, int VEC, bool FLUSH>
-__device__ __forceinline__ void wrow_body(const WrowCtx<T, VEC>& c, const StepArgs<T>& a, const int i,
-                                          const Coff12& use, Coff12& pf,
-                                          const typename VT<T, VEC>::t& ov_use,
-                                          const typename VT<T, VEC>::t& ra_use,
-                                          typename VT<T, VEC>::t& ov_pf,
-                                          typename VT<T, VEC>::t& ra_pf) {
-  typedef VT<T, VEC> X;
-  typedef typename X::t V;
-  typedef VS<T, VEC> S;
-  const int row = c.row0 + i;
-  const int rp0 = __builtin_amdgcn_readlane(c.v_rp, i);
-  const int rp1 = __builtin_amdgcn_readlane(c.v_rp, i + 1);
-  const int rp2 = __builtin_amdgcn_readlane(c.v_rp, i + 2 < 64 ? i + 2 : 63);
-  const int s = rp0 & ~3;
-  const int nch = ((rp1 & ~3) - s) >> 2;  // >= 1
-  const u32 rowoff = (u32)row * c.ldb;
-  // offsets of the next row while this row's gathers fly (reads stay inside the padded arrays)
-  load_coff12(c.coff + (rp1 & ~3), pf);
-  // factor values of this row (SGPRs), needed only after the gathers return
-  const T* vp = c.val + s;
-  T v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
-  T v4 = vp[4], v5 = vp[5], v6 = vp[6], v7 = vp[7];
-  T v8 = vp[8], v9 = vp[9], v10 = vp[10], v11 = vp[11];
-
-  V x0 = S::ld(c.rc, c.voff, use.c0), x1 = S::ld(c.rc, c.voff, use.c1);
-  V x2 = S::ld(c.rc, c.voff, use.c2), x3 = S::ld(c.rc, c.voff, use.c3);
-  V x4 = 0, x5 = 0, x6 = 0, x7 = 0, x8 = 0, x9 = 0, x10 = 0, x11 = 0;
-  if (nch > 1) {
-    x4 = S::ld(c.rc, c.voff, use.c4); x5 = S::ld(c.rc, c.voff, use.c5);
-    x6 = S::ld(c.rc, c.voff, use.c6); x7 = S::ld(c.rc, c.voff, use.c7);
-  }
-  if (nch > 2) {
-    x8 = S::ld(c.rc, c.voff, use.c8); x9 = S::ld(c.rc, c.voff, use.c9);
-    x10 = S::ld(c.rc, c.voff, use.c10); x11 = S::ld(c.rc, c.voff, use.c11);
-  }
-  V curv = 0;
-  if constexpr (FLUSH) curv = S::ld(c.rc, c.voff, rowoff);
-  // streaming reads of the NEXT row (row i+1 may be past the end: the load is then out of range)
-  {
-    const bool nx = (i + 1 < c.nrows);
-    const u32 vo = nx ? c.voff : GSPX_POISON;
-    ov_pf = S::ld(c.rold, vo, rowoff + c.ldb);
-    if constexpr (FLUSH) ra_pf = S::ld(c.rra, vo, rowoff + c.ldb);
-  }
-  (void)rp2;
-
-  V acc = v0 * x0;
-  acc += v1 * x1; acc += v2 * x2; acc += v3 * x3;
-  if (nch > 1) { acc += v4 * x4; acc += v5 * x5; acc += v6 * x6; acc += v7 * x7; }
-  if (nch > 2) { acc += v8 * x8; acc += v9 * x9; acc += v10 * x10; acc += v11 * x11; }
-  // rows longer than 12 stored entries: remaining chunks on demand
-  for (int k = 3; k < nch; ++k) {
-    const u32* cp = c.coff + s + 4 * k;
-    const T* wp = c.val + s + 4 * k;
-    const u32 o0 = cp[0], o1 = cp[1], o2 = cp[2], o3 = cp[3];
-    const T w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-    const V y0 = S::ld(c.rc, c.voff, o0), y1 = S::ld(c.rc, c.voff, o1);
-    const V y2 = S::ld(c.rc, c.voff, o2), y3 = S::ld(c.rc, c.voff, o3);
-    acc += w0 * y0; acc += w1 * y1; acc += w2 * y2; acc += w3 * y3;
-  }
-
-  V nv = a.scale * acc;
-  nv += a.gamma * ov_use;  // gamma == 0: the host points `old` at `cur`, the product vanishes
-  X::sstore(c.rout, c.voff + rowoff, nv);
-  if constexpr (FLUSH) {
-    if (c.lane_on) {
-      const size_t o = (size_t)row * a.ld + c.colel;
-      size_t orow = (size_t)row;
-      if (a.final && c.perm) orow = (size_t)c.perm[row];
-      const size_t plane_r = (size_t)a.N * a.ld;
-      const size_t plane_y = (size_t)a.N * a.ldy;
-      for (int f = 0; f < a.nf; ++f) {
-        const T wn = c.wts[3 * f + 0], wc = c.wts[3 * f + 1], wo = c.wts[3 * f + 2];
-        V res = wn * nv + wc * curv + wo * ov_use;
-        if (a.flush == 2) res += (f == 0) ? ra_use : *(const V*)(a.racc + f * plane_r + o);
-        if (a.final)
-          *(V*)(a.y + f * plane_y + orow * a.ldy + c.colel) = res;
-        else
-          *(V*)(a.racc + f * plane_r + o) = res;
-      }
-    }
-  }
-}
-
-template <typename T, int VEC, bool FLUSH>
-__global__ __launch_bounds__(256) void k_step_wrow2(const int* __restrict__ rowptr,
-                                                    const u32* __restrict__ coff,
-                                                    const T* __restrict__ val,
-                                                    const T* __restrict__ cur,
-                                                    const T* __restrict__ wts,
-                                                    const int* __restrict__ perm,
-                                                    const StepArgs<T> a) {
-  typedef VT<T, VEC> X;
-  typedef typename X::t V;
-  typedef VS<T, VEC> S;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int chunk = blockIdx.x;
-  if (a.cpx > 0) chunk = (chunk & 7) * a.cpx + (chunk >> 3);
-  if (chunk >= a.nchunks) return;
-
-  WrowCtx<T, VEC> c;
-  c.coff = coff;
-  c.val = val;
-  c.wts = wts;
-  c.perm = perm;
-  c.colel = (blockIdx.y * 64 + lane) * VEC;
-  c.lane_on = c.colel < a.ld;
-  c.ldb = a.ld * (u32)sizeof(T);
-  c.voff = c.lane_on ? c.colel * (u32)sizeof(T) : GSPX_POISON;
-  c.rc = __builtin_amdgcn_make_buffer_rsrc((void*)cur, 0, a.curbytes, 0x00020000);
-  c.rold = __builtin_amdgcn_make_buffer_rsrc((void*)a.old, 0, a.curbytes, 0x00020000);
-  c.rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.curbytes, 0x00020000);
-  c.rra = __builtin_amdgcn_make_buffer_rsrc((void*)a.racc, 0, a.curbytes, 0x00020000);
-  c.row0 = (chunk * 4 + wave) * a.rows_per_wave;
-  if (c.row0 >= a.N) return;
-  c.nrows = a.N - c.row0 < a.rows_per_wave ? a.N - c.row0 : a.rows_per_wave;
-  {
-    const int idx = c.row0 + lane;
-    c.v_rp = rowptr[idx < a.N ? idx : a.N];  // rows_per_wave <= 62: lanes 0..nrows+1 are what we read
-  }
-  Coff12 cA, cB;
-  load_coff12(coff + (__builtin_amdgcn_readlane(c.v_rp, 0) & ~3), cA);
-  V ovA = S::ld(c.rold, c.voff, (u32)c.row0 * c.ldb), raA = 0, ovB = 0, raB = 0;
-  if constexpr (FLUSH) raA = S::ld(c.rra, c.voff, (u32)c.row0 * c.ldb);
-#pragma unroll 1
-  for (int i = 0; i < c.nrows; i += 2) {
-    wrow_body<T, VEC, FLUSH>(c, a, i, cA, cB, ovA, raA, ovB, raB);
-    if (i + 1 >= c.nrows) break;
-    wrow_body<T, VEC, FLUSH>(c, a, i + 1, cB, cA, ovB, raB, ovA, raA);
+    coff[j] = (c == N) ? GSPX_POISON : (u32)c * ldb;
   }
 }
 

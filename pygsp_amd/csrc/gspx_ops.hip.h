@@ -6,21 +6,6 @@
 #include "gspx_ops_kernels.hip.h"
 
 // byte offsets col*ld*sizeof(T) for this panel width (LDS / wave-row kernels), cached on the graph
-template <typename T>
-static int prepare_coff(gspx_graph* g, const Shape& shape, unsigned ld, hipStream_t st) {
-  const int pad_self = (shape.kernel == 3 || shape.kernel == 4) ? 1 : 0;
-  if (shape.kernel >= 3 &&
-      (g->coff_ldb != ld * (unsigned)sizeof(T) || g->coff_pad_self != pad_self)) {
-    CHK(g->coff.ensure(((size_t)g->nnz_int + 64) * sizeof(unsigned)));
-    const int nb = std::max(1, (int)((g->N + 255) / 256));
-    hipLaunchKernelGGL((k_coff<T>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(),
-                       g->rcol.as<int>(), (int)g->N, ld * (unsigned)sizeof(T), pad_self,
-                       g->coff.as<unsigned>());
-    g->coff_ldb = ld * (unsigned)sizeof(T);
-    g->coff_pad_self = pad_self;
-  }
-  return GSPX_OK;
-}
 
 // out = scale * (vals . cur) + beta * cur on internal-order panels (one launch of the step kernel);
 // with y != null the result goes to y in the caller's order instead (rows y[perm[i]])
@@ -46,7 +31,6 @@ static int spmm_internal(gspx_graph* g, const T* vals, T scale, T beta, const T*
     t.final = y ? 1 : 0;
     return launch_step_tile<T>(g, opt, t, ld, ctx->stream, vals);
   }
-  if (opt.kernel == 3 || opt.kernel == 4) opt.kernel = 0;  // wave-row kernels have no beta term
   int veccap = 4;
   if (y)
     while (veccap > 1 && ((ldy % veccap) != 0 || (((uintptr_t)y / sizeof(T)) % veccap) != 0))

@@ -55,7 +55,7 @@ def test_kernel_variants_agree(ctx, dtype):
     dev = engine.DeviceGraph.from_w(W, dtype=dtype, ctx=ctx)
     tol = TOL[np.dtype(dtype)]
     try:
-        for kern in (1, 3, 4, 5):  # lane-group panel, wave-row, pipelined wave-row, LDS-staged
+        for kern in (1, 5):  # lane-group panel (scalar metadata), LDS-staged CSR slice
             ctx.set_option("kernel", kern)
             for vec in (0, 1, 2, 4):
                 for rpw in (1, 2, 4, 32):
@@ -228,7 +228,8 @@ def test_options_api(ctx):
     ctx.set_option("rows_per_wave", 8)
     assert ctx.get_option("rows_per_wave") == 8
     ctx.set_option("rows_per_wave", 0)
-    for key, bad in (("vec", 3), ("waves_per_block", 5), ("rows_per_wave", -1), ("narrow_g_log2", 9)):
+    for key, bad in (("vec", 3), ("waves_per_block", 5), ("rows_per_wave", -1), ("narrow_g_log2", 9), ("kernel", 3),
+                     ("kernel", 4), ("kernel", 6)):
         with pytest.raises(ValueError):
             ctx.set_option(key, bad)
     with pytest.raises(ValueError):

@@ -46,7 +46,7 @@ def _run(cases, rng, ctx):
         tiles = bool(rng.integers(2))
         if tiles:
             (dev.build_gather_tiles if rng.integers(2) else dev.enable_gather_tiles)()
-        opts = {"kernel": int(rng.integers(0, 6)), "tile_gather": int(rng.integers(2)), "graph_launch": int(rng.integers(3)),
+        opts = {"kernel": int(rng.choice([0, 0, 1, 2, 5, 5])), "tile_gather": int(rng.integers(2)), "graph_launch": int(rng.integers(3)),
                 "xcd_remap": int(rng.integers(2)), "alternate_sweep": int(rng.integers(2)), "combine": int(rng.integers(3)),
                 "synthesis": int(rng.integers(2)), "max_batch": int(rng.choice([0, 0, 0, 8, 20]))}
         for k, v in opts.items():

@@ -44,7 +44,7 @@ for dtype in (np.float64, np.float32):
             dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
         else:
             dev = engine.DeviceGraph.from_l(L, dtype=dtype, ctx=ctx)
-        for kern, vec in ((1, 0), (3, 0)):
+        for kern, vec in ((1, 0), (5, 0)):
             ctx.set_option("kernel", kern)
             ctx.set_option("vec", vec)
             best = 1e9

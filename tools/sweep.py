@@ -62,13 +62,9 @@ def main():
             vecs = (1, 2) if elt == 8 else (1, 2, 4)
             rpws = (2, 4, 8, 16, 32) if not a.quick else (4,)
             remaps = (1, 0) if reorder == "morton" else (1,)
-            kerns = (5, 4, 1)
+            kerns = (5, 1)
             for kern, vec, rpw, remap in itertools.product(kerns, vecs, rpws, remaps):
                 if kern == 1 and (rpw not in (4,) or vec == 1):
-                    continue
-                if kern in (3, 4) and (vec != 1 or remap == 1):
-                    continue
-                if kern == 4 and rpw not in (8,):
                     continue
                 if kern == 5 and vec == 1:
                     continue
