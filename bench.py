@@ -88,6 +88,10 @@ def parse():
     p.add_argument("--opt", action="append", default=[], help="engine option key=value")
     p.add_argument("--reorder", default="auto")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    p.add_argument("--devices", default=None,
+                   help="single-process launch (no WORLD_SIZE in the environment): comma-separated GPU ids, one "
+                        "driver thread and one libgspx context per entry (default 0..N-1; an id may repeat - "
+                        "the one-GPU test hook)")
     p.add_argument("--evaluation", choices=["recurrence", "newton"], default="recurrence",
                    help="recurrence = the reference's three-term Chebyshev recurrence (headline); "
                         "newton = same polynomial, Newton form (extra line 'newton_form')")
@@ -344,6 +348,252 @@ def run_batch_config(local, rank, world, ctx, gdist, rdev, fence, comm):
             "parity_vs_oracle": {"max_rel_err": err, "columns": 1, "tolerance": 1e-5}}
 
 
+class RankWork:
+    """One rank's share of the headline workload, resident on one libgspx context: an independent sensor graph
+    (device k-NN -> device Laplacian -> tiles), Heat coefficients, the input panel and the output buffer."""
+
+    def __init__(self, a, ctx, rank, dtype, output=True):
+        from pygsp_amd import engine, filters, graphs
+        self.ctx, self.rank, self.dtype = ctx, rank, dtype
+        N, nsig, K = a.n, a.nsig, a.order
+        self.coords = np.random.default_rng(42 + rank).uniform(0, 1, (N, 2))  # nngraphs/sensor.py:56-70
+        t0 = time.perf_counter()
+        self.W, _, self.knn_info = engine.knn_graph(self.coords, a.knn, ctx=ctx)  # SURVEY 8(f) row 4
+        self.t_gen_dev = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        self.G = graphs.Graph(self.W, coords=self.coords, compute_dtype=dtype, ctx=ctx, reorder=a.reorder,
+                              tiles="auto" if a.tiles == "auto" else False)
+        self.t_graph = time.perf_counter() - t0
+        self.dev = self.G.device_graph()
+        self.G.estimate_lmax("bounds")
+        self.lmax = float(self.G.lmax)
+        # Heat(scale) coefficients, compute_cheby_coeff (approximations.py:9-55)
+        self.c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(self.G, a.scale), m=K))
+        self.x = np.random.default_rng(1234 + rank).standard_normal((N, nsig)).astype(dtype)  # zeros would clock higher
+        self.bx = ctx.upload(self.x)
+        self.by = ctx.alloc(self.x.nbytes) if output else None
+        self.nsig = nsig
+        self.dev_ms = self.steps_ms = 0.0
+        self.launches = 0
+
+    def step(self, y_ptr=None):
+        return self.dev.cheby_filter_dev(self.c, self.bx.ptr, y_ptr or self.by.ptr, self.nsig, self.lmax)
+
+    def step_timed(self):
+        self.dev_ms += self.step()
+        t = self.ctx.last_timing()
+        self.steps_ms += t["steps_ms"]
+        self.launches += t["step_launches"]
+
+    def parity(self, cols=2):
+        from oracle import cheby_oracle as orc
+        ref = orc.cheby_op(self.G.L.astype(np.float64), self.lmax, self.c[0], self.x[:, :cols].astype(np.float64))
+        y = self.by.download(self.x.shape, self.dtype)[:, :cols]
+        return float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+
+    def free(self):
+        self.bx.free()
+        if self.by is not None:
+            self.by.free()
+        for g_ in list(self.G._dev.values()):
+            g_.destroy()
+        self.G._dev = {}
+
+
+def run_batch_config_threads(group, no_parity=False):
+    """BASELINE.json configs[4] from ONE process: the batch of 8 independent Sensor(N=500000) graphs x 32 signals,
+    Heat order 30, sharded over the group's contexts (one driver thread each, no data-path collective), the 8
+    output blocks gathered onto context 0 by gspx_gather.  Strong scaling of a fixed batch."""
+    import threading
+
+    from pygsp_amd import dist as gdist
+    from pygsp_amd import filters, graphs
+    n_graphs, N5, nsig, K = 8, 500000, 32, 30
+    n = len(group)
+    block = N5 * nsig * 8
+    shards = [list(gdist.shard_units(n_graphs, r, n)) for r in range(n)]
+    state = [None] * n
+
+    def setup(i, ctx):
+        by_all = ctx.alloc(max(len(shards[i]), 1) * block)
+        jobs = []
+        for slot, g in enumerate(shards[i]):
+            G = graphs.Sensor(N5, seed=g, compute_dtype=np.float64, ctx=ctx)
+            G.estimate_lmax("bounds")
+            c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, 50), m=K))
+            x = np.random.default_rng(100 + g).standard_normal((N5, nsig))
+            jobs.append((G, c, x, ctx.upload(x), by_all.ptr + slot * block))
+        state[i] = (by_all, jobs)
+        run_all(i)
+        ctx.sync()
+
+    def run_all(i):
+        for G, c, _, bx, y_ptr in state[i][1]:
+            G.device_graph().cheby_filter_dev(c, bx.ptr, y_ptr, nsig, float(G.lmax))
+
+    group.run(setup)
+    reps = 3
+    bar = threading.Barrier(n)
+
+    def timed(i, ctx):
+        bar.wait()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run_all(i)
+        ctx.sync()
+        return t0, time.perf_counter()
+
+    spans = group.run(timed)
+    wall = (max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans)) / reps
+    # the gather hands whole buffers over: a context with fewer graphs than slots would ship nothing extra
+    root_buf, t_g, impl = group.gather([st[0] if shards[i] else None for i, st in enumerate(state)], 0)
+    root_buf.free()
+    root_buf, t_g, impl = group.gather([st[0] if shards[i] else None for i, st in enumerate(state)], 0)
+    err = None
+    if not no_parity:
+        from oracle import cheby_oracle as orc
+        got = root_buf.download((n_graphs, N5, nsig), np.float64)
+        err = 0.0
+        for i in range(n):  # the first graph of every context, one column, as it arrived on the root
+            if not shards[i]:
+                continue
+            G, c, x, _, _ = state[i][1][0]
+            ref = orc.cheby_op(orc.laplacian(G.W), float(G.lmax), c[0], x[:, :1])
+            y = got[shards[i][0]]
+            err = max(err, float(np.max(np.abs(y[:, :1] - ref.reshape(N5, 1))) / np.max(np.abs(ref))))
+    root_buf.free()
+    for by_all, jobs in state:
+        for G, _, _, bx, _ in jobs:
+            bx.free()
+            for g_ in list(G._dev.values()):
+                g_.destroy()
+            G._dev = {}
+        by_all.free()
+    return {"workload": "configs[4]: 8 x Sensor(N=500000), Heat(50) order 30, 32 signals each, f64, sharded {} per GPU "
+                        "(strong scaling of a fixed batch)".format("/".join(str(len(s_)) for s_ in shards)),
+            "n_graphs": n_graphs, "n_gpus": n, "ms": wall * 1e3, "value": n_graphs * N5 * nsig * K / wall,
+            "unit": "vertex*signal*order/s", "gather_ms": t_g * 1e3, "gather_impl": impl,
+            "parity_vs_oracle": {"max_rel_err": err, "columns": 1, "graphs_checked": sum(1 for s_ in shards if s_),
+                                 "tolerance": 1e-5}}
+
+
+def main_threads(a):
+    """`python bench.py --gpus N` without a launcher: ONE process, one libgspx context and one driver thread per
+    GPU (ctypes releases the GIL inside the library), the final gather through gspx_gather - RCCL
+    (ncclCommInitAll, grouped send / recv) inside libgspx.  No torch on this path.  Refuses to run on fewer GPUs
+    than asked for."""
+    import threading
+
+    from pygsp_amd import _capi, multi
+    devices = [int(d) for d in a.devices.split(",")] if a.devices else list(range(a.gpus))
+    if len(devices) != a.gpus:
+        raise SystemExit("bench.py: --gpus {} but --devices names {} entries".format(a.gpus, len(devices)))
+    visible = _capi.device_count()
+    if visible < 1 or max(devices) >= visible or min(devices) < 0:
+        raise SystemExit("bench.py: --gpus {} needs HIP devices {} but only {} visible - refusing to report a "
+                         "{}-GPU number from fewer GPUs".format(a.gpus, sorted(set(devices)), visible, a.gpus))
+    group = multi.DeviceGroup(devices)
+    n = len(group)
+    dtype = np.float64 if a.dtype == "f64" else np.float32
+    elt = np.dtype(dtype).itemsize
+    N, nsig, K = a.n, a.nsig, a.order
+    ranks = [None] * n
+
+    def setup(i, ctx):
+        for kv in a.opt:
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
+        ranks[i] = RankWork(a, ctx, i, dtype)
+        for _ in range(a.warmup):
+            ranks[i].step()
+        ctx.sync()
+
+    group.run(setup)
+    bar = threading.Barrier(n)
+
+    def timed(i, ctx):
+        r = ranks[i]
+        bar.wait()  # every context idle, every thread here: the timed region starts
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            r.step_timed()
+        ctx.sync()
+        return t0, time.perf_counter()
+
+    spans = group.run(timed)
+    elapsed = max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans)  # first start to last finish
+
+    # ---- the path's one collective, outside the timed region: every GPU's output block -> context 0 ----
+    gather = None
+    if not a.no_gather:
+        root_buf, t_first, impl = group.gather([r.by for r in ranks], 0)  # first call builds the communicators
+        root_buf.free()
+        root_buf, t_g, impl = group.gather([r.by for r in ranks], 0)
+        got = root_buf.download((n, N, nsig), dtype)
+        for i in (0, n - 1):  # as it arrived: the root's own block and the last peer's, bit for bit
+            assert np.array_equal(got[i], ranks[i].by.download((N, nsig), dtype)), "gathered block {} differs".format(i)
+        del got
+        root_buf.free()
+        uses_rccl = "RCCL" in impl
+        gather = {"gather_ms": t_g * 1e3, "gather_first_call_ms": t_first * 1e3, "gather_impl": impl,
+                  "rccl_ranks": group.n_distinct if uses_rccl else 0,
+                  "gather_GBps": (n - 1) * N * nsig * elt / max(t_g, 1e-9) / 1e9 if group.n_distinct > 1 else None}
+    parity = None
+    if not a.no_cpu:
+        errs = [r.parity(2) for r in ranks]
+        parity = {"max_rel_err": max(errs), "columns": 2, "ranks": n, "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
+
+    r0 = ranks[0]
+    nnz_l = r0.dev.nnz_l
+    U = N * nsig * elt
+    b_alg_launch = (K * (nnz_l * (elt + 4) + 4 * (N + 1) + 3 * U) + U) / K
+    launches = sum(r.launches for r in ranks)
+    avg_launch_ms = sum(r.steps_ms for r in ranks) / max(launches, 1)
+    achieved = b_alg_launch / (avg_launch_ms * 1e-3) / 1e9
+    tiled = bool(r0.G.tile_stats and r0.G.tile_stats.get("enabled"))
+    out = {
+        "metric": baseline_metric(), "value": n * N * nsig * K * a.steps / elapsed, "unit": "vertex*signal*order/s",
+        "n_gpus": n, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {
+            "workload": "Sensor(N={}, k={}) combinatorial Laplacian, Heat(scale={:g}) order {}, {} signals, "
+                        "device-resident (north-star headline), one independent graph per GPU".format(N, a.knn, a.scale, K, nsig),
+            "N": N, "Nsig": nsig, "order": K, "Nf": 1, "nnz_W": int(r0.W.nnz), "nnz_L": int(nnz_l),
+            "n_edges": int(r0.G.n_edges), "lmax": r0.lmax, "lmax_method": "bounds",
+            "parallelism": "graph-parallel x{} (independent graphs, no data-path collective; one final gather)".format(n),
+            "evaluation": "recurrence", "engine_options": a.opt, "gather_tiles": r0.G.tile_stats},
+        "launcher": "one process, one driver thread + one libgspx context per GPU (no torch)",
+        "devices": devices,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_step_tile" if tiled else "k_step_panel / k_step_lds",
+                     "algorithmic_bytes_per_launch": b_alg_launch, "avg_launch_ms": avg_launch_ms,
+                     "launches_timed": launches, "note": "average over the launches of all GPUs"},
+        "per_device": [{"device": devices[i], "ms_per_step": (spans[i][1] - spans[i][0]) / a.steps * 1e3,
+                        "device_ms_per_step": r.dev_ms / a.steps, "avg_launch_ms": r.steps_ms / max(r.launches, 1),
+                        "frac": b_alg_launch / (r.steps_ms / max(r.launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                       for i, r in enumerate(ranks)],
+        "parity_vs_oracle": parity,
+    }
+    if gather:
+        out.update(gather)
+    else:
+        out.update(gather_ms=None, gather_impl=None, rccl_ranks=0)
+    for r in ranks:
+        r.free()
+    if not a.no_configs:
+        try:
+            out["batch_config4"] = run_batch_config_threads(group, no_parity=a.no_cpu)
+        except Exception as e:  # an extra: never a reason to lose the headline measurement
+            out["batch_config4"] = {"error": repr(e)}
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # RCCL's banner (printf) before the result line
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -351,6 +601,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(a.gpus, world))
+    if world == 1 and a.gpus > 1:  # no launcher: this process drives the N GPUs itself
+        return main_threads(a)
 
     # all host cores first: its workers are forked, so it runs before this process touches HIP
     cpu_all = None
@@ -391,15 +643,18 @@ def main():
     N, nsig, K = a.n, a.nsig, a.order
 
     # ---- synthetic workload: one independent sensor graph per rank -----------------------------
+    from pygsp_amd import _capi
+    if local >= _capi.device_count():
+        raise SystemExit("bench.py: rank {} wants HIP device {} but only {} visible - refusing to run".format(
+            rank, local, _capi.device_count()))
     ctx = engine.default_context(local)
     for kv in a.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    coords = np.random.default_rng(42 + rank).uniform(0, 1, (N, 2))  # nngraphs/sensor.py:56-70
     # the graph's weights come from the device k-NN path ...
-    t0 = time.perf_counter()
-    W, _, knn_info = engine.knn_graph(coords, a.knn, ctx=ctx)
-    t_gen_dev = time.perf_counter() - t0
+    rw = RankWork(a, ctx, rank, dtype, output=(world == 1))
+    coords, W, knn_info, t_gen_dev, t_graph = rw.coords, rw.W, rw.knn_info, rw.t_gen_dev, rw.t_graph
+    G, dev, lmax, c, x, bx, by = rw.G, rw.dev, rw.lmax, rw.c, rw.x, rw.bx, rw.by
     t_gen, knn_diff = None, None
     if world == 1:  # ... and are checked against the host (KD-tree) construction of the same matrix
         t0 = time.perf_counter()
@@ -408,26 +663,12 @@ def main():
         assert np.array_equal(ch, coords)
         knn_diff = float(abs(Wh - W).max()) if Wh.nnz == W.nnz else float("inf")
         del Wh
-    t0 = time.perf_counter()
-    G = graphs.Graph(W, coords=coords, compute_dtype=dtype, device=local, reorder=a.reorder,
-                     tiles="auto" if a.tiles == "auto" else False)
-    t_graph = time.perf_counter() - t0
-    dev = G.device_graph()
-    G.estimate_lmax("bounds")
-    lmax = float(G.lmax)
-    # Heat(scale) coefficients, compute_cheby_coeff (approximations.py:9-55)
     from pygsp_amd import filters
-    c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, a.scale), m=K))
-    rng = np.random.default_rng(1234 + rank)
-    x = rng.standard_normal((N, nsig)).astype(dtype)  # random data: zeros would clock higher
-    bx = ctx.upload(x)
     if torch is not None:
         ty = torch.empty((1, N, nsig), dtype=torch.float64 if a.dtype == "f64" else torch.float32,
                          device=tdev)
         y_ptr = ty.data_ptr()
-        by = None
     else:
-        by = ctx.alloc(x.nbytes)
         y_ptr = by.ptr
 
     nodes, dcoef = filters.cheb_to_newton(c[0])
@@ -501,7 +742,6 @@ def main():
     if torch is not None and not a.no_gather:
         fence()
         # in the library: RCCL grouped send / recv (gspx_comm_gather); torch only carried the 128-byte id
-        lib_ok = 0.0
         lib_mode = os.environ.get("GSPX_BENCH_LIB_GATHER", "1")  # "0": never, "force": also under gloo (tests)
         if (a.backend == "nccl" and lib_mode != "0") or lib_mode == "force":
             # run under a watchdog: a communicator that never forms (or a send that never completes) must not
@@ -527,8 +767,14 @@ def main():
                     box["ok"] = True
                 except Exception as e:  # agreed on below: every rank falls back together
                     sys.stderr.write("rank {}: in-library RCCL gather unavailable ({!r})\n".format(rank, e))
+                # the agreement runs under the same watchdog: a rank that failed fast must not wait in a torch
+                # collective for a peer that hangs inside ncclCommInitRank
+                box["agree"] = gdist.sum_over_ranks(1.0 if box.get("ok") else 0.0, rdev)
 
-            th = threading.Thread(target=lib_gather if uid is not None else (lambda: None), daemon=True)
+            def no_id():
+                box["agree"] = gdist.sum_over_ranks(0.0, rdev)
+
+            th = threading.Thread(target=lib_gather if uid is not None else no_id, daemon=True)
             th.start()
             th.join(240.0)
             if th.is_alive():
@@ -550,10 +796,10 @@ def main():
                 os._exit(0)
             comm = box.get("comm")
             if box.get("ok"):
-                lib_ok, t_lib = 1.0, box["ms"]
-        if gdist.sum_over_ranks(lib_ok, rdev) != float(world) and comm is not None:
-            comm.close()
-            comm = None
+                t_lib = box["ms"]
+            if box.get("agree") != float(world) and comm is not None:
+                comm.close()
+                comm = None
         if comm is not None:
             gather_ms = gdist.max_over_ranks(t_lib, rdev)
             gather_impl = "libgspx gspx_comm_gather: RCCL grouped ncclSend/ncclRecv, one xGMI link per peer"

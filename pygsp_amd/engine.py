@@ -279,7 +279,7 @@ def hilbert_order(coords, bits=16):
     return np.argsort(d, kind="stable").astype(np.int32)
 
 
-def locality_order(W, coords=None, curve="auto", device=0):
+def locality_order(W, coords=None, curve="auto", device=0, ctx=None):
     """Vertex order used INSIDE the engine (perm[new] = old) so that neighbour gathers hit cache.
 
     * with coordinates (NN graphs such as Sensor): a space-filling curve through the first two /
@@ -299,7 +299,7 @@ def locality_order(W, coords=None, curve="auto", device=0):
         hil = curve == "hilbert" or (curve == "auto" and coords.shape[1] == 2)
         c = np.ascontiguousarray(coords, dtype=np.float64)
         keys = np.empty(N, dtype=np.uint64)
-        _capi.check(_capi.load().gspx_curve_keys(default_context(device)._h, N, c.shape[1], _capi.ptr(c),
+        _capi.check(_capi.load().gspx_curve_keys((ctx or default_context(device))._h, N, c.shape[1], _capi.ptr(c),
                                                  1 if hil else 0, _capi.ptr(keys)))
         return np.argsort(keys, kind="stable").astype(np.int32)
     if has_coords and (curve == "hilbert" or (curve == "auto" and coords.shape[1] == 2)):
@@ -347,11 +347,11 @@ def locality_score(W, perm=None, reach=None, sample=None):
     return float(np.mean(np.abs(r.astype(np.int64) - c.astype(np.int64)) <= reach))
 
 
-def auto_order(W, coords=None, device=0):
+def auto_order(W, coords=None, device=0, ctx=None):
     """The internal order `reorder='auto'` picks: Morton order when coordinates exist, otherwise
     reverse Cuthill-McKee - but only if it beats the graph's own order on `locality_score`
     (block-structured graphs such as a sorted SBM are already local; RCM would scramble them)."""
-    perm = locality_order(W, coords, device=device)
+    perm = locality_order(W, coords, device=device, ctx=ctx)
     if perm is None:
         return None
     # (scored on a sample of the entries: coordinates may be a plotting layout unrelated to the edges)

@@ -162,11 +162,15 @@ def cheby_op(G, c, signal, **kwargs):
     evaluation = kwargs.get("evaluation") or EVALUATION
     if evaluation not in ("recurrence", "newton"):
         raise ValueError("evaluation must be 'recurrence' or 'newton'")
-    dev = _device_graph_of(G)
-    if evaluation == "newton" and coeffs.shape[0] == 1:
-        y, ms = dev.newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
+    devices = _device_list(G, kwargs.get("devices"))
+    if devices is not None and x.shape[1] > 0:
+        # signal-parallel: the graph replicated per GPU, the columns split, one RCCL gather
+        from . import multi
+        y, ms = multi.filter_columns(G, coeffs, x, devices, _capi.ANALYSIS)
+    elif evaluation == "newton" and coeffs.shape[0] == 1:
+        y, ms = _device_graph_of(G).newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
     else:
-        y, ms = dev.cheby_filter(coeffs, x, G.lmax, _capi.ANALYSIS)
+        y, ms = _device_graph_of(G).cheby_filter(coeffs, x, G.lmax, _capi.ANALYSIS)
     _record_timing(G, ms)
     stacked = np.asarray(y, dtype=np.float64).reshape(coeffs.shape[0] * G.N, x.shape[1])
     return stacked[:, 0] if vector_in else stacked
@@ -221,6 +225,20 @@ def _device_graph_of(G):
         return G.device_graph()
     from . import plugin
     return plugin.device_graph_for(G)
+
+
+def _device_list(G, devices):
+    """The GPUs a call is split over: the `devices` argument of the call, else the list given to
+    plugin.install(devices=[...]) when `G` is a reference graph; None (one device) otherwise."""
+    if devices is None and not hasattr(G, "device_graph"):
+        from . import plugin
+        devices = plugin._config.get("devices")
+    if devices is None:
+        return None
+    devices = [int(d) for d in devices]
+    if not devices:
+        raise ValueError("devices must name at least one GPU")
+    return devices if len(devices) > 1 else None
 
 
 def _record_timing(G, ms):
@@ -295,12 +313,12 @@ class Filter:
             raise ValueError("At most 3 dimensions: #nodes x #signals x #features.")
         return s, s.shape[2] != 1
 
-    def filter(self, s, method="chebyshev", order=30):
+    def filter(self, s, method="chebyshev", order=30, devices=None):
         """Filter signals (analysis or synthesis), filter.py:146-328.
 
         Shapes follow the reference exactly: `s` is (N,), (N, Nsig) or (N, Nsig, Nfeat) with
         Nfeat in {1, Nf}; a trailing dimension equal to Nf means synthesis.  The result is
-        squeezed.
+        squeezed.  `devices` (this engine's addition): a list of GPU ids to split the signal columns over.
         """
         cube, synthesis = self._as_three_axes(s)
         if method == "exact":
@@ -312,29 +330,34 @@ class Filter:
         coeffs = compute_cheby_coeff(self, m=order)
         if not synthesis:
             # device buffer [filter][vertex][signal] -> (vertex, signal, filter), as filter.py:310-311
-            flat = cheby_op(self.G, coeffs, cube[:, :, 0])
+            flat = cheby_op(self.G, coeffs, cube[:, :, 0], devices=devices)
             out = np.moveaxis(flat.reshape(self.Nf, self.G.N, cube.shape[1]), 0, 2)
         else:
             # out = sum_f p_f(L) s[:, :, f]  (filter.py:313-322), one device call
             if np.iscomplexobj(cube):
                 raise TypeError("complex signals are not supported by the Chebyshev path")
             planes = np.ascontiguousarray(np.moveaxis(cube, 2, 0))
-            y, ms = _device_graph_of(self.G).cheby_filter(_as_coeff_matrix(coeffs), planes, self.G.lmax,
-                                                          _capi.SYNTHESIS)
+            split = _device_list(self.G, devices)
+            if split is not None and planes.shape[2] > 0:
+                from . import multi
+                y, ms = multi.filter_columns(self.G, _as_coeff_matrix(coeffs), planes, split, _capi.SYNTHESIS)
+            else:
+                y, ms = _device_graph_of(self.G).cheby_filter(_as_coeff_matrix(coeffs), planes, self.G.lmax,
+                                                              _capi.SYNTHESIS)
             _record_timing(self.G, ms)
             out = np.asarray(y, dtype=np.float64)
         return np.squeeze(out)
 
-    def analyze(self, s, method="chebyshev", order=30):
+    def analyze(self, s, method="chebyshev", order=30, devices=None):
         if np.ndim(s) == 3 and np.shape(s)[-1] != 1:
             raise ValueError("Last dimension (#features) should be 1, got {}.".format(np.shape(s)))
-        return self.filter(s, method, order)
+        return self.filter(s, method, order, devices=devices)
 
-    def synthesize(self, s, method="chebyshev", order=30):
+    def synthesize(self, s, method="chebyshev", order=30, devices=None):
         if np.shape(s)[-1] != self.Nf:
             raise ValueError("Last dimension (#features) should be the number of filters "
                              "Nf = {}, got {}.".format(self.Nf, np.shape(s)))
-        return self.filter(s, method, order)
+        return self.filter(s, method, order, devices=devices)
 
     def localize(self, i, **kwargs):
         """The kernel(s) localised at vertex i: sqrt(N) * filter(delta_i)  (filter.py:350-391)."""

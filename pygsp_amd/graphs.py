@@ -56,7 +56,7 @@ class Graph:
     are this engine's: compute dtype, device, internal vertex order, gather tiles."""
 
     def __init__(self, adjacency, lap_type="combinatorial", coords=None, plotting={}, *,
-                 compute_dtype=np.float64, device=0, reorder="auto", tiles="auto"):
+                 compute_dtype=np.float64, device=0, reorder="auto", tiles="auto", ctx=None):
         self.logger = _logger
         self._adjacency = _checked_adjacency(adjacency, self.logger)
         self.n_vertices = self.N = self._adjacency.shape[0]
@@ -70,7 +70,10 @@ class Graph:
         self.plotting, self.signals = dict(plotting), {}
 
         # engine-side configuration and state
-        self.compute_dtype, self.device = np.dtype(compute_dtype), int(device)
+        # (ctx: a specific libgspx context instead of the default one of `device` - one per driver thread
+        # when a process runs several GPUs, pygsp_amd.multi)
+        self._ctx = ctx
+        self.compute_dtype, self.device = np.dtype(compute_dtype), int(ctx.device if ctx is not None else device)
         self.reorder = reorder
         self.tiles = tiles  # "auto" | True | False: gather tiles of the LDS-staged recurrence step
         self.tile_stats = None
@@ -105,6 +108,11 @@ class Graph:
         """W itself if undirected, else (W + W.T)/2 (utils.symmetrize 'average', graph.py:613-616)."""
         return sparse.csr_matrix((self.W + self.W.T) / 2) if self.is_directed() else self.W
 
+    @property
+    def context(self):
+        """The libgspx context (device + stream) this graph's device state lives on."""
+        return self._ctx if self._ctx is not None else engine.default_context(self.device)
+
     # ---- Laplacian (device) --------------------------------------------------------------------
     def _internal_order(self):
         if not self._perm_done:
@@ -117,10 +125,10 @@ class Graph:
                 # Cuthill-McKee on the pattern (0.25 s at N = 1M; within 6 % of Morton on kNN
                 # graphs) - kept only if it improves locality over the graph's own order
                 big = self.n_vertices >= 4096
-                self._perm = engine.auto_order(self.W, getattr(self, "coords", None), self.device) if big else None
+                self._perm = engine.auto_order(self.W, getattr(self, "coords", None), ctx=self.context) if big else None
             elif mode in ("morton", "hilbert"):
                 self._perm = engine.locality_order(self.W, getattr(self, "coords", None), curve=mode,
-                                                   device=self.device)
+                                                   ctx=self.context)
             elif mode == "rcm":
                 self._perm = engine.locality_order(self.W, None)
             else:
@@ -132,9 +140,8 @@ class Graph:
         dt = np.dtype(dtype or self.compute_dtype)
         g = self._dev.get(dt)
         if g is None:
-            ctx = engine.default_context(self.device)
             g = engine.DeviceGraph.from_w(self._symmetric_w(), self.lap_type, dtype=dt,
-                                          perm=self._internal_order(), ctx=ctx)
+                                          perm=self._internal_order(), ctx=self.context)
             if self.tiles == "auto":  # LDS tiles for the recurrence step, when the order is local
                 self.tile_stats = g.auto_gather_tiles()
             elif self.tiles:
@@ -372,7 +379,7 @@ class NNGraph(Graph):
         if rescale:  # nngraph.py:132-137: N^(1/min(d,3)) / 10 over half the bounding-box diagonal
             half_diagonal = 0.5 * np.linalg.norm(points.max(axis=0) - points.min(axis=0), 2)
             points = points * (np.power(n_points, 1.0 / float(min(dim, 3))) / 10.0 / half_diagonal)
-        ctx = engine.default_context(int(kwargs.get("device", 0)))
+        ctx = kwargs.get("ctx") or engine.default_context(int(kwargs.get("device", 0)))
         if NNtype == "knn":
             W, self.sigma, info = engine.knn_graph(points, k, sigma, ctx=ctx, metric=metric,
                                                    symmetrize=symmetrize_type)
@@ -497,7 +504,7 @@ class StochasticBlockModel(Graph):
         if self.M.min() < 0 or self.M.max() > 1:
             raise ValueError("Probabilities should be in [0, 1].")
         device_seed = int(stream.integers(0, 2 ** 63))
-        ctx = engine.default_context(int(kwargs.get("device", 0)))
+        ctx = kwargs.get("ctx") or engine.default_context(int(kwargs.get("device", 0)))
         pattern, self.sampler_ms = engine.sbm_graph(self.z, self.M, seed=device_seed, ctx=ctx)
         # unit int64 weights, like the reference's W
         W = sparse.csr_matrix((np.ones(pattern.nnz, dtype=np.int64), pattern.indices, pattern.indptr),

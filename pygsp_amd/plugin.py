@@ -14,8 +14,12 @@ from scipy import sparse
 
 from . import engine, filters as _filters
 
+import threading
+
 _saved = {}
-_config = {"laplacian": "device", "dtype": np.float64, "device": 0, "reorder": "auto", "tiles": "auto"}
+_config = {"laplacian": "device", "dtype": np.float64, "device": 0, "reorder": "auto", "tiles": "auto",
+           "devices": None}
+_cache_lock = threading.RLock()
 
 
 def _finite_coords(G):
@@ -29,45 +33,57 @@ def _finite_coords(G):
     return coords
 
 
-def device_graph_for(G):
+def device_graph_for(G, ctx=None):
     """libgspx graph attached to a reference ``pygsp.graphs.Graph``: cached on the object next to the
     very ``G.L`` (and ``G.W``) it was built from, and rebuilt when ``G.compute_laplacian`` replaced
     them, mirroring graph.py:602-609.  The cache entry holds the matrices themselves and compares with
-    ``is`` - an ``id()`` alone could be recycled by a later matrix."""
+    ``is`` - an ``id()`` alone could be recycled by a later matrix.  One entry per context (`ctx`: the
+    context of the configured device unless given - the replicas of a device list, pygsp_amd.multi).
+    A stale entry is dropped, not destroyed: whoever still holds the old DeviceGraph (another thread in the
+    middle of a filter call, a caller that kept the return value) keeps a live handle, and the device memory
+    goes when the last reference does (DeviceGraph.__del__)."""
     conf = (G.lap_type, np.dtype(_config["dtype"]).str, _config["laplacian"], _config["reorder"],
-            bool(_config.get("tiles", "auto")), _config["device"])
-    cached = getattr(G, "_gspx_dev", None)
-    if cached is not None and cached[0] is G.L and cached[1] is G.W and cached[2] == conf:
-        return cached[3]
-    if cached is not None:
-        cached[3].destroy()
-    ctx = engine.default_context(_config["device"])
-    perm = None
-    if _config["reorder"] == "auto" and G.N >= 4096:
-        perm = engine.auto_order(G.W, _finite_coords(G), _config["device"])
-    elif _config["reorder"] == "rcm":
-        perm = engine.locality_order(G.W, None)
-    if _config["laplacian"] == "device":
-        W = G.W if not G.is_directed() else sparse.csr_matrix((G.W + G.W.T) / 2)
-        dev = engine.DeviceGraph.from_w(W, G.lap_type, dtype=_config["dtype"], perm=perm, ctx=ctx)
-    else:  # bit-parity mode: upload the Laplacian the reference built
-        dev = engine.DeviceGraph.from_l(G.L, dtype=_config["dtype"], perm=perm, ctx=ctx)
-    if _config.get("tiles", "auto"):
-        dev.auto_gather_tiles()
-    G._gspx_dev = (G.L, G.W, conf, dev)
-    return dev
+            bool(_config.get("tiles", "auto")))
+    ctx = ctx or engine.default_context(_config["device"])
+    with _cache_lock:
+        cache = G.__dict__.setdefault("_gspx_dev", {})
+        cached = cache.get(id(ctx))
+        if (cached is not None and cached[0] is G.L and cached[1] is G.W and cached[2] == conf
+                and cached[4] is ctx and getattr(cached[3], "_h", None)):
+            return cached[3]
+        perm = None
+        if _config["reorder"] == "auto" and G.N >= 4096:
+            perm = engine.auto_order(G.W, _finite_coords(G), ctx=ctx)
+        elif _config["reorder"] == "rcm":
+            perm = engine.locality_order(G.W, None)
+        if _config["laplacian"] == "device":
+            W = G.W if not G.is_directed() else sparse.csr_matrix((G.W + G.W.T) / 2)
+            dev = engine.DeviceGraph.from_w(W, G.lap_type, dtype=_config["dtype"], perm=perm, ctx=ctx)
+        else:  # bit-parity mode: upload the Laplacian the reference built
+            dev = engine.DeviceGraph.from_l(G.L, dtype=_config["dtype"], perm=perm, ctx=ctx)
+        if _config.get("tiles", "auto"):
+            dev.auto_gather_tiles()
+        cache[id(ctx)] = (G.L, G.W, conf, dev, ctx)
+        return dev
 
 
 def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, reorder="auto",
-            tiles="auto"):
+            tiles="auto", devices=None):
     """Patch the real pygsp in place.  `laplacian`: 'device' (L assembled by HIP kernels from
-    G.W) or 'host' (upload the reference's G.L)."""
+    G.W) or 'host' (upload the reference's G.L).  `devices` (a list of GPU ids, optional): every
+    ``Filter.filter(method='chebyshev')`` splits its signal columns over these GPUs - the graph is replicated
+    once per GPU, the outputs are gathered by RCCL inside libgspx (pygsp_amd.multi.filter_columns)."""
     if laplacian not in ("device", "host"):
         raise ValueError("laplacian must be 'device' or 'host'")
     if pygsp_module is None:
         import pygsp as pygsp_module
+    if devices is not None:
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one GPU")
+        device = devices[0]
     _config.update(laplacian=laplacian, dtype=np.dtype(dtype), device=int(device), reorder=reorder,
-                   tiles=tiles)
+                   tiles=tiles, devices=devices)
     approx = pygsp_module.filters.approximations
     if "cheby_op" not in _saved:
         _saved["cheby_op"] = approx.cheby_op

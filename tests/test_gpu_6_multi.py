@@ -151,3 +151,152 @@ def test_two_ranks_on_this_gpu_through_bench():
     b5 = out["batch_config4"]  # BASELINE configs[4]: 8 graphs sharded 4 + 4
     assert b5["n_gpus"] == 2 and b5["n_graphs"] == 8 and b5["value"] > 0 and "4/4" in b5["workload"]
     assert b5["parity_vs_oracle"]["max_rel_err"] < 1e-11
+
+
+# ---- one process, several contexts / GPUs: bench.py --gpus N without a launcher, signal-parallel filtering ----
+def _run_bench(args, timeout=900):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` with fewer than N devices: non-zero exit and a one-line reason, never a silent
+    single-GPU line."""
+    n = _capi.device_count()
+    res = _run_bench(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], timeout=300)
+    assert res.returncode != 0
+    assert "refusing" in res.stderr and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_threads_two_contexts_on_this_gpu():
+    """The launcher-free N > 1 path of bench.py on this box's one GPU: two contexts, two driver threads
+    (`--devices 0,0`), barrier-bracketed timing, gspx_gather, parity of BOTH ranks, the strong-scaling batch."""
+    res = _run_bench(["--gpus", "2", "--devices", "0,0", "--steps", "2", "--warmup", "1", "--vertices", "100000",
+                      "--nsig", "16"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["devices"] == [0, 0]
+    assert out["gather_ms"] > 0 and "gspx_gather" in out["gather_impl"] and out["rccl_ranks"] == 0
+    assert len(out["per_device"]) == 2 and all(p["frac"] > 0 for p in out["per_device"])
+    assert out["parity_vs_oracle"]["ranks"] == 2 and out["parity_vs_oracle"]["max_rel_err"] < 1e-11
+    b5 = out["batch_config4"]
+    assert b5["n_gpus"] == 2 and b5["n_graphs"] == 8 and "4/4" in b5["workload"] and b5["value"] > 0
+    assert b5["parity_vs_oracle"]["max_rel_err"] < 1e-11 and b5["parity_vs_oracle"]["graphs_checked"] == 2
+
+
+def test_bench_all_visible_gpus_through_rccl():
+    """On a box with >= 2 GPUs: bench.py --gpus <all> drives them from one process and gathers through the
+    library's RCCL communicators (ncclCommInitAll) with real peers."""
+    n = _capi.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: cross-device gspx_gather cannot run here")
+    res = _run_bench(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--vertices", "200000", "--nsig", "16"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == n and out["rccl_ranks"] == n and "RCCL" in out["gather_impl"]
+    assert out["parity_vs_oracle"]["ranks"] == n and out["parity_vs_oracle"]["max_rel_err"] < 1e-11
+    assert out["batch_config4"]["parity_vs_oracle"]["max_rel_err"] < 1e-11
+
+
+def test_comm_gather_real_peers():
+    """gspx_comm_* (one process per GPU) with real peers, on a box with >= 2 GPUs: bench.py under
+    torch.distributed.run, backend nccl, the in-library gather must succeed on every rank."""
+    n = _capi.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible")
+    pytest.importorskip("torch")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", str(n), "--steps", "2", "--warmup", "1", "--vertices", "200000", "--nsig", "16", "--no-newton"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == n and "gspx_comm_gather" in out["gather_impl"]
+    assert out["parity_vs_oracle"]["max_rel_err"] < 1e-11
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_filter_columns_split_over_two_contexts(ctx, dtype):
+    """ONE graph replicated on every context of the device list, the signal columns split,
+    one gather - through Filter.filter(..., devices=[...]).  Two contexts on this box's GPU; columns come back
+    in the caller's order and equal the single-device result bit for bit (same kernels, same panel widths are
+    not guaranteed - so: equal to the oracle within the bar, and to the one-device call within rounding)."""
+    from pygsp_amd import multi
+    G = graphs.Sensor(6000, seed=3, compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    rng = np.random.default_rng(8)
+    L = orc.laplacian(G.W)
+    tol = TOL[np.dtype(dtype)] * 10
+    for bank, kernels in ((filters.Heat(G, 10), [orc.heat_kernel(10, G.lmax)]),
+                          (filters.MexicanHat(G, Nf=4), orc.mexican_hat_kernels(G.lmax, 4))):
+        for nsig in (1, 5, 16):
+            x = rng.standard_normal((G.N, nsig))
+            one = bank.filter(x, order=20)
+            two = bank.filter(x, order=20, devices=[0, 0])
+            assert two.shape == one.shape
+            ref = orc.filter_chebyshev(L, G.lmax, kernels, x.astype(dtype).astype(np.float64), 20)
+            assert rel_err(two, np.squeeze(ref)) < tol and rel_err(two, one) < tol
+    # synthesis: (N, Nsig, Nf) -> (N, Nsig), columns split the same way
+    bank = filters.MexicanHat(G, Nf=4)
+    s = rng.standard_normal((G.N, 6, 4))
+    assert rel_err(bank.filter(s, order=12, devices=[0, 0]), bank.filter(s, order=12)) < tol
+    # three "devices", fewer columns than devices: the empty shard is skipped
+    x = rng.standard_normal((G.N, 2))
+    tm = {}
+    y, _ = multi.filter_columns(G, filters.compute_cheby_coeff(filters.Heat(G, 10), m=10), x, [0, 0, 0], timings=tm)
+    assert tm["columns"] == [1, 1, 0] and y.shape == (1, G.N, 2)
+    assert rel_err(y[0], orc.filter_chebyshev(L, G.lmax, [orc.heat_kernel(10, G.lmax)],
+                                              x.astype(dtype).astype(np.float64), 10)) < tol
+    # the replicas are cached on the graph: a second call builds nothing
+    reps = dict(G._gspx_replicas)
+    bank.filter(s, order=12, devices=[0, 0])
+    assert {k: v[1] for k, v in G._gspx_replicas.items()} == {k: v[1] for k, v in reps.items()}
+    with pytest.raises(ValueError):
+        bank.filter(x, devices=[0, _capi.device_count()])
+
+
+def test_plugin_install_with_a_device_list(ctx):
+    """plugin.install(devices=[...]): a reference-shaped graph is replicated per context and every
+    cheby_op call splits its columns (here over two contexts of this GPU)."""
+    import types
+
+    from pygsp_amd import plugin
+    W = random_graph(5000, 6, 21)
+
+    class RefGraph:
+        def __init__(self):
+            self.W, self.N, self.lap_type = W, W.shape[0], "combinatorial"
+            self.L = orc.laplacian(W)
+            self.lmax = upper_lmax(W)
+
+        def is_directed(self):
+            return False
+
+    fake = types.ModuleType("pygsp")
+    fake.filters = types.ModuleType("pygsp.filters")
+    fake.filters.approximations = types.ModuleType("pygsp.filters.approximations")
+    orig = lambda G, c, s, **kw: orc.cheby_op(G.L, G.lmax, c, s)  # noqa: E731
+    fake.filters.approximations.cheby_op = orig
+    fake.filters.cheby_op = orig
+    G = RefGraph()
+    c = orc.compute_cheby_coeff(orc.heat_kernel(4, G.lmax), G.lmax, 15)
+    s = np.random.default_rng(3).standard_normal((G.N, 7))
+    plugin.install(fake, devices=[0, 0])
+    try:
+        y = fake.filters.approximations.cheby_op(G, c, s)
+        assert y.shape == (G.N, 7) and rel_err(y, orig(G, c, s)) < 1e-12
+        assert len(G._gspx_dev) == 2  # one device graph per context
+        assert fake.filters.cheby_op(G, c, s[:, 0]).shape == (G.N,)
+    finally:
+        plugin.uninstall(fake)
+        plugin.install(fake)  # back to the single-device configuration for the tests that follow
+        plugin.uninstall(fake)

@@ -1,5 +1,7 @@
 """Host-side logic of the product that needs no GPU: coefficient quadrature, kernel designs,
 filterbank handler, shape algebra (with a stubbed device call), generators, vertex ordering."""
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -235,3 +237,19 @@ def test_use_backend_patches_and_restores_both_lookup_sites(monkeypatch):
         monkeypatch.delenv("PYGSP_AMD_BACKEND")
         importlib.reload(plugin)
     assert mod2.filters.cheby_op is orig2
+
+
+def test_bench_refuses_gpus_it_cannot_see():
+    """`python bench.py --gpus 2` on a box that cannot provide two devices (here: none) exits non-zero with a
+    one-line reason instead of reporting a smaller run under a larger n_gpus."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    from pygsp_amd import _capi
+    if _capi.device_count() >= 2:
+        pytest.skip("two devices visible here")
+    assert res.returncode != 0 and "refusing" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
