@@ -88,7 +88,12 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *                   kernels (0 / -1 = auto)
  *   "newton_pair"   1 (default) Newton-form filtering runs two orders per launch when the graph carries
  *                   pair tiles (gspx_graph_set_tiles)
- *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order; 0 edge order */
+ *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order; 0 edge order
+ *   "host_pipeline" gspx_cheby_filter: 1 (default) large calls pipelined in column batches, 2 always, 0 never;
+ *                   "host_batch" signals per batch, "host_threads" per direction (0 = auto)
+ *   "streamed_alloc" 1 (default) workspaces from scrambled 2 MB chunks (+2..8 % bandwidth; a retired range
+ *                   keeps its address space: read-only "retired_va_mb"); 0 plain hipMalloc, the safe mode
+ *                   (also GSPX_STREAMED_ALLOC=0 in the environment) */
 int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value);
 int gspx_ctx_get_option(gspx_ctx* ctx, const char* key, int64_t* value);
 
@@ -173,7 +178,11 @@ int gspx_graph_build_ms(gspx_graph* g, double* ms);
 int gspx_cheby_filter_dev(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                           int64_t Nsig, const void* x_dev, void* y_dev, int mode,
                           double* kernel_ms);
-/* Same with HOST pointers (one H2D + one D2H around the device call). */
+/* Same with HOST pointers (pageable memory is fine): what a caller of pygsp/filters/filter.py:146-328 hands
+ * over.  Large calls are cut into signal-column batches and pipelined over pinned staging buffers - host
+ * threads pack batch b+2, DMA of b+1, kernels of b, DMA of b-1 and unpacking of b-2 overlap - so the call
+ * costs about max(PCIe, kernels) instead of their sum; small calls are one copy in, the kernels, one copy
+ * out (option "host_pipeline").  Bit-identical either way.  kernel_ms: device time of the kernels alone. */
 int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                       int64_t Nsig, const void* x_host, void* y_host, int mode,
                       double* kernel_ms);

@@ -144,6 +144,12 @@ int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int
  * `plan` must hold (M-1)*(4+3*Nf) doubles.  a1 = a2 = lmax/2 as approximations.py:93-96. */
 int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, double* plan);
 
+/* Stage times of the LAST gspx_cheby_filter call on this context (milliseconds): out[0] wall time of the
+ * pipelined call, out[1] packing (busiest host thread), out[2] host-to-device DMA (sum over batches), out[3]
+ * kernels (sum of device times), out[4] device-to-host DMA, out[5] unpacking (busiest host thread), out[6]
+ * batches (0: the call was not pipelined), out[7] signals per batch, out[8] host threads per direction. */
+int gspx_last_host_timing(gspx_ctx* ctx, double out[9]);
+
 /* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two
  * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */
 int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);

@@ -100,6 +100,7 @@ SIGNATURES = {
     "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,
                                         _c.c_int, _c.c_int]),
     "gspx_last_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
+    "gspx_last_host_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "gspx_plan_describe": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P]),
     "gspx_lanczos_lmax": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.POINTER(_c.c_double),
                                      _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),

@@ -84,6 +84,8 @@ extern "C" const char* gspx_version(void) { return "gspx 0.1 (gfx950)"; }
 //     range: it stays reserved for the life of the process, so no later mapping can ever alias it
 //     (costs address space only: at most max(2 x size, 1 GiB) of the 2^47-byte space per retired buffer);
 //   * a request beyond the reservation retires the range that way and starts a new one.
+static std::atomic<size_t> g_retired_va_bytes{0};  // address space of retired ranges (never handed back)
+
 struct DevMem {
   void* p = nullptr;
   size_t bytes = 0;     // usable bytes
@@ -107,6 +109,7 @@ struct DevMem {
       }
       pieces.clear();
       (void)hipGetLastError();  // the range itself is retired, never freed (see above)
+      g_retired_va_bytes += va_size;
     } else if (p) {
       (void)hipFree(p);
     }
@@ -222,6 +225,83 @@ struct DevMem {
   template <typename T> T* as() const { return (T*)p; }
 };
 
+// pinned host memory and the per-context state of the pipelined host-pointer entry point
+// (gspx_hostpipe.hip.h): two staging panels per direction, two device panels per direction, a stream per
+// copy direction
+struct PinMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  PinMem() = default;
+  PinMem(const PinMem&) = delete;
+  PinMem& operator=(const PinMem&) = delete;
+  ~PinMem() { release(); }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  int ensure(size_t n) {
+    if (p && n <= bytes) return GSPX_OK;
+    release();
+    hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      p = nullptr;
+      (void)hipGetLastError();
+      return set_err(GSPX_ERR_HIP, "hipHostMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    return GSPX_OK;
+  }
+};
+
+struct HostPipe {
+  hipStream_t stream_in = nullptr, stream_out = nullptr;
+  hipEvent_t h2d_ev[2] = {nullptr, nullptr};
+  hipEvent_t t_in[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // per slot: H2D start / stop
+  hipEvent_t t_out[2] = {nullptr, nullptr};                          // D2H start / stop (the shipper waits for each)
+  PinMem pin_in[2], pin_out[2];
+  DevMem dx[2], dy[2];
+  // timings of the last pipelined call (ms): wall, pack (busiest worker), H2D (sum of DMA times), kernels
+  // (sum of device times), D2H, unpack (busiest worker), batches, batch width, host threads per direction
+  double timing[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool ready = false;
+  int init() {
+    if (ready) return GSPX_OK;
+    HIPCHK(hipStreamCreateWithFlags(&stream_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&stream_out, hipStreamNonBlocking));
+    for (auto& e : h2d_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& sl : t_in)
+      for (auto& e : sl) HIPCHK(hipEventCreate(&e));
+    for (auto& e : t_out) HIPCHK(hipEventCreate(&e));
+    ready = true;
+    return GSPX_OK;
+  }
+  void destroy() {
+    if (stream_in) (void)hipStreamDestroy(stream_in);
+    if (stream_out) (void)hipStreamDestroy(stream_out);
+    for (auto& e : h2d_ev)
+      if (e) (void)hipEventDestroy(e);
+    for (auto& sl : t_in)
+      for (auto& e : sl) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+      }
+    for (auto& e : t_out) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    stream_in = stream_out = nullptr;
+    for (auto& e : h2d_ev) e = nullptr;
+    for (int i = 0; i < 2; ++i) {
+      pin_in[i].release();
+      pin_out[i].release();
+      dx[i].release();
+      dy[i].release();
+    }
+    ready = false;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------------
@@ -248,6 +328,13 @@ struct Options {
   int64_t ws_limit_mb = 65536;  // workspace budget per filter call
   int64_t max_batch = 0;        // 0 = no extra cap on signals per batch
   int64_t gather_rccl = 1;      // gspx_gather: 0 peer copies, 1 RCCL between devices (peer copies if it fails), 2 RCCL for every block
+  int64_t host_pipeline = 1;    // gspx_cheby_filter (host pointers): 1 column batches pipelined over pinned staging when the
+                                // call is large enough, 2 always, 0 one pageable copy in, the kernels, one out
+  int64_t host_batch = 0;       // signals per pipelined batch (0: auto)
+  int64_t host_threads = 0;     // host threads packing / unpacking, per direction (0: auto, at most 8)
+  int64_t streamed_alloc = 1;   // 1: the two streamed workspaces are assembled from scrambled 2 MB chunks (HIP
+                                // virtual-memory API; +2..8 % bandwidth); 0: plain hipMalloc (the safe mode on an
+                                // untested ROCm: no address range is ever reserved or retired)
 };
 
 struct gspx_ctx {
@@ -260,6 +347,7 @@ struct gspx_ctx {
   DevMem ws_r;      // accumulators
   DevMem ws_w;      // per-step flush weights / combine coefficients
   DevMem io_x, io_y;  // staging for the host-pointer entry point
+  HostPipe* pipe = nullptr;  // its pipelined form (created on first use)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev_pool;
   double timing[5] = {0, 0, 0, 0, 0};
@@ -359,8 +447,11 @@ extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
   HIPCHK(hipSetDevice(device));
   gspx_ctx* ctx = new gspx_ctx();
   ctx->device = device;
-  ctx->ws_t.streamed = true;  // the two workspaces the recurrence streams every step
-  ctx->ws_r.streamed = true;
+  {  // the two workspaces the recurrence streams every step (GSPX_STREAMED_ALLOC=0: plain hipMalloc)
+    const char* env = getenv("GSPX_STREAMED_ALLOC");
+    ctx->opt.streamed_alloc = (env && env[0] == '0') ? 0 : 1;
+    ctx->ws_t.streamed = ctx->ws_r.streamed = ctx->opt.streamed_alloc != 0;
+  }
   if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device) !=
           hipSuccess ||
       ctx->cu_count < 1)
@@ -398,6 +489,11 @@ extern "C" int gspx_ctx_destroy(gspx_ctx* ctx) {
   ctx->ws_w.release();
   ctx->io_x.release();
   ctx->io_y.release();
+  if (ctx->pipe) {
+    ctx->pipe->destroy();
+    delete ctx->pipe;
+    ctx->pipe = nullptr;
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return GSPX_OK;
@@ -432,6 +528,10 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
   if (!strcmp(key, "max_batch")) return &o.max_batch;
   if (!strcmp(key, "gather_rccl")) return &o.gather_rccl;
+  if (!strcmp(key, "host_pipeline")) return &o.host_pipeline;
+  if (!strcmp(key, "host_batch")) return &o.host_batch;
+  if (!strcmp(key, "host_threads")) return &o.host_threads;
+  if (!strcmp(key, "streamed_alloc")) return &o.streamed_alloc;
   return nullptr;
 }
 
@@ -451,11 +551,26 @@ extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value
   if (!strcmp(key, "vec") && !(value == 0 || value == 1 || value == 2 || value == 4))
     return set_err(GSPX_ERR_INVALID, "vec must be 0, 1, 2 or 4");
   *s = value;
+  if (!strcmp(key, "streamed_alloc")) {
+    const bool on = value != 0;
+    (void)hipSetDevice(ctx->device);
+    for (DevMem* m : {&ctx->ws_t, &ctx->ws_r}) {
+      if (!on && m->va_size) {  // currently chunked: drop it, the next call allocates plainly
+        (void)hipStreamSynchronize(ctx->stream);
+        m->release();
+      }
+      m->streamed = on;
+    }
+  }
   return GSPX_OK;
 }
 
 extern "C" int gspx_ctx_get_option(gspx_ctx* ctx, const char* key, int64_t* value) {
   if (!ctx || !value) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (key && !strcmp(key, "retired_va_mb")) {  // read-only: address space of retired workspace ranges, whole process
+    *value = (int64_t)(g_retired_va_bytes.load() >> 20);
+    return GSPX_OK;
+  }
   int64_t* s = option_slot(ctx->opt, key);
   if (!s) return set_err(GSPX_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
   *value = *s;
@@ -2270,6 +2385,8 @@ extern "C" int gspx_newton_filter(gspx_graph* g, double lmax, int K, const doubl
   return GSPX_OK;
 }
 
+#include "gspx_hostpipe.hip.h"
+
 static int check_filter_args(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                              int64_t Nsig, const void* x, void* y, int mode) {
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
@@ -2315,6 +2432,21 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
     if (kernel_ms) *kernel_ms = 0;
     return GSPX_OK;
   }
+  {  // large calls: column batches pipelined over pinned staging buffers (gspx_hostpipe.hip.h)
+    int64_t w = 0;
+    int threads = 1;
+    host_pipeline_shape(ctx->opt, e, g->N, Nsig, Nf + 1, &w, &threads);
+    if (w > 0) {
+      if (!ctx->pipe) ctx->pipe = new HostPipe();
+      replay_reset(ctx);
+      return g->dtype == GSPX_F32
+                 ? filter_host_pipelined<float>(g, lmax, Nf, M, coeffs, Nsig, (const float*)x_host, (float*)y_host,
+                                                mode, w, threads, kernel_ms)
+                 : filter_host_pipelined<double>(g, lmax, Nf, M, coeffs, Nsig, (const double*)x_host,
+                                                 (double*)y_host, mode, w, threads, kernel_ms);
+    }
+    if (ctx->pipe) ctx->pipe->timing[6] = 0;  // the last host call was not pipelined
+  }
   CHK(ctx->io_x.ensure(n_in * e));
   CHK(ctx->io_y.ensure(n_out * e));
   HIPCHK(hipMemcpyAsync(ctx->io_x.p, x_host, n_in * e, hipMemcpyHostToDevice, ctx->stream));
@@ -2323,6 +2455,12 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
                             kernel_ms));
   HIPCHK(hipMemcpyAsync(y_host, ctx->io_y.p, n_out * e, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GSPX_OK;
+}
+
+extern "C" int gspx_last_host_timing(gspx_ctx* ctx, double out[9]) {
+  if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null argument");
+  for (int i = 0; i < 9; ++i) out[i] = ctx->pipe ? ctx->pipe->timing[i] : 0.0;
   return GSPX_OK;
 }
 

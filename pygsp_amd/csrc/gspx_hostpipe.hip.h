@@ -1,0 +1,248 @@
+// gspx_hostpipe.hip.h - the host-pointer entry point (gspx_cheby_filter) as a five-stage pipeline over
+// signal-column batches.  Included by gspx.hip.
+//
+// What a plugin-mode caller of pygsp/filters/filter.py:146-328 hands over is pageable numpy memory: round 2
+// copied the whole input (pageable hipMemcpyAsync: the runtime stages it on one thread), ran the kernels,
+// copied the whole output back - 18 + 11 + 18 ms for the 1M x 64 fp64 headline call.  The columns of a panel
+// are independent (the recurrence never mixes signals), so the call is cut into column batches and the
+// stages overlap on three streams and two small groups of host threads:
+//
+//   pack(b+2)    host threads gather columns [c0, c0+w) of x (row pitch Nsig) into a PINNED compact panel
+//   H2D(b+1)     one contiguous DMA of that panel                                   (stream_in)
+//   kernels(b)   the ordinary device path on the compact panel (ld = w)              (the context's stream)
+//   D2H(b-1)     one contiguous DMA of the compact result into pinned memory        (stream_out)
+//   unpack(b-2)  host threads scatter it into columns [c0, c0+w) of y
+//
+// Two buffers per stage (slot = b & 1).  All hand-offs are host-side (a mutex, a condition variable and four
+// counters), plus ONE device-side dependency: the kernels of batch b wait for the H2D event of batch b on
+// their stream, so the compute thread never blocks on a copy.  The staging buffers are pinned once per
+// context and grow only.  Per column the arithmetic is the device path's own, so the result equals the
+// unpipelined call bit for bit (tests/test_gpu_2_kernels.py::test_host_pipeline_*).
+#pragma once
+
+#include <condition_variable>
+#include <thread>
+
+// (PinMem and HostPipe - the pinned staging buffers, streams and events a context keeps for this - are defined
+// in gspx.hip next to the context itself)
+
+// rows [r0, r1) of a strided column block <-> a compact panel; `rb` bytes per row piece
+static inline void copy_rows(unsigned char* dst, size_t dpitch, const unsigned char* src, size_t spitch, size_t rb,
+                             int64_t r0, int64_t r1) {
+  dst += (size_t)r0 * dpitch;
+  src += (size_t)r0 * spitch;
+  switch (rb) {  // the common piece sizes get an inlined fixed-size copy
+#define GSPX_CR(B)                                                        \
+  case B:                                                                 \
+    for (int64_t r = r0; r < r1; ++r, dst += dpitch, src += spitch) memcpy(dst, src, B); \
+    return;
+    GSPX_CR(32)
+    GSPX_CR(64)
+    GSPX_CR(128)
+    GSPX_CR(256)
+#undef GSPX_CR
+    default:
+      for (int64_t r = r0; r < r1; ++r, dst += dpitch, src += spitch) memcpy(dst, src, rb);
+  }
+}
+
+template <typename T>
+static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs, int64_t Nsig,
+                                 const T* x, T* y, int mode, int64_t w, int nthreads, double* kernel_ms) {
+  gspx_ctx* ctx = g->ctx;
+  HostPipe& hp = *ctx->pipe;
+  CHK(hp.init());
+  const int64_t N = g->N;
+  const bool analysis = mode == GSPX_ANALYSIS;
+  const int in_planes = analysis ? 1 : Nf, out_planes = analysis ? Nf : 1;
+  const int nb = (int)((Nsig + w - 1) / w);
+  const size_t in_cap = (size_t)in_planes * N * w * sizeof(T), out_cap = (size_t)out_planes * N * w * sizeof(T);
+  for (int s = 0; s < 2; ++s) {
+    CHK(hp.pin_in[s].ensure(in_cap));
+    CHK(hp.pin_out[s].ensure(out_cap));
+    CHK(hp.dx[s].ensure(in_cap));
+    CHK(hp.dy[s].ensure(out_cap));
+  }
+  const int P = std::max(1, nthreads), Q = std::max(1, nthreads);
+  const auto wall0 = std::chrono::steady_clock::now();
+
+  std::mutex mu;
+  std::condition_variable cv;
+  int issued = 0, computed = 0, shipped = 0, unpacked = 0;  // batches past each stage
+  std::vector<int> pack_arrived((size_t)nb, 0), unpack_arrived((size_t)nb, 0);
+  int err = GSPX_OK;
+  std::string err_msg;
+  auto fail = [&](int rc) {  // called with g_err set on the calling thread
+    std::lock_guard<std::mutex> lock(mu);
+    if (err == GSPX_OK) {
+      err = rc;
+      err_msg = g_err;
+    }
+    cv.notify_all();
+  };
+  auto wait_for = [&](auto pred) {  // false: the pipeline failed elsewhere
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [&] { return err != GSPX_OK || pred(); });
+    return err == GSPX_OK;
+  };
+  auto hipfail = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return false;
+    fail(set_err(GSPX_ERR_HIP, "%s failed in the host pipeline: %s", what, hipGetErrorString(e)));
+    return true;
+  };
+  std::vector<double> pack_ms((size_t)P, 0.0), unpack_ms((size_t)Q, 0.0);
+  double h2d_ms = 0, d2h_ms = 0;
+  auto width_of = [&](int b) { return std::min<int64_t>(w, Nsig - (int64_t)b * w); };
+
+  auto pack_worker = [&](int p) {
+    const int64_t r0 = N * p / P, r1 = N * (p + 1) / P;
+    for (int b = 0; b < nb; ++b) {
+      const int s = b & 1;
+      if (!wait_for([&] { return computed >= b - 1; })) return;  // slot s: batch b-2 consumed
+      const auto t0 = std::chrono::steady_clock::now();
+      const int64_t wl = width_of(b);
+      for (int pl = 0; pl < in_planes; ++pl)
+        copy_rows((unsigned char*)hp.pin_in[s].p + (size_t)pl * N * wl * sizeof(T), (size_t)wl * sizeof(T),
+                  (const unsigned char*)(x + (size_t)pl * N * Nsig + (size_t)b * w), (size_t)Nsig * sizeof(T),
+                  (size_t)wl * sizeof(T), r0, r1);
+      pack_ms[(size_t)p] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      bool last;
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        last = ++pack_arrived[(size_t)b] == P;
+      }
+      if (last) {  // the panel is complete: one contiguous DMA
+        if (hipfail(hipSetDevice(ctx->device), "hipSetDevice")) return;
+        if (b >= 2) {  // the slot's previous DMA (batch b-2) is complete: its kernels have run
+          float t = 0;
+          if (hipEventElapsedTime(&t, hp.t_in[s][0], hp.t_in[s][1]) == hipSuccess) h2d_ms += t;
+        }
+        if (hipfail(hipEventRecord(hp.t_in[s][0], hp.stream_in), "hipEventRecord")) return;
+        if (hipfail(hipMemcpyAsync(hp.dx[s].p, hp.pin_in[s].p, (size_t)in_planes * N * wl * sizeof(T),
+                                   hipMemcpyHostToDevice, hp.stream_in), "hipMemcpyAsync (H2D)")) return;
+        if (hipfail(hipEventRecord(hp.t_in[s][1], hp.stream_in), "hipEventRecord")) return;
+        if (hipfail(hipEventRecord(hp.h2d_ev[s], hp.stream_in), "hipEventRecord")) return;
+        std::lock_guard<std::mutex> lock(mu);
+        issued = b + 1;
+        cv.notify_all();
+      }
+    }
+  };
+  auto shipper = [&]() {
+    if (hipfail(hipSetDevice(ctx->device), "hipSetDevice")) return;
+    for (int b = 0; b < nb; ++b) {
+      const int s = b & 1;
+      if (!wait_for([&] { return computed >= b + 1 && unpacked >= b - 1; })) return;
+      const int64_t wl = width_of(b);
+      if (hipfail(hipEventRecord(hp.t_out[0], hp.stream_out), "hipEventRecord")) return;
+      if (hipfail(hipMemcpyAsync(hp.pin_out[s].p, hp.dy[s].p, (size_t)out_planes * N * wl * sizeof(T),
+                                 hipMemcpyDeviceToHost, hp.stream_out), "hipMemcpyAsync (D2H)")) return;
+      if (hipfail(hipEventRecord(hp.t_out[1], hp.stream_out), "hipEventRecord")) return;
+      if (hipfail(hipStreamSynchronize(hp.stream_out), "hipStreamSynchronize")) return;
+      float t = 0;
+      if (hipEventElapsedTime(&t, hp.t_out[0], hp.t_out[1]) == hipSuccess) d2h_ms += t;
+      std::lock_guard<std::mutex> lock(mu);
+      shipped = b + 1;
+      cv.notify_all();
+    }
+  };
+  auto unpack_worker = [&](int q) {
+    const int64_t r0 = N * q / Q, r1 = N * (q + 1) / Q;
+    for (int b = 0; b < nb; ++b) {
+      const int s = b & 1;
+      if (!wait_for([&] { return shipped >= b + 1; })) return;
+      const auto t0 = std::chrono::steady_clock::now();
+      const int64_t wl = width_of(b);
+      for (int pl = 0; pl < out_planes; ++pl)
+        copy_rows((unsigned char*)(y + (size_t)pl * N * Nsig + (size_t)b * w), (size_t)Nsig * sizeof(T),
+                  (const unsigned char*)hp.pin_out[s].p + (size_t)pl * N * wl * sizeof(T), (size_t)wl * sizeof(T),
+                  (size_t)wl * sizeof(T), r0, r1);
+      unpack_ms[(size_t)q] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      std::lock_guard<std::mutex> lock(mu);
+      if (++unpack_arrived[(size_t)b] == Q) {
+        unpacked = b + 1;
+        cv.notify_all();
+      }
+    }
+  };
+
+  std::vector<std::thread> threads;
+  threads.reserve((size_t)P + Q + 1);
+  try {
+    for (int p = 0; p < P; ++p) threads.emplace_back(pack_worker, p);
+    threads.emplace_back(shipper);
+    for (int q = 0; q < Q; ++q) threads.emplace_back(unpack_worker, q);
+  } catch (...) {
+    fail(set_err(GSPX_ERR_HIP, "could not start the host pipeline threads"));
+  }
+
+  // this thread: the kernels, batch by batch
+  double k_ms = 0, tm[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < nb; ++b) {
+    const int s = b & 1;
+    if (!wait_for([&] { return issued >= b + 1 && shipped >= b - 1; })) break;
+    if (hipfail(hipStreamWaitEvent(ctx->stream, hp.h2d_ev[s], 0), "hipStreamWaitEvent")) break;
+    const int rc = filter_dev_t<T>(g, lmax, Nf, M, coeffs, width_of(b), (const T*)hp.dx[s].p, (T*)hp.dy[s].p, mode);
+    if (rc != GSPX_OK) {
+      fail(rc);
+      break;
+    }
+    k_ms += ctx->timing[0];
+    for (int i = 0; i < 5; ++i) tm[i] += ctx->timing[i];
+    std::lock_guard<std::mutex> lock(mu);
+    computed = b + 1;
+    cv.notify_all();
+  }
+  for (auto& t : threads) t.join();
+  (void)hipSetDevice(ctx->device);
+  if (err != GSPX_OK) {
+    (void)hipStreamSynchronize(hp.stream_in);
+    (void)hipStreamSynchronize(hp.stream_out);
+    (void)hipStreamSynchronize(ctx->stream);
+    g_err = err_msg;
+    return err;
+  }
+  for (int b = std::max(0, nb - 2); b < nb; ++b) {  // the DMAs whose slot was not reused
+    float t = 0;
+    if (hipEventElapsedTime(&t, hp.t_in[b & 1][0], hp.t_in[b & 1][1]) == hipSuccess) h2d_ms += t;
+  }
+  (void)hipGetLastError();
+  for (int i = 0; i < 5; ++i) ctx->timing[i] = tm[i];
+  hp.timing[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  hp.timing[1] = *std::max_element(pack_ms.begin(), pack_ms.end());
+  hp.timing[2] = h2d_ms;
+  hp.timing[3] = k_ms;
+  hp.timing[4] = d2h_ms;
+  hp.timing[5] = *std::max_element(unpack_ms.begin(), unpack_ms.end());
+  hp.timing[6] = nb;
+  hp.timing[7] = (double)w;
+  hp.timing[8] = P;
+  if (kernel_ms) *kernel_ms = k_ms;
+  return GSPX_OK;
+}
+
+// batch width and threads of a pipelined call; w == 0: run the one-shot path
+static void host_pipeline_shape(const Options& opt, size_t elt, int64_t N, int64_t Nsig, int planes_total, int64_t* w_out,
+                                int* threads_out) {
+  *w_out = 0;
+  if (!opt.host_pipeline) return;
+  const int64_t wmin = (int64_t)(64 / elt);  // 64-byte row pieces at least
+  int64_t w = opt.host_batch > 0 ? opt.host_batch : 0;
+  if (w == 0) {
+    // at least four batches when the panel allows (pipeline fill and drain cost one batch each way), 16 fp64 /
+    // 32 fp32 columns at most: wider batches run the kernels nearer their best rate (the matrix is streamed
+    // once per batch) but fill and drain slower
+    w = std::min<int64_t>(128 / (int64_t)elt, std::max<int64_t>(wmin, (Nsig / 4) / wmin * wmin));
+  }
+  w = std::max<int64_t>(1, std::min<int64_t>(w, Nsig));
+  const size_t total = (size_t)N * (size_t)Nsig * elt * (size_t)planes_total;
+  if (opt.host_pipeline == 1 && (Nsig < 2 * w || total < ((size_t)48 << 20))) return;  // too small to pay for threads
+  if (Nsig <= w) return;
+  int t = (int)opt.host_threads;
+  if (t <= 0) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    t = (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 4));
+  }
+  *w_out = w;
+  *threads_out = std::min(t, 64);
+}

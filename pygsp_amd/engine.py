@@ -49,6 +49,17 @@ class Context:
         return {"total_ms": out[0], "steps_ms": out[1], "step_launches": int(out[2]),
                 "permute_ms": out[3], "combine_ms": out[4]}
 
+    def last_host_timing(self):
+        """Stage times (ms) of the last host-array filter call on this context (gspx_last_host_timing); None
+        when that call was not pipelined."""
+        out = (ctypes.c_double * 9)()
+        _capi.check(_capi.load().gspx_last_host_timing(self._h, out))
+        if out[6] == 0:
+            return None
+        return {"wall_ms": out[0], "pack_ms": out[1], "h2d_ms": out[2], "kernel_ms": out[3], "d2h_ms": out[4],
+                "unpack_ms": out[5], "batches": int(out[6]), "signals_per_batch": int(out[7]),
+                "host_threads_per_direction": int(out[8])}
+
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 

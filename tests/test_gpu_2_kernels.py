@@ -469,3 +469,61 @@ def test_compute_frame_in_device_panels():
     # localize(i) is sqrt(N) times column i of every block (filter.py:389-391)
     loc = bank.localize(77, order=20)
     assert rel_err(loc, np.sqrt(G.N) * blocks[:, :, 77].T) < 1e-11
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_host_pipeline_equals_one_shot_call(ctx, dtype):
+    """gspx_cheby_filter with host arrays (what Filter.filter of the reference hands over, filter.py:146-328):
+    the pipelined form - column batches packed into pinned staging by host threads, H2D / kernels / D2H of
+    successive batches overlapping on three streams - returns exactly the bytes of the one-shot form (one copy in,
+    the kernels, one copy out), for every batch width (ragged last batch included), thread count, filterbanks
+    and synthesis."""
+    G = graphs.Sensor(60000, seed=4, compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    dev, lmax = G.device_graph(), float(G.lmax)
+    rng = np.random.default_rng(6)
+    c1 = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, 20), m=12))
+    c3 = np.array(filters.compute_cheby_coeff(filters.MexicanHat(G, Nf=3), m=9))
+    x = rng.standard_normal((G.N, 56)).astype(dtype)
+    s3 = rng.standard_normal((3, G.N, 24)).astype(dtype)
+    try:
+        ctx.set_option("host_pipeline", 0)
+        y1, _ = dev.cheby_filter(c1, x, lmax)
+        y3, _ = dev.cheby_filter(c3, x, lmax)
+        ys, _ = dev.cheby_filter(c3, s3, lmax, _capi.SYNTHESIS)
+        assert ctx.last_host_timing() is None
+        ref = orc.cheby_op(orc.laplacian(G.W), lmax, c1[0], x[:, :3].astype(np.float64))
+        assert rel_err(y1[0][:, :3], ref) < TOL[np.dtype(dtype)] * 10
+        ctx.set_option("host_pipeline", 2)
+        for batch, threads in ((8, 1), (16, 3), (24, 2), (0, 0), (4, 5)):
+            ctx.set_option("host_batch", batch)
+            ctx.set_option("host_threads", threads)
+            p1, ms = dev.cheby_filter(c1, x, lmax)
+            tm = ctx.last_host_timing()
+            assert tm is not None and tm["batches"] >= 2 and ms > 0 and tm["kernel_ms"] == pytest.approx(ms)
+            if batch:
+                assert tm["signals_per_batch"] == batch and tm["batches"] == -(-56 // batch)
+            # every batch of at least 32-byte rows runs the kernel family of the one-shot call (same order of
+            # operations per column): identical bytes.  16-byte rows (4 fp32 signals) go to the sub-wave kernel,
+            # which sums a row's entries in another order: equal to rounding.
+            same = (lambda a, b: np.array_equal(a, b)) if batch * np.dtype(dtype).itemsize >= 32 or batch == 0 else \
+                (lambda a, b: rel_err(a, b) < TOL[np.dtype(dtype)])
+            assert same(p1, y1), (batch, threads)
+            assert same(dev.cheby_filter(c3, x, lmax)[0], y3), (batch, threads)
+            assert same(dev.cheby_filter(c3, s3, lmax, _capi.SYNTHESIS)[0], ys), (batch, threads)
+        # auto mode: a call of this size (25 MB in + out at fp64) stays on the one-shot path, a large one pipelines
+        ctx.set_option("host_pipeline", 1)
+        ctx.set_option("host_batch", 0)
+        ctx.set_option("host_threads", 0)
+        dev.cheby_filter(c1, x[:, :8].copy(), lmax)
+        assert ctx.last_host_timing() is None
+        big = rng.standard_normal((G.N, 128)).astype(dtype)
+        yb, _ = dev.cheby_filter(c1, big, lmax)
+        tm = ctx.last_host_timing()
+        if big.nbytes * 2 >= (48 << 20):
+            assert tm is not None and tm["batches"] >= 4
+        ctx.set_option("host_pipeline", 0)
+        assert np.array_equal(dev.cheby_filter(c1, big, lmax)[0], yb)
+    finally:
+        for k, v in (("host_pipeline", 1), ("host_batch", 0), ("host_threads", 0)):
+            ctx.set_option(k, v)

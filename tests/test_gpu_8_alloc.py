@@ -104,3 +104,44 @@ def test_two_contexts_interleaved():
             dev.destroy()
         for c in ctxs:
             c.close()
+
+
+def test_plain_allocation_switch_and_retired_address_space():
+    """The safe mode of the workspaces: option "streamed_alloc" = 0 - or GSPX_STREAMED_ALLOC=0
+    before the context exists - makes them plain hipMalloc allocations; switching it off on a live context
+    drops a chunk-mapped workspace; results are the same either way; "retired_va_mb" counts the address space
+    the chunked mode has retired in this process."""
+    import os
+    W, coords = graphs.sensor_weights(60000, k=6, seed=6)
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    rng = np.random.default_rng(4)
+    ctx = engine.Context(0)
+    dev = engine.DeviceGraph.from_w(W, dtype=np.float64, ctx=ctx)
+    try:
+        assert ctx.get_option("streamed_alloc") == 1
+        before = ctx.get_option("retired_va_mb")
+        _check(dev, L, lmax, rng, 100, 7, 1)  # 48 MB panels: chunk-mapped
+        ctx.set_option("streamed_alloc", 0)  # drops (retires) the mapped ranges
+        assert ctx.get_option("retired_va_mb") >= before + 2048  # two ranges of at least 1 GiB each
+        mid = ctx.get_option("retired_va_mb")
+        for nsig in (100, 200, 64):
+            _check(dev, L, lmax, rng, nsig, 7, 1)
+        assert ctx.get_option("retired_va_mb") == mid  # plain allocations retire nothing, also when they grow
+        ctx.set_option("streamed_alloc", 1)
+        _check(dev, L, lmax, rng, 100, 7, 1)
+    finally:
+        dev.destroy()
+        ctx.close()
+    os.environ["GSPX_STREAMED_ALLOC"] = "0"
+    try:
+        ctx = engine.Context(0)
+        assert ctx.get_option("streamed_alloc") == 0
+        dev = engine.DeviceGraph.from_w(W, dtype=np.float64, ctx=ctx)
+        mid = ctx.get_option("retired_va_mb")
+        _check(dev, L, lmax, rng, 150, 7, 1)
+        dev.destroy()
+        ctx.close()
+        assert engine.default_context(0).get_option("retired_va_mb") == mid
+    finally:
+        del os.environ["GSPX_STREAMED_ALLOC"]
