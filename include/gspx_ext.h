@@ -157,6 +157,16 @@ int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);
 /* Calibration: read-only GB/s of a `bytes`-sized buffer streamed `passes` times in one launch. */
 int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
 
+/* Calibration for graphs WITHOUT vertex locality (BASELINE configs 2, 3: Erdos-Renyi, block model): the rate
+ * of random row gathers, measured with nothing else in the way.  n_gathers rows of row_bytes (64 / 128 / 256 /
+ * 512; 16 bytes per lane, the step kernels' lane layout) are fetched from a panel of panel_rows rows by 32-bit
+ * indices, in_flight (2 / 4 / 8 / 16) independent gathers per lane before the first use; no matrix values, no
+ * FMA, no panel writes.  blocks == 1: indices uniform over the panel (ER); blocks > 1: the panel is cut into
+ * that many row ranges and a gather lands in the range of the row it is issued "from" with probability p_intra
+ * (SBM), each XCD walking a contiguous eighth of the stream.  ms: per launch; gbps: row bytes per second. */
+int gspx_bench_gather(gspx_ctx* ctx, int64_t panel_rows, int row_bytes, int64_t n_gathers, int in_flight,
+                      int blocks, double p_intra, int workgroups_per_cu, int iters, double* ms, double* gbps);
+
 #ifdef __cplusplus
 }
 #endif

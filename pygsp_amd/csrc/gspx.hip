@@ -2714,5 +2714,6 @@ extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double*
   return GSPX_OK;
 }
 
+#include "gspx_calib.hip.h"
 #include "gspx_ops.hip.h"
 #include "gspx_knn.hip.h"

@@ -75,6 +75,15 @@ class Context:
         _capi.check(_capi.load().gspx_bench_read(self._h, int(nbytes), int(passes), ctypes.byref(v)))
         return v.value
 
+    def bench_gather(self, panel_rows, row_bytes, n_gathers, in_flight=8, blocks=1, p_intra=0.0, workgroups_per_cu=8,
+                     iters=5):
+        """Rate of random row gathers on this device (gspx_bench_gather): (ms per launch, GB/s of row bytes)."""
+        ms, gb = ctypes.c_double(0), ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_bench_gather(self._h, int(panel_rows), int(row_bytes), int(n_gathers),
+                                                   int(in_flight), int(blocks), float(p_intra), int(workgroups_per_cu),
+                                                   int(iters), ctypes.byref(ms), ctypes.byref(gb)))
+        return ms.value, gb.value
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         buf = DeviceBuffer(self, arr.nbytes)
