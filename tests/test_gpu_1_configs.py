@@ -102,6 +102,61 @@ def test_sbm_normalized_isolated_rule():
     assert rel_err(y[:, :3], ref) < 1e-11
 
 
+def test_config2_full_size_parity(ctx):
+    """BASELINE.json configs[2] at FULL size: ErdosRenyi(N=1e6, p=1e-5) (~10M stored entries, isolated vertices
+    occur), MexicanHat x 6, order 50, 64 signals, fp32 engine, device resident; two oracle columns (fp64) at a
+    tenth of the north star's 1e-3 bar, and the constant-signal identity p_f(L) 1 = p_f(0) 1 on a third."""
+    N, nsig, K = 1000000, 64, 50
+    G = graphs.ErdosRenyi(N, p=10.0 / N, seed=0, compute_dtype=np.float32)
+    G.estimate_lmax("bounds")
+    bank = filters.MexicanHat(G, Nf=6)
+    c = np.array(filters.compute_cheby_coeff(bank, m=K))
+    x = np.random.default_rng(0).standard_normal((N, nsig)).astype(np.float32)
+    x[:, 5] = 1.0
+    dev = G.device_graph()
+    bx, by = ctx.upload(x), ctx.alloc(6 * x.nbytes)
+    try:
+        dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, float(G.lmax))
+        y = by.download((6, N, nsig), np.float32)
+    finally:
+        bx.free()
+        by.free()
+    cols = [0, 63]
+    L = orc.laplacian(G.W.astype(np.float64))
+    ref = orc.cheby_op(L, float(G.lmax), c, x[:, cols].astype(np.float64)).reshape(6, N, 2)
+    assert rel_err(y[:, :, cols], ref) < 1e-3 * 1e-1
+    for f in range(6):
+        gain = _constant_signal_gain(c[f])
+        assert np.max(np.abs(y[f][:, 5] - gain)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_config3_full_size_parity(ctx, dtype):
+    """BASELINE.json configs[3] at FULL size: StochasticBlockModel(N=2e6, k=16, p=9.6e-5, q=2.13e-6), normalized
+    Laplacian (isolated-vertex rule included), Heat order 30, 16 signals; two oracle columns at a tenth of the
+    north star's bar (1e-5 fp64 / 1e-3 fp32)."""
+    N, nsig, K = 2000000, 16, 30
+    G = graphs.StochasticBlockModel(N, k=16, p=9.6e-5, q=2.13e-6, seed=0, lap_type="normalized", compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    assert G.lmax == 2
+    c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, 10), m=K))
+    x = np.random.default_rng(0).standard_normal((N, nsig)).astype(dtype)
+    dev = G.device_graph()
+    bx, by = ctx.upload(x), ctx.alloc(x.nbytes)
+    try:
+        dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, 2.0)
+        y = by.download((N, nsig), dtype)
+    finally:
+        bx.free()
+        by.free()
+    cols = [0, 15]
+    L = orc.laplacian(G.W.astype(np.float64), "normalized")
+    ref = orc.cheby_op(L, 2.0, c[0], x[:, cols].astype(np.float64))
+    assert rel_err(y[:, cols], ref) < (1e-5 if dtype == np.float64 else 1e-3) * 1e-1
+    if dtype == np.float64:
+        assert abs(G.L - L).max() < 1e-14 and G.L.nnz == L.nnz
+
+
 def test_panel_beyond_the_2gib_descriptor_window(ctx):
     """A signal panel larger than the 2 GiB window of a buffer descriptor (600k vertices x 500 fp64 signals =
     2.4 GB in, 2.4 GB out) is split into column batches inside the call; every batch must land in its own

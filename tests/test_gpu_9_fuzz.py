@@ -82,3 +82,26 @@ def _run(cases, rng, ctx):
             if not err < tol * 100:
                 raise AssertionError(("newton", case, dict(N=N, lap=lap, nsig=nsig, order=order, tiles=tiles, opts=opts, err=err)))
         dev.destroy()
+
+
+def test_soak_slice_of_the_tile_kernel():
+    """A two-minute slice of tools/soak.py: the LDS-staged recurrence kernel against oracle columns over panel
+    widths x dtypes x orders x repeats on Hilbert-ordered sensor graphs.  (The kernel's tile-DMA race of round 2
+    had passed 120 functional tests: rare events need repetition, so a slice of the soak lives in the suite.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak
+    runs, bad = soak.soak_kernel(rounds=3, log=lambda *a: None, **soak.SLICE)
+    assert runs == 2 * 2 * 6 * 3 * 3 and bad == 0
+
+
+def test_soak_slice_of_the_host_pipeline():
+    """Pipelined host-pointer calls (threads + three streams) against their one-shot form, bit for bit, over random
+    batch widths, thread counts, panel widths, filterbanks and synthesis."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak
+    runs, bad = soak.soak_host_pipeline(calls=60, log=lambda *a: None)
+    assert runs == 60 and bad == 0
