@@ -331,7 +331,7 @@ struct Options {
   int64_t host_pipeline = 1;    // gspx_cheby_filter (host pointers): 1 column batches pipelined over pinned staging when the
                                 // call is large enough, 2 always, 0 one pageable copy in, the kernels, one out
   int64_t host_batch = 0;       // signals per pipelined batch (0: auto)
-  int64_t host_threads = 0;     // host threads packing / unpacking, per direction (0: auto, at most 8)
+  int64_t host_threads = 0;     // host threads packing / unpacking, per direction (0: auto, a quarter of the cores, at most 16)
   int64_t streamed_alloc = 1;   // 1: the two streamed workspaces are assembled from scrambled 2 MB chunks (HIP
                                 // virtual-memory API; +2..8 % bandwidth); 0: plain hipMalloc (the safe mode on an
                                 // untested ROCm: no address range is ever reserved or retired)
@@ -2433,17 +2433,17 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
     return GSPX_OK;
   }
   {  // large calls: column batches pipelined over pinned staging buffers (gspx_hostpipe.hip.h)
-    int64_t w = 0;
+    std::vector<int64_t> widths;
     int threads = 1;
-    host_pipeline_shape(ctx->opt, e, g->N, Nsig, Nf + 1, &w, &threads);
-    if (w > 0) {
+    host_pipeline_shape(ctx->opt, e, g->N, Nsig, Nf + 1, &widths, &threads);
+    if (widths.size() >= 2) {
       if (!ctx->pipe) ctx->pipe = new HostPipe();
       replay_reset(ctx);
       return g->dtype == GSPX_F32
                  ? filter_host_pipelined<float>(g, lmax, Nf, M, coeffs, Nsig, (const float*)x_host, (float*)y_host,
-                                                mode, w, threads, kernel_ms)
+                                                mode, widths, threads, kernel_ms)
                  : filter_host_pipelined<double>(g, lmax, Nf, M, coeffs, Nsig, (const double*)x_host,
-                                                 (double*)y_host, mode, w, threads, kernel_ms);
+                                                 (double*)y_host, mode, widths, threads, kernel_ms);
     }
     if (ctx->pipe) ctx->pipe->timing[6] = 0;  // the last host call was not pipelined
   }

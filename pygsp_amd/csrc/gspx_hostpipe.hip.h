@@ -20,6 +20,8 @@
 // unpipelined call bit for bit (tests/test_gpu_2_kernels.py::test_host_pipeline_*).
 #pragma once
 
+#include <sys/mman.h>
+
 #include <condition_variable>
 #include <thread>
 
@@ -46,16 +48,28 @@ static inline void copy_rows(unsigned char* dst, size_t dpitch, const unsigned c
   }
 }
 
+// `widths`: the signal columns of each batch, in order (they add up to Nsig)
 template <typename T>
 static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs, int64_t Nsig,
-                                 const T* x, T* y, int mode, int64_t w, int nthreads, double* kernel_ms) {
+                                 const T* x, T* y, int mode, const std::vector<int64_t>& widths, int nthreads,
+                                 double* kernel_ms) {
   gspx_ctx* ctx = g->ctx;
   HostPipe& hp = *ctx->pipe;
   CHK(hp.init());
   const int64_t N = g->N;
   const bool analysis = mode == GSPX_ANALYSIS;
   const int in_planes = analysis ? 1 : Nf, out_planes = analysis ? Nf : 1;
-  const int nb = (int)((Nsig + w - 1) / w);
+  const int nb = (int)widths.size();
+  std::vector<int64_t> col0((size_t)nb, 0);
+  for (int b = 1; b < nb; ++b) col0[(size_t)b] = col0[(size_t)b - 1] + widths[(size_t)b - 1];
+  const int64_t w = *std::max_element(widths.begin(), widths.end());
+  {  // the result array is usually fresh from the allocator (mmap): ask for huge pages before the unpacking
+     // threads fault it in (131k page faults of 4 KB for a 512 MB result cost them several milliseconds)
+    const size_t bytes = (size_t)out_planes * N * Nsig * sizeof(T);
+    const uintptr_t lo = ((uintptr_t)y + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+    const uintptr_t hi = ((uintptr_t)y + bytes) & ~(((uintptr_t)2 << 20) - 1);
+    if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+  }
   const size_t in_cap = (size_t)in_planes * N * w * sizeof(T), out_cap = (size_t)out_planes * N * w * sizeof(T);
   for (int s = 0; s < 2; ++s) {
     CHK(hp.pin_in[s].ensure(in_cap));
@@ -92,7 +106,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
   };
   std::vector<double> pack_ms((size_t)P, 0.0), unpack_ms((size_t)Q, 0.0);
   double h2d_ms = 0, d2h_ms = 0;
-  auto width_of = [&](int b) { return std::min<int64_t>(w, Nsig - (int64_t)b * w); };
+  auto width_of = [&](int b) { return widths[(size_t)b]; };
 
   auto pack_worker = [&](int p) {
     const int64_t r0 = N * p / P, r1 = N * (p + 1) / P;
@@ -103,7 +117,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
       const int64_t wl = width_of(b);
       for (int pl = 0; pl < in_planes; ++pl)
         copy_rows((unsigned char*)hp.pin_in[s].p + (size_t)pl * N * wl * sizeof(T), (size_t)wl * sizeof(T),
-                  (const unsigned char*)(x + (size_t)pl * N * Nsig + (size_t)b * w), (size_t)Nsig * sizeof(T),
+                  (const unsigned char*)(x + (size_t)pl * N * Nsig + (size_t)col0[(size_t)b]), (size_t)Nsig * sizeof(T),
                   (size_t)wl * sizeof(T), r0, r1);
       pack_ms[(size_t)p] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       bool last;
@@ -154,7 +168,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
       const auto t0 = std::chrono::steady_clock::now();
       const int64_t wl = width_of(b);
       for (int pl = 0; pl < out_planes; ++pl)
-        copy_rows((unsigned char*)(y + (size_t)pl * N * Nsig + (size_t)b * w), (size_t)Nsig * sizeof(T),
+        copy_rows((unsigned char*)(y + (size_t)pl * N * Nsig + (size_t)col0[(size_t)b]), (size_t)Nsig * sizeof(T),
                   (const unsigned char*)hp.pin_out[s].p + (size_t)pl * N * wl * sizeof(T), (size_t)wl * sizeof(T),
                   (size_t)wl * sizeof(T), r0, r1);
       unpack_ms[(size_t)q] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -221,28 +235,41 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
   return GSPX_OK;
 }
 
-// batch width and threads of a pipelined call; w == 0: run the one-shot path
-static void host_pipeline_shape(const Options& opt, size_t elt, int64_t N, int64_t Nsig, int planes_total, int64_t* w_out,
-                                int* threads_out) {
-  *w_out = 0;
+// batches and threads of a pipelined call; no batches: run the one-shot path
+static void host_pipeline_shape(const Options& opt, size_t elt, int64_t N, int64_t Nsig, int planes_total,
+                                std::vector<int64_t>* widths, int* threads_out) {
+  widths->clear();
   if (!opt.host_pipeline) return;
-  const int64_t wmin = (int64_t)(64 / elt);  // 64-byte row pieces at least
-  int64_t w = opt.host_batch > 0 ? opt.host_batch : 0;
-  if (w == 0) {
-    // at least four batches when the panel allows (pipeline fill and drain cost one batch each way), 16 fp64 /
-    // 32 fp32 columns at most: wider batches run the kernels nearer their best rate (the matrix is streamed
-    // once per batch) but fill and drain slower
-    w = std::min<int64_t>(128 / (int64_t)elt, std::max<int64_t>(wmin, (Nsig / 4) / wmin * wmin));
-  }
-  w = std::max<int64_t>(1, std::min<int64_t>(w, Nsig));
   const size_t total = (size_t)N * (size_t)Nsig * elt * (size_t)planes_total;
-  if (opt.host_pipeline == 1 && (Nsig < 2 * w || total < ((size_t)48 << 20))) return;  // too small to pay for threads
-  if (Nsig <= w) return;
+  if (opt.host_pipeline == 1 && total < ((size_t)48 << 20)) return;  // too small to pay for the threads
+  if (opt.host_batch > 0) {  // uniform batches of the given width (the last one may be narrower)
+    const int64_t w = std::min<int64_t>(opt.host_batch, Nsig);
+    if (Nsig <= w) return;
+    for (int64_t c = 0; c < Nsig; c += w) widths->push_back(std::min<int64_t>(w, Nsig - c));
+  } else {
+    // The call's critical path is: fill (pack + H2D of the first batch), the kernels of all batches, drain (D2H +
+    // unpack of the last batch).  Narrow first and last batches keep fill and drain short; wide middle batches
+    // run the kernels near their best rate (the matrix is streamed once per batch).  In 64-byte row units:
+    // edge batches of about Nsig / 8, middle batches of at most 3 x that (24 fp64 / 48 fp32 signals at 64).
+    const int64_t unit = (int64_t)(64 / elt);
+    if (Nsig < 4 * unit) return;
+    const int64_t edge = std::max<int64_t>(unit, (Nsig / 8) / unit * unit);
+    const int64_t mid_cap = std::min<int64_t>(3 * edge, (int64_t)(256 / elt));
+    int64_t rest = Nsig - 2 * edge;
+    widths->push_back(edge);
+    const int64_t nmid = std::max<int64_t>(1, (rest + mid_cap - 1) / mid_cap);
+    for (int64_t i = 0; i < nmid; ++i) {
+      int64_t wm = ((rest / (nmid - i)) + unit - 1) / unit * unit;
+      wm = std::min(wm, rest);
+      if (wm > 0) widths->push_back(wm);
+      rest -= wm;
+    }
+    widths->push_back(edge);
+  }
   int t = (int)opt.host_threads;
   if (t <= 0) {
     const unsigned hc = std::thread::hardware_concurrency();
-    t = (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 4));
+    t = (int)std::min<unsigned>(16, std::max<unsigned>(1, hc / 4));
   }
-  *w_out = w;
   *threads_out = std::min(t, 64);
 }

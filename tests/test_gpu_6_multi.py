@@ -29,6 +29,24 @@ def _flush_c_stdio():
     ctypes.CDLL(None).fflush(None)
 
 
+def _torchrun_bench(nproc, bench_args, env, timeout=900):
+    """bench.py under torch.distributed.run on a free local port; a port that was taken between probing and
+    binding (EADDRINUSE: other sockets of this very test session) is retried on another one."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = None
+    for _ in range(4):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py")] + bench_args
+        res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+        if res.returncode == 0 or "EADDRINUSE" not in res.stderr:
+            break
+    return res
+
+
 def test_gather_and_batch_across_contexts(ctx):
     """gspx_gather: buffers of several contexts concatenated on the root (single-process form of the
     final gather; two contexts on this box's one GPU), and engine.filter_batch on top of it."""
@@ -127,20 +145,12 @@ def test_two_ranks_on_this_gpu_through_bench():
     N > 1 path - independent graph per rank, barrier-bracketed timing, MAX over ranks, final gather - runs
     end to end with libgspx outputs; rank 0 prints one JSON line with n_gpus = 2 and a gather time."""
     pytest.importorskip("torch")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # GSPX_BENCH_LIB_GATHER=force: the in-library RCCL gather is attempted although RCCL must refuse two ranks
     # on one device - the attempt (id exchange, communicator creation under the watchdog), the agreement of the
     # ranks on its failure and the fall-back to the launcher's gather all run
     env = dict(os.environ, GSPX_ALL_RANKS_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GSPX_BENCH_LIB_GATHER="force")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--vertices", "100000", "--nsig", "16",
-           "--backend", "gloo", "--no-newton"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    res = _torchrun_bench(2, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--vertices", "100000", "--nsig", "16",
+                              "--backend", "gloo", "--no-newton"], env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
@@ -208,16 +218,9 @@ def test_comm_gather_real_peers():
     if n < 2:
         pytest.skip("one GPU visible")
     pytest.importorskip("torch")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", str(n), "--steps", "2", "--warmup", "1", "--vertices", "200000", "--nsig", "16", "--no-newton"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    res = _torchrun_bench(n, ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--vertices", "200000", "--nsig", "16",
+                              "--no-newton"], env, timeout=1200)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == n and "gspx_comm_gather" in out["gather_impl"]

@@ -16,7 +16,7 @@ try:
     print("value %.4g"%b["value"], "ms/step %.3f"%b["ms_per_step"], {k:(round(v,4) if isinstance(v,float) else v) for k,v in b["roofline"].items() if k in ("achieved","frac","traffic","avg_launch_ms")})
     print("e2e", b.get("end_to_end_host_arrays"))
     for c in b.get("configs", []):
-        print(c["key"], c["dtype"], "ms %.3f"%c["ms"], "frac %.3f"%c["roofline"]["frac"], "gather", c.get("roofline_gather") and {k: c["roofline_gather"][k] for k in ("achieved","peak","frac","pure_gather_ms","serial_model_ms","step_ms")})
+        print(c["key"], c["dtype"], "ms %.3f"%c["ms"], "frac %.3f"%c["roofline"]["frac"], "gather", c.get("roofline_gather") and {k: c["roofline_gather"][k] for k in ("achieved","peak","frac","bound_ms","step_ms")})
 except Exception as e:
     print("bench failed", e)
 try:
