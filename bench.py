@@ -284,7 +284,7 @@ def run_config(key, workload, G, bank, nsig, K, dtype, ctx, oracle_cols=2, reps=
         "gather": {"bytes_per_step": gather_bytes, "rate_GBps": gather_bytes / (step_ms * 1e-3) / 1e9},
         "roofline_gather": roof_gather,
         "kernel": "k_step_tile (LDS-staged gathers)" if tiled else "plain gather kernels (no vertex locality: no tiles)",
-        "internal_order": "curve / RCM" if G._perm is not None else "none (graph's own order)",
+        "internal_order": "curve / RCM" if G._internal_order() is not None else "none (graph's own order)",
         "parity_vs_oracle": {"max_rel_err": err, "columns": len(cols), "tolerance": 1e-5 if elt == 8 else 1e-3},
         "lmax": lmax,
     }
@@ -964,7 +964,7 @@ def main():
                 "n_edges": int(G.n_edges), "lmax": lmax, "lmax_method": "bounds",
                 "parallelism": "graph-parallel x{} (independent graphs, no data-path collective)".format(world),
                 "internal_order": ("hilbert (2-D coordinates)" if coords.shape[1] == 2 else "morton")
-                                  if G._perm is not None else "none",
+                                  if G._internal_order() is not None else "none",
                 "evaluation": a.evaluation,
                 "engine_options": a.opt, "gather_tiles": G.tile_stats,
             },

@@ -131,6 +131,29 @@ int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const 
  * for graphs with coordinates is the stable argsort of these keys (pygsp_amd.engine.locality_order). */
 int gspx_curve_keys(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve, uint64_t* keys);
 
+/* The vertex order itself: the stable argsort of those keys (what numpy.argsort(keys, kind="stable") returns),
+ * by a radix sort on the device.  perm[new] = old, N int32 on the HOST. */
+int gspx_curve_order(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve, int32_t* perm);
+
+/* Graph set-up in ONE call, on the device: what pygsp/graphs/graph.py:98-176 (the checks of Graph.__init__),
+ * Graph.is_directed (graph.py:357-405) and Graph.compute_laplacian (graph.py:510-630) do to W, plus this engine's
+ * own preparation (CSR validation, curve order of the vertices and its locality score).  W (host CSR; data_dtype
+ * GSPX_F32, GSPX_F64 or 2 = int64) is uploaded once and inspected in place; coords (N x d doubles on the HOST,
+ * nullable) feed the internal order: order_mode 0 none, 1 auto (Hilbert in 2-D / Morton in 3-D, kept only when
+ * it beats the graph's own order by 0.05 of locality score), 2 Morton, 3 Hilbert, 4 the permutation perm_in.
+ * report[12]: [0] NaN entries, [1] infinite, [2] negative, [3] explicit zeros, [4] non-zero diagonal entries
+ * (self-loops), [5] entries whose mirror entry is missing or different (directed graph), [6] CSR violations,
+ * [7] 1 when an internal order is in use, [8] / [9] locality score x 1e9 of the graph's own / the curve order
+ * (auto mode), [10] 0 = graph built, 1 = not built, [11] microseconds of the whole call.
+ * NaN / inf / CSR violations: GSPX_ERR_INVALID with the reference's message.  A directed graph or explicit zeros:
+ * GSPX_OK with *out == NULL and report[10] == 1 - the host layer symmetrises (utils.symmetrize, graph.py:613-616)
+ * / drops the zeros and calls gspx_graph_create_from_w. */
+int gspx_graph_setup(gspx_ctx* ctx, int64_t N, int64_t nnz, const int32_t* indptr, const int32_t* indices,
+                     const void* data, int data_dtype, int lap_type, int compute_dtype, const double* coords,
+                     int d, int order_mode, const int32_t* perm_in, int64_t report[12], gspx_graph** out);
+/* the internal vertex order of a graph (perm[new] = old); GSPX_ERR_INVALID when it has none */
+int gspx_graph_download_perm(gspx_graph* g, int32_t* perm);
+
 /* Columns [j0, j0 + w) of the N x N identity as a row-major N x w panel in device memory (dtype GSPX_F32 /
  * GSPX_F64), queued on the context's stream: the input of Filter.compute_frame (filter.py:593-600 filters
  * np.identity(N)) produced where it is consumed. */

@@ -831,35 +831,23 @@ template <typename T> static int build_internal(gspx_graph* g) {
   return GSPX_OK;
 }
 
+// W already on the device (canonical CSR, values in the compute dtype): degrees, Laplacian, internal layout
 template <typename T>
-static int create_from_w_t(gspx_graph* g, int64_t nnz, const int32_t* indptr,
-                           const int32_t* indices, const void* data, int data_dtype,
-                           int lap_type) {
+static int create_from_w_dev(gspx_graph* g, int64_t nnz, const int* wptr, const int* wcol, const T* wval) {
   gspx_ctx* ctx = g->ctx;
   const int N = (int)g->N;
-  std::vector<T> vals;
-  convert_values<T>(data, data_dtype, nnz, vals);
-  DevMem wptr, wcol, wval, cnt;
-  CHK(wptr.alloc((size_t)(N + 1) * sizeof(int)));
-  CHK(wcol.alloc((size_t)nnz * sizeof(int)));
-  CHK(wval.alloc((size_t)nnz * sizeof(T)));
+  const int lap_type = g->lap_type;
+  DevMem cnt;
   CHK(g->dw.alloc((size_t)std::max(N, 1) * sizeof(T)));
-  HIPCHK(hipMemcpy(wptr.p, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice));
-  if (nnz > 0) {
-    HIPCHK(hipMemcpy(wcol.p, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(wval.p, vals.data(), (size_t)nnz * sizeof(T), hipMemcpyHostToDevice));
-  }
   const auto t0 = std::chrono::steady_clock::now();
   const int nb = std::max(1, (N + 255) / 256);
   CHK(cnt.alloc((size_t)(N + 1) * sizeof(int)));
   HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(N + 1) * sizeof(int), ctx->stream));
   CHK(g->lptr.alloc((size_t)(N + 1) * sizeof(int)));
   if (N > 0) {
-    hipLaunchKernelGGL((k_degree<T>), dim3(nb), dim3(256), 0, ctx->stream, wptr.as<int>(),
-                       wval.as<T>(), N, g->dw.as<T>());
-    hipLaunchKernelGGL((k_lap_build<T, false>), dim3(nb), dim3(256), 0, ctx->stream,
-                       wptr.as<int>(), wcol.as<int>(), wval.as<T>(), g->dw.as<T>(), N, lap_type,
-                       cnt.as<int>(), (int*)nullptr, (int*)nullptr, (T*)nullptr);
+    hipLaunchKernelGGL((k_degree<T>), dim3(nb), dim3(256), 0, ctx->stream, wptr, wval, N, g->dw.as<T>());
+    hipLaunchKernelGGL((k_lap_build<T, false>), dim3(nb), dim3(256), 0, ctx->stream, wptr, wcol, wval,
+                       g->dw.as<T>(), N, lap_type, cnt.as<int>(), (int*)nullptr, (int*)nullptr, (T*)nullptr);
     HIPCHK(hipGetLastError());
   }
   CHK(scan_exclusive(ctx, cnt.as<int>(), g->lptr.as<int>(), N + 1));
@@ -869,9 +857,9 @@ static int create_from_w_t(gspx_graph* g, int64_t nnz, const int32_t* indptr,
   CHK(g->lcol.alloc((size_t)total * sizeof(int)));
   CHK(g->lval.alloc((size_t)total * sizeof(T)));
   if (N > 0) {
-    hipLaunchKernelGGL((k_lap_build<T, true>), dim3(nb), dim3(256), 0, ctx->stream,
-                       wptr.as<int>(), wcol.as<int>(), wval.as<T>(), g->dw.as<T>(), N, lap_type,
-                       (int*)nullptr, g->lptr.as<int>(), g->lcol.as<int>(), g->lval.as<T>());
+    hipLaunchKernelGGL((k_lap_build<T, true>), dim3(nb), dim3(256), 0, ctx->stream, wptr, wcol, wval,
+                       g->dw.as<T>(), N, lap_type, (int*)nullptr, g->lptr.as<int>(), g->lcol.as<int>(),
+                       g->lval.as<T>());
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -879,6 +867,25 @@ static int create_from_w_t(gspx_graph* g, int64_t nnz, const int32_t* indptr,
   g->build_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return GSPX_OK;
+}
+
+template <typename T>
+static int create_from_w_t(gspx_graph* g, int64_t nnz, const int32_t* indptr,
+                           const int32_t* indices, const void* data, int data_dtype,
+                           int lap_type) {
+  const int N = (int)g->N;
+  std::vector<T> vals;
+  convert_values<T>(data, data_dtype, nnz, vals);
+  DevMem wptr, wcol, wval;
+  CHK(wptr.alloc((size_t)(N + 1) * sizeof(int)));
+  CHK(wcol.alloc((size_t)nnz * sizeof(int)));
+  CHK(wval.alloc((size_t)nnz * sizeof(T)));
+  HIPCHK(hipMemcpy(wptr.p, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIPCHK(hipMemcpy(wcol.p, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(wval.p, vals.data(), (size_t)nnz * sizeof(T), hipMemcpyHostToDevice));
+  }
+  return create_from_w_dev<T>(g, nnz, wptr.as<int>(), wcol.as<int>(), wval.as<T>());
 }
 
 template <typename T>
@@ -2717,3 +2724,4 @@ extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double*
 #include "gspx_calib.hip.h"
 #include "gspx_ops.hip.h"
 #include "gspx_knn.hip.h"
+#include "gspx_setup.hip.h"

@@ -336,11 +336,8 @@ __global__ void k_curve_keys(const double* __restrict__ x, int N, int d, double 
 
 }  // namespace gspx
 
-extern "C" int gspx_curve_keys(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve,
-                               uint64_t* keys) {
-  if (!ctx || !coords || !keys) return set_err(GSPX_ERR_INVALID, "null argument");
-  if (N < 1 || N >= ((int64_t)1 << 31) || d < 2) return set_err(GSPX_ERR_INVALID, "gspx_curve_keys: bad N or d");
-  if (curve != 0 && curve != 1) return set_err(GSPX_ERR_INVALID, "curve: 0 Morton, 1 Hilbert");
+// keys of N host points into a device buffer (queued on the context's stream; returns after the launch)
+static int curve_keys_dev(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve, unsigned long long* keys_dev) {
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, inv[3] = {1, 1, 1};
   const int dm = std::min(d, 3);
   for (int j = 0; j < dm; ++j) lo[j] = hi[j] = coords[j];
@@ -352,17 +349,26 @@ extern "C" int gspx_curve_keys(gspx_ctx* ctx, int64_t N, int d, const double* co
       hi[j] = std::max(hi[j], v);
     }
   for (int j = 0; j < dm; ++j) inv[j] = hi[j] > lo[j] ? 1.0 / (hi[j] - lo[j]) : 1.0;
-  HIPCHK(hipSetDevice(ctx->device));
-  DevMem x, k;
+  DevMem x;
   CHK(x.alloc((size_t)N * d * sizeof(double)));
-  CHK(k.alloc((size_t)N * sizeof(uint64_t)));
   HIPCHK(hipMemcpyAsync(x.p, coords, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_curve_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, x.as<double>(),
-                     (int)N, d, lo[0], lo[1], lo[2], inv[0], inv[1], inv[2], curve,
-                     (unsigned long long*)k.p);
+                     (int)N, d, lo[0], lo[1], lo[2], inv[0], inv[1], inv[2], curve, keys_dev);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(keys, k.p, (size_t)N * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // x goes out of scope
+  return GSPX_OK;
+}
+
+extern "C" int gspx_curve_keys(gspx_ctx* ctx, int64_t N, int d, const double* coords, int curve,
+                               uint64_t* keys) {
+  if (!ctx || !coords || !keys) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (N < 1 || N >= ((int64_t)1 << 31) || d < 2) return set_err(GSPX_ERR_INVALID, "gspx_curve_keys: bad N or d");
+  if (curve != 0 && curve != 1) return set_err(GSPX_ERR_INVALID, "curve: 0 Morton, 1 Hilbert");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevMem k;
+  CHK(k.alloc((size_t)N * sizeof(uint64_t)));
+  CHK(curve_keys_dev(ctx, N, d, coords, curve, (unsigned long long*)k.p));
+  HIPCHK(hipMemcpy(keys, k.p, (size_t)N * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return GSPX_OK;
 }
 

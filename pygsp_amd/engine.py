@@ -315,13 +315,13 @@ def locality_order(W, coords=None, curve="auto", device=0, ctx=None):
         return None
     has_coords = coords is not None and np.ndim(coords) == 2 and coords.shape[0] == N and coords.shape[1] >= 2
     if has_coords and N >= 4096 and _capi.device_count() > 0:
-        # curve keys on the device (gspx_curve_keys), stable argsort on the host
+        # curve keys and their stable argsort (a radix sort) on the device: gspx_curve_order
         hil = curve == "hilbert" or (curve == "auto" and coords.shape[1] == 2)
         c = np.ascontiguousarray(coords, dtype=np.float64)
-        keys = np.empty(N, dtype=np.uint64)
-        _capi.check(_capi.load().gspx_curve_keys((ctx or default_context(device))._h, N, c.shape[1], _capi.ptr(c),
-                                                 1 if hil else 0, _capi.ptr(keys)))
-        return np.argsort(keys, kind="stable").astype(np.int32)
+        perm = np.empty(N, dtype=np.int32)
+        _capi.check(_capi.load().gspx_curve_order((ctx or default_context(device))._h, N, c.shape[1], _capi.ptr(c),
+                                                  1 if hil else 0, _capi.ptr(perm)))
+        return perm
     if has_coords and (curve == "hilbert" or (curve == "auto" and coords.shape[1] == 2)):
         return hilbert_order(coords)
     if has_coords:
@@ -408,6 +408,69 @@ class DeviceGraph:
             _capi.dtype_code(data.dtype), lap, _capi.dtype_code(dtype), _capi.ptr(p),
             ctypes.byref(h)))
         return cls(h, ctx, W.shape[0], dtype)
+
+    ORDER_MODES = {"none": 0, None: 0, False: 0, "auto": 1, "morton": 2, "hilbert": 3}
+
+    @classmethod
+    def setup(cls, W, lap_type="combinatorial", dtype=np.float64, coords=None, order="auto", ctx=None):
+        """Graph set-up in one device call (gspx_graph_setup): W - a scipy CSR matrix, NOT checked on the host - is
+        uploaded once, validated, inspected (NaN / inf / negative / zero / diagonal entries, symmetry), given its
+        internal vertex order (curve order of `coords`: 'auto' / 'morton' / 'hilbert' / 'none', or a permutation
+        array) and turned into the device Laplacian.  Returns (DeviceGraph or None, report): None when the graph
+        is directed or stores explicit zeros - the caller prepares W on the host (graph.py:613-616) and uses
+        from_w.  Raises ValueError for NaN / inf entries (the reference's messages) and for a non-canonical CSR."""
+        ctx = ctx or default_context()
+        if lap_type not in ("combinatorial", "normalized"):
+            raise ValueError("Unknown Laplacian type {}".format(lap_type))
+        if not sparse.isspmatrix_csr(W):
+            W = sparse.csr_matrix(W)
+        N = W.shape[0]
+        indptr, indices, data = W.indptr, W.indices, W.data
+        if indptr.dtype != np.int32 or indices.dtype != np.int32:
+            if N >= 2 ** 31 - 1 or W.nnz >= 2 ** 31 - 1:
+                raise ValueError("graph too large for int32 CSR indices")
+            indptr, indices = indptr.astype(np.int32), indices.astype(np.int32)
+        if data.dtype == np.float32:
+            code = _capi.F32
+        elif data.dtype == np.float64:
+            code = _capi.F64
+        elif data.dtype == np.int64:
+            code = 2  # int64 adjacency (ER / SBM): converted on the device
+        else:
+            data, code = data.astype(np.float64), _capi.F64
+        c = np.ascontiguousarray
+        perm_in, xy, d = None, None, 0
+        if isinstance(order, np.ndarray) or isinstance(order, (list, tuple)):
+            perm_in, mode = c(order, dtype=np.int32), 4
+        else:
+            mode = cls.ORDER_MODES[order]
+        if mode in (1, 2, 3):
+            ok = coords is not None and np.ndim(coords) == 2 and np.shape(coords)[0] == N and np.shape(coords)[1] >= 2
+            if ok and N >= 4096:
+                xy = c(coords, dtype=np.float64)
+                d = xy.shape[1]
+            else:
+                mode = 0
+        report = np.zeros(12, dtype=np.int64)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.load().gspx_graph_setup(
+            ctx._h, N, W.nnz, _capi.ptr(c(indptr)), _capi.ptr(c(indices)), _capi.ptr(c(data)), code,
+            _capi.LAP_COMBINATORIAL if lap_type == "combinatorial" else _capi.LAP_NORMALIZED, _capi.dtype_code(dtype),
+            _capi.ptr(xy), d, mode, _capi.ptr(perm_in), _capi.ptr(report), ctypes.byref(h)))
+        rep = {"nan": int(report[0]), "inf": int(report[1]), "negative": int(report[2]), "zeros": int(report[3]),
+               "self_loops": int(report[4]), "asymmetric": int(report[5]), "reordered": bool(report[7]),
+               "locality_own": report[8] / 1e9, "locality_curve": report[9] / 1e9, "built": report[10] == 0,
+               "setup_ms": report[11] / 1e3}
+        return (cls(h, ctx, N, dtype) if h.value else None), rep
+
+    def download_perm(self):
+        """The internal vertex order (perm[new] = old), or None when the graph keeps its own order."""
+        perm = np.empty(self.N, dtype=np.int32)
+        try:
+            _capi.check(_capi.load().gspx_graph_download_perm(self._h, _capi.ptr(perm)))
+        except ValueError:
+            return None
+        return perm
 
     @classmethod
     def from_l(cls, L, dtype=np.float64, perm=None, ctx=None):

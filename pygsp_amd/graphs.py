@@ -58,17 +58,6 @@ class Graph:
     def __init__(self, adjacency, lap_type="combinatorial", coords=None, plotting={}, *,
                  compute_dtype=np.float64, device=0, reorder="auto", tiles="auto", ctx=None):
         self.logger = _logger
-        self._adjacency = _checked_adjacency(adjacency, self.logger)
-        self.n_vertices = self.N = self._adjacency.shape[0]
-        self._flags = {}   # lazily computed facts about W ("directed")
-        # stored entries of a directed graph; unordered pairs (+ self-loops) of an undirected one
-        loops = int(np.count_nonzero(self._adjacency.diagonal()))
-        stored = self._adjacency.nnz
-        self.n_edges = self.Ne = stored if self.is_directed() else (stored - loops) // 2 + loops
-        if coords is not None:
-            self.coords = np.asanyarray(coords)
-        self.plotting, self.signals = dict(plotting), {}
-
         # engine-side configuration and state
         # (ctx: a specific libgspx context instead of the default one of `device` - one per driver thread
         # when a process runs several GPUs, pygsp_amd.multi)
@@ -80,9 +69,62 @@ class Graph:
         self._perm, self._perm_done = None, False
         self._dev = {}     # compute dtype -> engine.DeviceGraph
         self._L = self._dw = None
+        self._flags = {}   # lazily computed facts about W ("directed")
         self._forget_spectrum()
+        if lap_type not in ("combinatorial", "normalized"):
+            raise ValueError("Unknown Laplacian type {}".format(lap_type))
         self.lap_type = lap_type
-        self.compute_laplacian(lap_type)
+        if coords is not None:
+            self.coords = np.asanyarray(coords)
+        self.plotting, self.signals = dict(plotting), {}
+        if not self._setup_on_device(adjacency):
+            # the host route (dense input, a directed graph, explicit zeros, ...): the reference's steps one by one
+            self._adjacency = _checked_adjacency(adjacency, self.logger)
+            self.n_vertices = self.N = self._adjacency.shape[0]
+            # stored entries of a directed graph; unordered pairs (+ self-loops) of an undirected one
+            loops = int(np.count_nonzero(self._adjacency.diagonal()))
+            stored = self._adjacency.nnz
+            self.n_edges = self.Ne = stored if self.is_directed() else (stored - loops) // 2 + loops
+            self.compute_laplacian(lap_type)
+
+    def _setup_on_device(self, adjacency):
+        """Fast route for a scipy CSR matrix: ONE device call (engine.DeviceGraph.setup -> gspx_graph_setup) does the
+        checks of graph.py:98-134, the directedness test of graph.py:357-405, the internal vertex order and the
+        Laplacian of graph.py:510-630 on the uploaded matrix - no host pass over the stored entries.  False when
+        the host route has to take over."""
+        if not sparse.isspmatrix_csr(adjacency) or adjacency.shape[0] != adjacency.shape[1]:
+            return False
+        order = self.reorder
+        if isinstance(order, str) and order == "rcm":
+            return False
+        if order == "auto" and getattr(self, "coords", None) is None and adjacency.shape[0] >= 4096:
+            return False  # no coordinates: reverse Cuthill-McKee is a host (scipy) algorithm
+        try:
+            dev, rep = engine.DeviceGraph.setup(adjacency, self.lap_type, self.compute_dtype,
+                                                getattr(self, "coords", None), order, ctx=self.context)
+        except ValueError as e:
+            if "canonical" in str(e):
+                return False  # duplicates / unsorted indices: the host route sums and sorts them
+            raise
+        if dev is None:  # directed, or explicit zeros to drop
+            return False
+        if rep["self_loops"]:
+            self.logger.warning("Adjacency: there are self-loops (non-zeros on the diagonal). "
+                                "The Laplacian will not see them.")
+        if rep["negative"]:
+            self.logger.warning("Adjacency: there are negative edge weights.")
+        self._adjacency = adjacency
+        self.n_vertices = self.N = adjacency.shape[0]
+        self._flags["directed"] = False
+        self.n_edges = self.Ne = (adjacency.nnz - rep["self_loops"]) // 2 + rep["self_loops"]
+        self._perm_done, self._perm_lazy = True, dev if rep["reordered"] else None
+        self.setup_report = rep
+        if self.tiles == "auto":
+            self.tile_stats = dev.auto_gather_tiles()
+        elif self.tiles:
+            self.tile_stats = dev.enable_gather_tiles()
+        self._dev[self.compute_dtype] = dev
+        return True
 
     def _forget_spectrum(self):
         """Everything derived from the Laplacian's spectrum (graph.py:602-609)."""
@@ -115,6 +157,13 @@ class Graph:
 
     # ---- Laplacian (device) --------------------------------------------------------------------
     def _internal_order(self):
+        lazy = getattr(self, "_perm_lazy", None)
+        if lazy is not None:  # chosen on the device (gspx_graph_setup): downloaded when somebody asks
+            self._perm_lazy = None
+            if getattr(lazy, "_h", None):
+                self._perm = lazy.download_perm()
+            else:
+                self._perm_done = False
         if not self._perm_done:
             self._perm_done = True
             mode = self.reorder
@@ -158,6 +207,7 @@ class Graph:
             self._forget_spectrum()
         self.lap_type = lap_type
         self._L = None
+        self._internal_order()  # (an order chosen on the device is fetched before its graph goes)
         while self._dev:
             self._dev.popitem()[1].destroy()
         self.device_graph()  # build now: errors surface here, like in the reference
