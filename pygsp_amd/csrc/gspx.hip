@@ -348,6 +348,9 @@ struct gspx_ctx {
   DevMem ws_w;      // per-step flush weights / combine coefficients
   DevMem io_x, io_y;  // staging for the host-pointer entry point
   HostPipe* pipe = nullptr;  // its pipelined form (created on first use)
+  // live RCCL communicators made on this context (gspx_comm_create): invalidated when the context goes
+  std::mutex comms_mu;
+  std::vector<struct gspx_comm*> comms;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev_pool;
   double timing[5] = {0, 0, 0, 0, 0};
@@ -472,9 +475,12 @@ extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
   return GSPX_OK;
 }
 
+static void comm_invalidate_all(gspx_ctx* ctx);  // gspx_comm.hip.h
+
 extern "C" int gspx_ctx_destroy(gspx_ctx* ctx) {
   replay_reset(ctx);
   if (!ctx) return GSPX_OK;
+  comm_invalidate_all(ctx);
   if (ctx->graph_exec) {
     (void)hipGraphExecDestroy(ctx->graph_exec);
     ctx->graph_exec = nullptr;

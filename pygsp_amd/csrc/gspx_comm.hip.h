@@ -87,10 +87,31 @@ static std::string unavailable() { return "RCCL is not available: " + instance()
   } while (0)
 
 struct gspx_comm {
-  gspx_ctx* ctx = nullptr;
+  gspx_ctx* ctx = nullptr;  // null once the context was destroyed: the handle is then only good for gspx_comm_destroy
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
 };
+
+// gspx_ctx_destroy: every communicator still alive on the context is torn down with it (its stream is about to
+// go) and its handle is left as an empty shell, so a later gspx_comm_gather / gspx_comm_destroy on it is an error
+// message / a plain delete instead of a use-after-free.
+static void comm_invalidate_all(gspx_ctx* ctx) {
+  std::vector<gspx_comm*> live;
+  {
+    std::lock_guard<std::mutex> lock(ctx->comms_mu);
+    live.swap(ctx->comms);
+  }
+  gspx_rccl::Api* R = live.empty() ? nullptr : gspx_rccl::api();
+  for (gspx_comm* h : live) {
+    if (R && h->comm) {
+      (void)hipSetDevice(ctx->device);
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)R->CommDestroy(h->comm);
+    }
+    h->comm = nullptr;
+    h->ctx = nullptr;
+  }
+}
 
 extern "C" int gspx_comm_available(void) { return gspx_rccl::api() ? 1 : 0; }
 
@@ -122,17 +143,28 @@ extern "C" int gspx_comm_create(gspx_ctx* ctx, int nranks, int rank, const unsig
   h->rank = rank;
   h->nranks = nranks;
   h->comm = c;
+  {
+    std::lock_guard<std::mutex> lock(ctx->comms_mu);
+    ctx->comms.push_back(h);
+  }
   *out = h;
   return GSPX_OK;
 }
 
 extern "C" int gspx_comm_destroy(gspx_comm* h) {
   if (!h) return GSPX_OK;
-  gspx_rccl::Api* R = gspx_rccl::api();
-  if (R && h->comm) {
-    (void)hipSetDevice(h->ctx->device);
-    (void)hipStreamSynchronize(h->ctx->stream);
-    (void)R->CommDestroy(h->comm);
+  if (h->ctx) {  // (a null context: gspx_ctx_destroy already took the communicator down)
+    {
+      std::lock_guard<std::mutex> lock(h->ctx->comms_mu);
+      auto& v = h->ctx->comms;
+      v.erase(std::remove(v.begin(), v.end(), h), v.end());
+    }
+    gspx_rccl::Api* R = gspx_rccl::api();
+    if (R && h->comm) {
+      (void)hipSetDevice(h->ctx->device);
+      (void)hipStreamSynchronize(h->ctx->stream);
+      (void)R->CommDestroy(h->comm);
+    }
   }
   delete h;
   return GSPX_OK;
@@ -146,6 +178,8 @@ extern "C" int gspx_comm_gather(gspx_comm* h, const void* part_dev, const int64_
                                 void* root_out_dev, double* ms) {
   if (!h || !bytes || root < 0 || root >= h->nranks)
     return set_err(GSPX_ERR_INVALID, "gspx_comm_gather: bad argument");
+  if (!h->ctx || !h->comm)
+    return set_err(GSPX_ERR_INVALID, "gspx_comm_gather: the communicator's context was destroyed");
   for (int r = 0; r < h->nranks; ++r)
     if (bytes[r] < 0) return set_err(GSPX_ERR_INVALID, "gspx_comm_gather: negative block size");
   if (bytes[h->rank] > 0 && !part_dev) return set_err(GSPX_ERR_INVALID, "gspx_comm_gather: null part");
@@ -184,9 +218,13 @@ extern "C" int gspx_comm_gather(gspx_comm* h, const void* part_dev, const int64_
 // ---- single-process form: several contexts (GPUs) driven by one process -----------------------------
 namespace gspx_rccl {
 // communicators of a device set, made once by ncclCommInitAll (rank i = i-th device of the sorted set)
+// They live until the process exits: destroying RCCL communicators from a static destructor would race the
+// HIP runtime's own teardown.  One gather at a time per set (`busy`): the communicators and the grouped
+// send / recv of a set are not re-entrant.
 struct DeviceSet {
   std::vector<int> devs;
   std::vector<ncclComm_t> comms;
+  std::mutex busy;
 };
 static std::mutex g_sets_mu;
 static std::vector<std::unique_ptr<DeviceSet>> g_sets;
@@ -198,7 +236,11 @@ static DeviceSet* device_set(Api* R, const std::vector<int>& devs) {
   std::unique_ptr<DeviceSet> s(new DeviceSet());
   s->devs = devs;
   s->comms.assign(devs.size(), nullptr);
-  if (R->CommInitAll(s->comms.data(), (int)devs.size(), devs.data()) != ncclSuccess) return nullptr;
+  if (R->CommInitAll(s->comms.data(), (int)devs.size(), devs.data()) != ncclSuccess) {
+    for (ncclComm_t c : s->comms)  // whatever a partial initialisation left behind
+      if (c) (void)R->CommDestroy(c);
+    return nullptr;
+  }
   g_sets.push_back(std::move(s));
   return g_sets.back().get();
 }
@@ -218,6 +260,7 @@ static int gather_rccl(int n, gspx_buf** parts, gspx_buf* root_out, bool force) 
   if (devs.size() == 1 && !force) return set_err(GSPX_ERR_INVALID, "gather_rccl: one device, nothing to send");
   gspx_rccl::DeviceSet* set = gspx_rccl::device_set(R, devs);
   if (!set) return set_err(GSPX_ERR_HIP, "ncclCommInitAll failed");
+  std::lock_guard<std::mutex> one_at_a_time(set->busy);
   auto rank_of = [&](int dev) { return (int)(std::lower_bound(devs.begin(), devs.end(), dev) - devs.begin()); };
   // one stream per device: the first context seen on it; everything queued on the parts' streams so far
   // must be complete before a foreign stream reads them

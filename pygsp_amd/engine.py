@@ -198,10 +198,25 @@ class Comm:
         return ms.value
 
     def close(self):
+        # (after its context is gone the handle is an empty shell inside libgspx - gspx_ctx_destroy took the RCCL
+        # communicator down with the stream - and gspx_comm_destroy only frees it)
         if getattr(self, "_h", None):
-            if getattr(self.ctx, "_h", None):
-                _capi.load().gspx_comm_destroy(self._h)
+            _capi.load().gspx_comm_destroy(self._h)
             self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def filter_batch(jobs, root_ctx=None):

@@ -140,6 +140,26 @@ def test_comm_gather_one_rank(ctx):
             b.free()
 
 
+def test_comm_outlives_its_context_safely():
+    """A communicator whose context is destroyed first (use-after-free at the C-ABI): the context
+    takes the RCCL communicator down with it, the handle stays a valid empty shell - gather reports an error,
+    close() just frees it."""
+    if not engine.comm_available():
+        pytest.skip("RCCL cannot be loaded on this box")
+    ctx2 = engine.Context(0)
+    comm = engine.Comm(ctx2, 1, 0, engine.comm_unique_id())
+    buf = ctx2.alloc(64)
+    ptr = buf.ptr
+    buf.free()
+    ctx2.close()
+    with pytest.raises(ValueError, match="context was destroyed"):
+        comm.gather(ptr, [64], 0, ptr)
+    comm.close()
+    comm.close()  # idempotent
+    with engine.Comm(engine.default_context(0), 1, 0, engine.comm_unique_id()) as c2:
+        assert c2.nranks == 1
+
+
 def test_two_ranks_on_this_gpu_through_bench():
     """bench.py --gpus 2 under torch.distributed.run, both ranks on device 0 (gloo process group): the
     N > 1 path - independent graph per rank, barrier-bracketed timing, MAX over ranks, final gather - runs

@@ -40,8 +40,13 @@ def main():
     ctx.set_option("host_pipeline", 0)
     y0 = timed("one-shot")
     ctx.set_option("host_pipeline", 2)
-    for batch in (8, 16, 32):
-        for threads in (2, 4, 8, 16):
+    for threads in (0, 8, 16, 32):  # host_batch 0: the engine's own schedule (narrow edge batches, wide middle ones)
+        ctx.set_option("host_batch", 0)
+        ctx.set_option("host_threads", threads)
+        y = timed("auto schedule, threads {}".format(threads or "auto"))
+        rows[-1]["identical_to_one_shot"] = bool(np.array_equal(y, y0))
+    for batch in ((16,) if "auto" in sys.argv else (8, 16, 32)):
+        for threads in ((16,) if "auto" in sys.argv else (2, 4, 8, 16)):
             ctx.set_option("host_batch", batch)
             ctx.set_option("host_threads", threads)
             y = timed("batch {} threads {}".format(batch, threads))
