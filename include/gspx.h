@@ -90,7 +90,7 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *                   pair tiles (gspx_graph_set_tiles)
  *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order; 0 edge order
  *   "host_pipeline" gspx_cheby_filter: 1 (default) large calls pipelined in column batches, 2 always, 0 never;
- *                   "host_batch" signals per batch, "host_threads" per direction (0 = auto)
+ *                   "host_batch" signals per batch, "host_edge" of the first / last one, "host_threads" (0 = auto)
  *   "streamed_alloc" 1 (default) workspaces from scrambled 2 MB chunks (+2..8 % bandwidth; a retired range
  *                   keeps its address space: read-only "retired_va_mb"); 0 plain hipMalloc, the safe mode
  *                   (also GSPX_STREAMED_ALLOC=0 in the environment) */

@@ -330,7 +330,8 @@ struct Options {
   int64_t gather_rccl = 1;      // gspx_gather: 0 peer copies, 1 RCCL between devices (peer copies if it fails), 2 RCCL for every block
   int64_t host_pipeline = 1;    // gspx_cheby_filter (host pointers): 1 column batches pipelined over pinned staging when the
                                 // call is large enough, 2 always, 0 one pageable copy in, the kernels, one out
-  int64_t host_batch = 0;       // signals per pipelined batch (0: auto)
+  int64_t host_batch = 0;       // signals per pipelined batch (0: auto = 128-byte rows; > 0: uniform batches of that width)
+  int64_t host_edge = 0;        // width of the first and the last batch (0: auto = half a batch in auto mode)
   int64_t host_threads = 0;     // host threads packing / unpacking, per direction (0: auto, a quarter of the cores, at most 16)
   int64_t streamed_alloc = 1;   // 1: the two streamed workspaces are assembled from scrambled 2 MB chunks (HIP
                                 // virtual-memory API; +2..8 % bandwidth); 0: plain hipMalloc (the safe mode on an
@@ -536,6 +537,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "gather_rccl")) return &o.gather_rccl;
   if (!strcmp(key, "host_pipeline")) return &o.host_pipeline;
   if (!strcmp(key, "host_batch")) return &o.host_batch;
+  if (!strcmp(key, "host_edge")) return &o.host_edge;
   if (!strcmp(key, "host_threads")) return &o.host_threads;
   if (!strcmp(key, "streamed_alloc")) return &o.streamed_alloc;
   return nullptr;

@@ -242,29 +242,29 @@ static void host_pipeline_shape(const Options& opt, size_t elt, int64_t N, int64
   if (!opt.host_pipeline) return;
   const size_t total = (size_t)N * (size_t)Nsig * elt * (size_t)planes_total;
   if (opt.host_pipeline == 1 && total < ((size_t)48 << 20)) return;  // too small to pay for the threads
-  if (opt.host_batch > 0) {  // uniform batches of the given width (the last one may be narrower)
-    const int64_t w = std::min<int64_t>(opt.host_batch, Nsig);
-    if (Nsig <= w) return;
-    for (int64_t c = 0; c < Nsig; c += w) widths->push_back(std::min<int64_t>(w, Nsig - c));
+  // The call's critical path is: fill (pack + H2D of the first batch), the kernels of all batches, drain (D2H +
+  // unpack of the last batch).  Batches of 128-byte rows (16 fp64 / 32 fp32 signals) run the kernels within ~20 %
+  // of their full-width rate (the matrix is streamed once per batch; narrower panels cost much more per column)
+  // while a batch's transfer still hides behind the previous batch's kernels; the first and the last batch are
+  // half as wide, which halves fill and drain.  (Measured on the 1M x 64 fp64 call, profiles/r03_hostpipe_*:
+  // uniform 8 / 16 / 32 columns 28.5 / 25.0 / 31.2 ms; narrow edges followed by 3x wider batches starve the
+  // kernels - the second batch's transfer outlasts the first batch's kernels - 27.5 ms.)
+  const int64_t unit = (int64_t)(64 / elt);  // auto sizes are multiples of 64-byte rows: the kernels' efficient widths
+  int64_t w = opt.host_batch > 0 ? opt.host_batch : (int64_t)(128 / elt);
+  if (opt.host_batch <= 0 && Nsig < 4 * w) w = std::max<int64_t>(unit, (Nsig / 4) / unit * unit);
+  w = std::min<int64_t>(w, Nsig);
+  int64_t edge = opt.host_edge > 0 ? std::min<int64_t>(opt.host_edge, w) : (opt.host_batch > 0 ? w : std::max(unit, w / 2 / unit * unit));
+  if (Nsig <= w || (opt.host_pipeline == 1 && Nsig < 2 * w)) {
+    if (opt.host_pipeline != 2 || Nsig < 2) return;
+    w = edge = (Nsig + 1) / 2;  // "always": two halves
+  }
+  if (2 * edge >= Nsig) edge = w;  // too few columns for separate edge batches
+  if (edge < w) {
+    widths->push_back(edge);
+    for (int64_t c = edge; c < Nsig - edge; c += w) widths->push_back(std::min<int64_t>(w, Nsig - edge - c));
+    widths->push_back(edge);
   } else {
-    // The call's critical path is: fill (pack + H2D of the first batch), the kernels of all batches, drain (D2H +
-    // unpack of the last batch).  Narrow first and last batches keep fill and drain short; wide middle batches
-    // run the kernels near their best rate (the matrix is streamed once per batch).  In 64-byte row units:
-    // edge batches of about Nsig / 8, middle batches of at most 3 x that (24 fp64 / 48 fp32 signals at 64).
-    const int64_t unit = (int64_t)(64 / elt);
-    if (Nsig < 4 * unit) return;
-    const int64_t edge = std::max<int64_t>(unit, (Nsig / 8) / unit * unit);
-    const int64_t mid_cap = std::min<int64_t>(3 * edge, (int64_t)(256 / elt));
-    int64_t rest = Nsig - 2 * edge;
-    widths->push_back(edge);
-    const int64_t nmid = std::max<int64_t>(1, (rest + mid_cap - 1) / mid_cap);
-    for (int64_t i = 0; i < nmid; ++i) {
-      int64_t wm = ((rest / (nmid - i)) + unit - 1) / unit * unit;
-      wm = std::min(wm, rest);
-      if (wm > 0) widths->push_back(wm);
-      rest -= wm;
-    }
-    widths->push_back(edge);
+    for (int64_t c = 0; c < Nsig; c += w) widths->push_back(std::min<int64_t>(w, Nsig - c));
   }
   int t = (int)opt.host_threads;
   if (t <= 0) {

@@ -12,7 +12,7 @@ DEFAULT_OPTIONS = (("kernel", 0), ("vec", 0), ("rows_per_wave", 0), ("xcd_remap"
                    ("max_batch", 0), ("narrow_g_log2", -1), ("tile_gather", 1), ("graph_launch", 2),
                    ("alternate_sweep", 1), ("synthesis", 0), ("fuse_input", 1), ("tile_workgroups", 0),
                    ("tile_nt", -1), ("ws_limit_mb", 65536), ("host_pipeline", 1), ("host_batch", 0),
-                   ("host_threads", 0))
+                   ("host_threads", 0), ("host_edge", 0))
 
 
 @pytest.fixture(scope="module")

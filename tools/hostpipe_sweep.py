@@ -40,11 +40,19 @@ def main():
     ctx.set_option("host_pipeline", 0)
     y0 = timed("one-shot")
     ctx.set_option("host_pipeline", 2)
-    for threads in (0, 8, 16, 32):  # host_batch 0: the engine's own schedule (narrow edge batches, wide middle ones)
+    for threads in (0, 8):  # host_batch 0: the engine's own schedule (half-width first and last batch)
         ctx.set_option("host_batch", 0)
+        ctx.set_option("host_edge", 0)
         ctx.set_option("host_threads", threads)
         y = timed("auto schedule, threads {}".format(threads or "auto"))
         rows[-1]["identical_to_one_shot"] = bool(np.array_equal(y, y0))
+    for batch, edge in ((16, 4), (16, 8), (16, 16), (24, 8), (32, 16)):
+        ctx.set_option("host_batch", batch)
+        ctx.set_option("host_edge", edge)
+        ctx.set_option("host_threads", 16)
+        y = timed("batch {} edge {} threads 16".format(batch, edge))
+        rows[-1]["identical_to_one_shot"] = bool(np.array_equal(y, y0))
+    ctx.set_option("host_edge", 0)
     for batch in ((16,) if "auto" in sys.argv else (8, 16, 32)):
         for threads in ((16,) if "auto" in sys.argv else (2, 4, 8, 16)):
             ctx.set_option("host_batch", batch)
