@@ -328,6 +328,7 @@ struct Options {
   int64_t ws_limit_mb = 65536;  // workspace budget per filter call
   int64_t max_batch = 0;        // 0 = no extra cap on signals per batch
   int64_t gather_rccl = 1;      // gspx_gather: 0 peer copies, 1 RCCL between devices (peer copies if it fails), 2 RCCL for every block
+  int64_t lds_pad_kb = 0;       // k_step_lds: unused dynamic LDS per workgroup (0..40 KB), caps the occupancy
   int64_t host_pipeline = 1;    // gspx_cheby_filter (host pointers): 1 column batches pipelined over pinned staging when the
                                 // call is large enough, 2 always, 0 one pageable copy in, the kernels, one out
   int64_t host_batch = 0;       // signals per pipelined batch (0: auto = 128-byte rows; > 0: uniform batches of that width)
@@ -535,6 +536,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "ws_limit_mb")) return &o.ws_limit_mb;
   if (!strcmp(key, "max_batch")) return &o.max_batch;
   if (!strcmp(key, "gather_rccl")) return &o.gather_rccl;
+  if (!strcmp(key, "lds_pad_kb")) return &o.lds_pad_kb;
   if (!strcmp(key, "host_pipeline")) return &o.host_pipeline;
   if (!strcmp(key, "host_batch")) return &o.host_batch;
   if (!strcmp(key, "host_edge")) return &o.host_edge;
@@ -1445,8 +1447,10 @@ static void launch_panel(const StepArgs<T>& a, const Shape& s, dim3 grid, hipStr
 template <typename T, int VEC, int MODE>
 static void launch_lds_w(const StepArgs<T>& a, const unsigned* coff, int wlog2, dim3 grid,
                          hipStream_t st) {
+  // (a.lds_pad: unused dynamic LDS that only lowers the workgroups resident per CU - an experiment knob for
+  // graphs without locality, where fewer gathers in flight per L2 can mean more hits)
 #define GSPX_LL(WL)                                                                          \
-  hipLaunchKernelGGL((k_step_lds<T, VEC, WL, MODE>), grid, dim3(256), 0, st, a.rowptr, coff, \
+  hipLaunchKernelGGL((k_step_lds<T, VEC, WL, MODE>), grid, dim3(256), (size_t)a.lds_pad, st, a.rowptr, coff, \
                      a.val, a.cur, a.wts, a.perm, a)
   switch (wlog2) {
     case 4: GSPX_LL(4); break;
@@ -1479,7 +1483,7 @@ static void launch_step(StepArgs<T> a, const Shape& s, const Options& opt, hipSt
   }
   a.rows_per_wave = rpw;
   int rows_per_chunk;
-  a.rows_per_wave = rpw;
+  a.lds_pad = (int)std::min<int64_t>(std::max<int64_t>(opt.lds_pad_kb, 0), 40) * 1024;
   a.wpb = (s.kernel == 1) ? (int)opt.waves_per_block : 4;
   if (s.kernel == 1 || s.kernel == 5)
     rows_per_chunk = a.wpb * rpw;

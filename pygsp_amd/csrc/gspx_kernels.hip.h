@@ -156,6 +156,7 @@ template <typename T> struct StepArgs {
   // row -> workgroup mapping
   int rows_per_wave;
   int wpb;          // waves per workgroup (panel kernel: 4, 8 or 16)
+  int lds_pad;      // host only: extra dynamic LDS bytes of the launch (occupancy experiments)
   int nchunks;      // number of (wpb*rows_per_wave)-row chunks
   int cpx;          // chunks per XCD (xcd_remap) or 0 for plain order
   int reverse;      // 1: sweep the rows from the end (alternate steps: the tail of the previous
