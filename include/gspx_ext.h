@@ -88,7 +88,8 @@ int gspx_grad_dev(gspx_graph* g, int64_t Nsig, const void* x_dev, void* y_dev, d
 int gspx_div_dev(gspx_graph* g, int64_t Nsig, const void* y_dev, void* z_dev, double* kernel_ms);
 
 /* ---- k-nearest-neighbour graph construction on the device ---------------
- * Replaces, for NNtype='knn', dist_type='euclidean', symmetrize_type='average' and 1..3 dimensions,
+ * Replaces, for NNtype='knn' and 1..64 dimensions (a uniform grid in 1-3 dimensions; beyond that a tiled brute
+ * force whose pair distances run on the matrix cores, candidates re-evaluated in the KD-tree's arithmetic),
  * the KD-tree query, the Gaussian weights and the symmetrisation of NNGraph
  * (pygsp/graphs/nngraphs/nngraph.py:213-226, 289-297):
  *   D, NN = KDTree(X).query(X, k + 1);  sigma = mean(D[:, 1:]);  w = exp(-D^2 / sigma);
@@ -103,6 +104,10 @@ int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, int k,
                    int metric, int symmetrize, gspx_knn** out);
 int gspx_knn_destroy(gspx_knn* h);
 int gspx_knn_info(gspx_knn* h, int64_t* nnz, double* sigma, double* build_ms);
+/* how the neighbour search of the last build ran in more than three dimensions (tiled brute force, pair
+ * distances on MFMA): out[0] sample size behind the per-query bounds, out[1] candidate capacity per query,
+ * out[2] mean candidates per query, out[3] queries that took the exact scan (zeros for the 1-3-D grid search) */
+int gspx_knn_search_stats(gspx_knn* h, double out[4]);
 /* symmetric W as CSR (sorted columns), float64 */
 int gspx_knn_download_w(gspx_knn* h, int32_t* indptr, int32_t* indices, double* data);
 /* NN[:, 1:] and D[:, 1:] of the reference: N x k, nearest first (either may be NULL) */

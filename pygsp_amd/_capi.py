@@ -90,6 +90,7 @@ SIGNATURES = {
     "gspx_knn_destroy": (_c.c_int, [_P]),
     "gspx_knn_info": (_c.c_int, [_P, _P, _P, _P]),
     "gspx_knn_download_w": (_c.c_int, [_P, _P, _P, _P]),
+    "gspx_knn_search_stats": (_c.c_int, [_P, _P]),
     "gspx_knn_download_neighbors": (_c.c_int, [_P, _P, _P]),
     "gspx_graph_set_gather_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     "gspx_curve_keys": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_int, _P]),

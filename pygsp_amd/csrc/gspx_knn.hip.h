@@ -1,7 +1,8 @@
 // gspx_knn.hip.h - k-nearest-neighbour graph construction on the device.
 // Included at the end of gspx.hip.  gfx950 only.
 //
-// Replaces, for NNtype='knn', dist_type='euclidean', symmetrize_type='average', 1 <= d <= 3:
+// Replaces, for NNtype='knn' (1 <= d <= 3 by the grid search below; 4 <= d <= 64 by the tiled brute force on the
+// matrix cores of gspx_knn_bf.hip.h; the weights / symmetrisation / CSR stages are shared):
 //   pygsp/graphs/nngraphs/nngraph.py:213-216  kdt = spatial.KDTree(Xout); D, NN = kdt.query(Xout, k + 1)
 //   nngraph.py:218-226                        sigma = mean(D[:, 1:]);  w = exp(-D^2 / sigma)
 //   nngraph.py:289-297                        W = csc((w, (i, j)));  W = (W + W.T) / 2
@@ -379,8 +380,12 @@ struct gspx_knn {
   double sigma = 0.0;
   int64_t nnz = 0;
   double build_ms = 0.0;
+  double search_stats[4] = {0, 0, 0, 0};  // brute-force search (d > 3): sample, capacity, mean candidates, exact scans
   DevMem nn, dist, rowptr, col, val;
 };
+
+#include "gspx_knn_bf.hip.h"
+
 
 template <int KMAX>
 static void launch_knn_query(const double* sorted, const int* order, const int* start, int N,
@@ -397,8 +402,8 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   if (symmetrize < 0 || symmetrize > 3)
     return set_err(GSPX_ERR_INVALID, "symmetrize: 0 average, 1 maximum / fill, 2 tril, 3 triu");
   if (N < 2 || N >= ((int64_t)1 << 31) / 64) return set_err(GSPX_ERR_INVALID, "gspx_knn_build: bad N");
-  if (d < 1 || d > 3)
-    return set_err(GSPX_ERR_INVALID, "gspx_knn_build: the device k-NN search covers 1 to 3 dimensions (got %d)", d);
+  if (d < 1 || d > 64)
+    return set_err(GSPX_ERR_INVALID, "gspx_knn_build: the device k-NN search covers 1 to 64 dimensions (got %d)", d);
   if (k < 1 || k > 64) return set_err(GSPX_ERR_INVALID, "gspx_knn_build: 1 <= k <= 64 (got %d)", k);
   if (k >= N)  // nngraph.py:123-127
     return set_err(GSPX_ERR_INVALID, "The number of neighbors (k=%d) must be smaller than the number of nodes (%lld).",
@@ -406,7 +411,9 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   if (!coords) return set_err(GSPX_ERR_INVALID, "null coordinates");
   if (!(sigma >= 0) || !std::isfinite(sigma)) return set_err(GSPX_ERR_INVALID, "sigma must be >= 0 (0: mean distance)");
   KnnGrid g{};
-  g.d = d;
+  const bool grid_search = d <= 3;  // beyond three dimensions: tiled brute force on the matrix cores (gspx_knn_bf.hip.h)
+  const int dg = grid_search ? d : 0;
+  g.d = dg;
   g.metric = metric;
   double hi[3] = {0, 0, 0};
   for (int j = 0; j < 3; ++j) {
@@ -414,7 +421,7 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
     g.inv_h[j] = 1;
     g.n[j] = 1;
   }
-  for (int j = 0; j < d; ++j) {
+  for (int j = 0; j < dg; ++j) {
     g.lo[j] = coords[j];
     hi[j] = coords[j];
   }
@@ -422,15 +429,17 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
     for (int j = 0; j < d; ++j) {
       const double v = coords[i * d + j];
       if (!std::isfinite(v)) return set_err(GSPX_ERR_INVALID, "non-finite coordinate");
-      g.lo[j] = std::min(g.lo[j], v);
-      hi[j] = std::max(hi[j], v);
+      if (j < dg) {
+        g.lo[j] = std::min(g.lo[j], v);
+        hi[j] = std::max(hi[j], v);
+      }
     }
   // about 2.5 points per cell over the bounding box; degenerate extents get one cell
   const int cap = d == 1 ? (1 << 21) : (d == 2 ? 2048 : 128);
-  const int per_dim = std::max(1, std::min(cap, (int)std::floor(std::pow((double)N / 2.5, 1.0 / d))));
+  const int per_dim = std::max(1, std::min(cap, (int)std::floor(std::pow((double)N / 2.5, 1.0 / std::max(dg, 1)))));
   g.h_min = 1e300;
   int64_t ncells = 1;
-  for (int j = 0; j < d; ++j) {
+  for (int j = 0; j < dg; ++j) {
     const double ext = hi[j] - g.lo[j];
     g.n[j] = ext > 0 ? per_dim : 1;
     const double h = ext > 0 ? ext / g.n[j] : 1.0;
@@ -477,6 +486,10 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   KHIP(hipMemsetAsync(count.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
   KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)std::max<int64_t>(ncells, N) + 1) * sizeof(int), st));
   const int nbN = (n + 255) / 256;
+  if (!grid_search) {
+    KHIP(hipStreamSynchronize(st));
+    KCHK(knn_bruteforce(ctx, x.as<double>(), n, d, k, metric, h->nn.as<int>(), h->dist.as<double>(), h->search_stats));
+  } else {
   hipLaunchKernelGGL(k_knn_cell_count, dim3(nbN), dim3(256), 0, st, x.as<double>(), n, g, cell.as<int>(),
                      count.as<int>());
   KCHK(scan_exclusive(ctx, count.as<int>(), start.as<int>(), (int)ncells + 1));
@@ -496,6 +509,7 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
   else
     launch_knn_query<64>(sorted.as<double>(), order.as<int>(), start.as<int>(), n, g, k, h->nn.as<int>(),
                          h->dist.as<double>(), st);
+  }
   KHIP(hipGetLastError());
   // sigma = mean neighbour distance (nngraph.py:218-219) unless given
   if (sigma == 0.0) {
@@ -554,6 +568,12 @@ extern "C" int gspx_knn_info(gspx_knn* h, int64_t* nnz, double* sigma, double* b
   if (nnz) *nnz = h->nnz;
   if (sigma) *sigma = h->sigma;
   if (build_ms) *build_ms = h->build_ms;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_knn_search_stats(gspx_knn* h, double out[4]) {
+  if (!h || !out) return set_err(GSPX_ERR_INVALID, "null argument");
+  for (int i = 0; i < 4; ++i) out[i] = h->search_stats[i];
   return GSPX_OK;
 }
 

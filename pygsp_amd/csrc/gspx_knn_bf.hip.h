@@ -1,0 +1,287 @@
+// gspx_knn_bf.hip.h - k nearest neighbours in MORE than three dimensions (NNGraph on feature / patch clouds,
+// pygsp/graphs/nngraphs/nngraph.py:213-226, nngraphs/imgpatches.py): tiled brute force with the pair
+// distances on the matrix cores.  Included by gspx_knn.hip.h (uses its KD-tree arithmetic helpers).
+//
+// A uniform grid stops paying beyond three dimensions (a KD-tree degrades the same way), while all pair
+// distances of a point block are ONE dense contraction,  |x - y|^2 = |x|^2 + |y|^2 - 2 x.y  - the one place
+// of the path's surroundings where a dense panel product is the natural formulation, so it runs on MFMA
+// (v_mfma_f64_16x16x4f64: a 16 x 16 tile of dot products per instruction, fp64 because the selection below
+// must not lose a true neighbour to rounding).  Four stages:
+//   1. k_bf_prepare   points -> MFMA operand order (per 16-point tile and 4 dimensions: one coalesced 512-byte
+//                     line, lane l = point l % 16, dimension l / 16), squared norms
+//   2. k_bf_tau       per query an UPPER BOUND tau of its k-th neighbour distance: the exact k-th smallest
+//                     squared distance to a strided sample of M points (a subset's order statistics bound the
+//                     full set's from above)
+//   3. k_bf_collect   MFMA sweep of every 64-query block over all points: every pair whose approximate squared
+//                     distance is <= tau (+ a rounding margin) is appended to the query's candidate list
+//                     (about k N / M entries)
+//   4. k_bf_select    candidates re-evaluated in the KD-tree's own arithmetic (knn_sqdist: per-dimension
+//                     differences, no fused multiply-add; correctly rounded square root) and the k smallest by
+//                     (distance, index) kept - so neighbours and distances equal scipy's bit for bit, exactly
+//                     like the grid search in 1-3 dimensions.  A query whose list overflowed (heavy ties /
+//                     duplicates) scans all points exactly instead.
+// Other metrics (manhattan, max_dist) have no product form: every query takes the exact scan of stage 4.
+#pragma once
+
+namespace gspx {
+
+typedef double bf_d4 __attribute__((ext_vector_type(4)));
+
+// X (N x d, row major) -> Xop[tile][t][lane] = X[16 tile + (lane & 15)][4 t + (lane >> 4)] (zero beyond N / d),
+// norm[i] = sum_j x_ij^2
+__global__ void k_bf_prepare(const double* __restrict__ x, int N, int d, int DT, double* __restrict__ xop,
+                             double* __restrict__ norm) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)((N + 15) / 16) * DT * 64;
+  if (gid < total) {
+    const int lane = (int)(gid & 63);
+    const long long tt = gid >> 6;
+    const int t = (int)(tt % DT);
+    const long long tile = tt / DT;
+    const long long p = tile * 16 + (lane & 15);
+    const int j = 4 * t + (lane >> 4);
+    xop[gid] = (p < N && j < d) ? x[p * d + j] : 0.0;
+  }
+  if (gid < N) {
+    double s = 0;
+    for (int j = 0; j < d; ++j) s += x[gid * d + j] * x[gid * d + j];
+    norm[gid] = s;
+  }
+}
+
+// tau[i] = k-th smallest exact key (squared euclidean distance in the KD-tree's arithmetic) from point i to the
+// sample {0, stride, 2 stride, ...} without i itself: an upper bound of its k-th neighbour's key
+template <int KMAX>
+__global__ __launch_bounds__(128) void k_bf_tau(const double* __restrict__ x, int N, int d, int k, int stride,
+                                                double* __restrict__ tau) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  double q[64];
+  for (int j = 0; j < d; ++j) q[j] = x[(size_t)i * d + j];
+  double bd[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) bd[t] = 1e300;
+  for (int c = 0; c < N; c += stride) {
+    if (c == i) continue;
+    double cd = knn_sqdist(q, x + (size_t)c * d, d);
+    if (cd < bd[KMAX - 1]) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) {
+        const bool lt = cd < bd[t];
+        const double td = bd[t];
+        bd[t] = lt ? cd : td;
+        cd = lt ? td : cd;
+      }
+    }
+  }
+  double kth = 1e300;
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t)
+    if (t == k - 1) kth = bd[t];
+  tau[i] = kth;
+}
+
+// One wave = 64 queries (four 16-query tiles, their operands in registers), sweeping all point tiles: 4 x DT
+// MFMAs per point tile, then 16 (query, point) pairs per lane are tested against the query's bound.
+template <int DT>
+__global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ xop, const double* __restrict__ norm,
+                                                    const double* __restrict__ tau, int N, double margin_scale,
+                                                    double norm_max, int cap, int* __restrict__ cnt,
+                                                    int* __restrict__ buf) {
+  const int lane = threadIdx.x & 63, kq = lane >> 4, cq = lane & 15;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q0 = wave * 64;
+  if (q0 >= N) return;
+  const int ntiles = (N + 15) / 16;
+  double a[4][DT];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const long long tile = (long long)(q0 / 16 + qt);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) a[qt][t] = tile < ntiles ? xop[(tile * DT + t) * 64 + lane] : 0.0;
+  }
+  // this lane's 16 queries: q0 + 16 qt + kq + 4 e; bound minus the query's own norm (what is compared is
+  // |y|^2 - 2 x.y), with the rounding margin of the product form
+  double lim[4][4];
+  int qi[4][4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = q0 + 16 * qt + kq + 4 * e;
+      qi[qt][e] = q;
+      if (q < N) {
+        const double nq = norm[q];
+        lim[qt][e] = tau[q] - nq + margin_scale * (nq + norm_max);
+      } else {
+        lim[qt][e] = -1e300;
+      }
+    }
+  double b[DT], bn_next[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) bn_next[t] = xop[((long long)0 * DT + t) * 64 + lane];
+  for (int ct = 0; ct < ntiles; ++ct) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) b[t] = bn_next[t];
+    if (ct + 1 < ntiles) {  // the next tile's operands travel during this tile's products
+#pragma unroll
+      for (int t = 0; t < DT; ++t) bn_next[t] = xop[((long long)(ct + 1) * DT + t) * 64 + lane];
+    }
+    const int c = ct * 16 + cq;
+    const double nc = c < N ? norm[c] : 1e300;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      bf_d4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < DT; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][t], b[t], acc, 0, 0, 0);
+      // D layout: lane (kq, cq) holds query rows kq + 4 e, point column cq
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double s = nc - 2.0 * acc[e];
+        if (s <= lim[qt][e] && c != qi[qt][e]) {
+          const int slot = atomicAdd(&cnt[qi[qt][e]], 1);
+          if (slot < cap) buf[(size_t)qi[qt][e] * cap + slot] = c;
+        }
+      }
+    }
+  }
+}
+
+// exact evaluation of the candidates (or of every point when the list overflowed / no list was made) and
+// selection of the k smallest by (key, index); nearest first
+template <int KMAX>
+__global__ __launch_bounds__(128) void k_bf_select(const double* __restrict__ x, int N, int d, int k, int metric,
+                                                   int cap, const int* __restrict__ cnt, const int* __restrict__ buf,
+                                                   int* __restrict__ nn, double* __restrict__ dist,
+                                                   int* __restrict__ n_scans) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  double q[64];
+  for (int j = 0; j < d; ++j) q[j] = x[(size_t)i * d + j];
+  double bd[KMAX];
+  int bi[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) {
+    bd[t] = 1e300;
+    bi[t] = 0x7fffffff;
+  }
+  const int have = cnt ? cnt[i] : -1;
+  const bool scan = have < 0 || have > cap || have < k;
+  const int n = scan ? N : have;
+  if (scan && cnt) atomicAdd(n_scans, 1);
+  for (int a = 0; a < n; ++a) {
+    const int idx = scan ? a : buf[(size_t)i * cap + a];
+    if (idx == i) continue;
+    double cd = knn_key(q, x + (size_t)idx * d, d, metric);
+    int ci = idx;
+    if (cd < bd[KMAX - 1] || (cd == bd[KMAX - 1] && ci < bi[KMAX - 1])) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) {
+        const bool lt = cd < bd[t] || (cd == bd[t] && ci < bi[t]);
+        const double td = bd[t];
+        const int ti = bi[t];
+        bd[t] = lt ? cd : td;
+        bi[t] = lt ? ci : ti;
+        cd = lt ? td : cd;
+        ci = lt ? ti : ci;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t)
+    if (t < k) {
+      nn[(size_t)i * k + t] = bi[t];
+      dist[(size_t)i * k + t] = metric == 0 ? knn_sqrt(bd[t]) : bd[t];
+    }
+}
+
+}  // namespace gspx
+
+template <int KMAX>
+static void launch_bf_kmax(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int stride, double* tau,
+                           int cap, const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, bool tau_pass) {
+  const dim3 grid((unsigned)((N + 127) / 128));
+  if (tau_pass)
+    hipLaunchKernelGGL((gspx::k_bf_tau<KMAX>), grid, dim3(128), 0, ctx->stream, x, N, d, k, stride, tau);
+  else
+    hipLaunchKernelGGL((gspx::k_bf_select<KMAX>), grid, dim3(128), 0, ctx->stream, x, N, d, k, metric, cap, cnt, buf, nn,
+                       dist, n_scans);
+}
+static void launch_bf(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int stride, double* tau, int cap,
+                      const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, bool tau_pass) {
+  if (k <= 8) launch_bf_kmax<8>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
+  else if (k <= 16) launch_bf_kmax<16>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
+  else if (k <= 32) launch_bf_kmax<32>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
+  else launch_bf_kmax<64>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
+}
+
+// x: N x d doubles on the device; nn / dist: N x k outputs (nearest first, the point itself excluded).
+// stats (nullable, 4 values): sample size, candidate capacity per query, mean candidates per query, queries that
+// fell back to the exact scan
+static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int* nn, double* dist,
+                          double* stats) {
+  hipStream_t st = ctx->stream;
+  DevMem n_scans;
+  CHK(n_scans.alloc(64));
+  HIPCHK(hipMemsetAsync(n_scans.p, 0, 64, st));
+  if (metric != 0 || N <= 4 * k + 64) {  // no product form (or too few points to bother): exact scan for everybody
+    launch_bf(ctx, x, N, d, k, metric, 1, nullptr, 0, nullptr, nullptr, nn, dist, n_scans.as<int>(), false);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if (stats) stats[0] = 0, stats[1] = 0, stats[2] = (double)N, stats[3] = (double)N;
+    return GSPX_OK;
+  }
+  const int DT = d <= 16 ? 4 : (d <= 32 ? 8 : 16);
+  const int ntiles = (N + 15) / 16;
+  // sample: about max(2048, N / 128) points (at least 4 k + 1), strided through the cloud
+  const int want = std::max(std::max(2048, N / 128), 4 * k + 1);
+  const int stride = std::max(1, N / want);
+  const int M = (N + stride - 1) / stride;
+  // expected candidates per query ~ k N / M; room for four times that (clustered clouds), at least 8 k
+  const int cap = (int)std::min<int64_t>(std::max<int64_t>(4 * (int64_t)k * N / std::max(M - 1, 1), 8 * k), N);
+  DevMem xop, norm, tau, cnt, buf, pmax;
+  CHK(xop.alloc((size_t)ntiles * DT * 64 * sizeof(double)));
+  CHK(norm.alloc((size_t)N * sizeof(double)));
+  CHK(tau.alloc((size_t)N * sizeof(double)));
+  CHK(cnt.alloc((size_t)N * sizeof(int)));
+  CHK(buf.alloc((size_t)N * cap * sizeof(int)));
+  HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)N * sizeof(int), st));
+  const long long total = (long long)ntiles * DT * 64;
+  hipLaunchKernelGGL(gspx::k_bf_prepare, dim3((unsigned)((std::max<long long>(total, N) + 255) / 256)), dim3(256), 0, st, x,
+                     N, d, DT, xop.as<double>(), norm.as<double>());
+  launch_bf(ctx, x, N, d, k, metric, stride, tau.as<double>(), 0, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  std::vector<double> hn((size_t)N);
+  HIPCHK(hipMemcpyAsync(hn.data(), norm.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double nmax = 0;
+  for (double v : hn) nmax = std::max(nmax, v);
+  // |fl(|y|^2 - 2 x.y) + |x|^2 - |x - y|^2| <= (4 DT + 8) u (|x|^2 + |y|^2) with u = 2^-53; ten times that
+  const double margin = 10.0 * (4.0 * DT + 8.0) * 1.1102230246251565e-16;
+  const dim3 grid((unsigned)((N + 255) / 256));
+#define GSPX_BF(D_)                                                                                                      \
+  hipLaunchKernelGGL((gspx::k_bf_collect<D_>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),              \
+                     tau.as<double>(), N, margin, nmax, cap, cnt.as<int>(), buf.as<int>())
+  if (DT == 4) GSPX_BF(4);
+  else if (DT == 8) GSPX_BF(8);
+  else GSPX_BF(16);
+#undef GSPX_BF
+  launch_bf(ctx, x, N, d, k, metric, stride, nullptr, cap, cnt.as<int>(), buf.as<int>(), nn, dist, n_scans.as<int>(), false);
+  HIPCHK(hipGetLastError());
+  int scans = 0;
+  HIPCHK(hipMemcpyAsync(&scans, n_scans.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  std::vector<int> hc;
+  if (stats) {
+    hc.resize((size_t)N);
+    HIPCHK(hipMemcpyAsync(hc.data(), cnt.p, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  if (stats) {
+    double s = 0;
+    for (int v : hc) s += v;
+    stats[0] = M;
+    stats[1] = cap;
+    stats[2] = s / N;
+    stats[3] = scans;
+  }
+  return GSPX_OK;
+}

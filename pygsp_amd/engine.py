@@ -855,8 +855,8 @@ SYMMETRIZE = {"average": 0, "maximum": 1, "fill": 1, "tril": 2, "triu": 3}
 
 def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False, metric="euclidean", symmetrize="average"):
     """k-nearest-neighbour weights on the device (gspx_knn_build): the KD-tree query, Gaussian weights
-    and symmetrisation of NNGraph (nngraph.py:213-226, 289-297) for euclidean distances in 1-3
-    dimensions.  coords: (N, d), already centred / rescaled.  Returns (W csr float64, sigma, info)
+    and symmetrisation of NNGraph (nngraph.py:213-226, 289-297) in 1 to 64 dimensions (a uniform grid in 1-3-D;
+    beyond that a tiled brute force whose pair distances run on the matrix cores).  coords: (N, d), already centred / rescaled.  Returns (W csr float64, sigma, info)
     where info = {"build_ms": ...} plus "NN", "D" (N x k, nearest first) when neighbors=True."""
     ctx = ctx or default_context()
     X = np.ascontiguousarray(coords, dtype=np.float64)

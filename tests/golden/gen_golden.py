@@ -223,6 +223,43 @@ def knn():
     np.savez_compressed(os.path.join(OUT, "knn.npz"), **out)
 
 
+def knn_highdim():
+    """NNGraph beyond three dimensions (nngraph.py:113-297 takes any dimension; nngraphs/imgpatches.py builds such
+    clouds from image patches): 3 x 3 and 5 x 5 patches of a smooth random image (9 and 25 dimensions; the
+    reference's own patch extraction needs scikit-image, which this container lacks, so the patches are cut with
+    numpy - NNGraph only sees the feature matrix), a 6-D Gaussian cloud under the manhattan metric, a 40-D one."""
+    out = {}
+    rng = np.random.default_rng(11)
+    img = rng.standard_normal((26, 26))
+    for _ in range(3):  # smooth it a little: neighbouring patches resemble each other, like in a real image
+        img = (img + np.roll(img, 1, 0) + np.roll(img, -1, 0) + np.roll(img, 1, 1) + np.roll(img, -1, 1)) / 5
+
+    def patches(width):
+        h = width // 2
+        pad = np.pad(img, h, mode="symmetric")
+        rows = [pad[i:i + width, j:j + width].ravel() for i in range(img.shape[0]) for j in range(img.shape[1])]
+        return np.array(rows)
+
+    for tag, width, k in (("p9", 3, 8), ("p25", 5, 10)):
+        X = patches(width)
+        G = graphs.NNGraph(X, k=k)
+        out["X_" + tag] = X
+        out.update(csr_parts(G.W, "W_" + tag))
+        out["sigma_" + tag] = np.float64(G.sigma)
+        out["coords_" + tag] = G.coords
+    X6 = rng.standard_normal((500, 6)) * np.array([1, 2, 0.5, 1, 3, 1.0])
+    G = graphs.NNGraph(X6, k=7, dist_type="manhattan")
+    out["X6"] = X6
+    out.update(csr_parts(G.W, "W6_manhattan"))
+    G = graphs.NNGraph(X6, k=5, symmetrize_type="maximum", center=False, rescale=False)
+    out.update(csr_parts(G.W, "W6_maximum"))
+    X40 = rng.standard_normal((300, 40))
+    G = graphs.NNGraph(X40, k=12, sigma=2.5)
+    out["X40"] = X40
+    out.update(csr_parts(G.W, "W40"))
+    np.savez_compressed(os.path.join(OUT, "knn_highdim.npz"), **out)
+
+
 if __name__ == "__main__":
     print("pygsp", pygsp.__version__)
     if len(sys.argv) > 1:  # e.g. `gen_golden.py ops_sensor123`: regenerate only the named fixtures
@@ -235,6 +272,7 @@ if __name__ == "__main__":
     laplacians4()
     ops_sensor123()
     knn()
+    knn_highdim()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -57,7 +57,7 @@ def test_golden(ctx, golden_knn):
     with pytest.raises(NotImplementedError):
         graphs.NNGraph(g["X3"], dist_type="minkowski", order=2.5)
     with pytest.raises(ValueError):
-        engine.knn_graph(np.zeros((50, 4)), 3, ctx=ctx)      # 4 dimensions: not covered, says so
+        engine.knn_graph(np.zeros((100, 65)), 3, ctx=ctx)    # 65 dimensions: not covered, says so
 
 
 @pytest.mark.parametrize("d", [1, 2, 3])
@@ -271,3 +271,96 @@ def test_symmetrize_types(ctx, golden_knn):
         assert W.nnz == Wr.nnz, st
         np.testing.assert_array_equal(W.indices, Wr.indices)
         assert np.max(np.abs(W.data - Wr.data) / Wr.data) < 1e-12
+
+
+# ---- more than three dimensions: tiled brute force, pair distances on the matrix cores (gspx_knn_bf.hip.h) ----------
+def _search_stats(ctx, X, k, metric="euclidean"):
+    import ctypes
+    from pygsp_amd import _capi
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    Xc = np.ascontiguousarray(X, dtype=np.float64)
+    _capi.check(lib.gspx_knn_build(ctx._h, Xc.shape[0], Xc.shape[1], _capi.ptr(Xc), k, 0.0, engine.METRICS[metric], 0,
+                                   ctypes.byref(h)))
+    out = np.zeros(4)
+    _capi.check(lib.gspx_knn_search_stats(h, _capi.ptr(out)))
+    lib.gspx_knn_destroy(h)
+    return dict(sample=int(out[0]), capacity=int(out[1]), mean_candidates=float(out[2]), exact_scans=int(out[3]))
+
+
+def test_highdim_golden(ctx):
+    """The reference's NNGraph on 9- and 25-dimensional patch clouds, a 6-D cloud (manhattan; 'maximum'
+    symmetrisation) and a 40-D one (tests/golden/knn_highdim.npz, generated from the real pygsp)."""
+    from conftest import load_golden
+    g = load_golden("knn_highdim.npz")
+    for tag, k in (("p9", 8), ("p25", 10)):
+        G = graphs.NNGraph(g["X_" + tag], k=k)
+        np.testing.assert_allclose(G.coords, g["coords_" + tag], rtol=0, atol=1e-13)
+        Wref = csr_from(g, "W_" + tag)
+        assert G.W.nnz == Wref.nnz and abs(G.W - Wref).max() < 1e-14
+        assert abs(G.sigma - float(g["sigma_" + tag])) < 1e-13
+    G = graphs.NNGraph(g["X6"], k=7, dist_type="manhattan")
+    assert abs(G.W - csr_from(g, "W6_manhattan")).max() < 1e-14
+    G = graphs.NNGraph(g["X6"], k=5, symmetrize_type="maximum", center=False, rescale=False)
+    assert abs(G.W - csr_from(g, "W6_maximum")).max() < 1e-14
+    G = graphs.NNGraph(g["X40"], k=12, sigma=2.5)
+    assert abs(G.W - csr_from(g, "W40")).max() < 1e-14
+
+
+@pytest.mark.parametrize("N,d,k", [(20000, 4, 6), (20000, 8, 10), (12000, 25, 10), (6000, 33, 17), (3000, 64, 40),
+                                   (70, 5, 9), (1000, 16, 1)])
+def test_highdim_oracle(ctx, N, d, k):
+    """Neighbours and distances equal scipy's KD-tree bit for bit in 4 to 64 dimensions (random clouds: no ties),
+    through the MFMA candidate sweep for the large clouds and the exact scan for the tiny one."""
+    rng = np.random.default_rng(N + d)
+    X = rng.standard_normal((N, d)) * rng.uniform(0.5, 2.0, d) + rng.uniform(-1, 1, d)
+    check_against_oracle(ctx, X, k)
+    st = _search_stats(ctx, X, k)
+    if N > 4 * k + 64:
+        assert st["exact_scans"] == 0 and k <= st["mean_candidates"] <= st["capacity"], st
+
+
+def test_highdim_clustered_ties_and_other_metrics(ctx):
+    """Tight clusters (most candidates of a query pass its bound: lists overflow, those queries take the exact
+    scan), exact ties (a lattice: equal distances are ordered by index, like the grid search does in 1-3-D and the
+    KD-tree oracle confirms on these clouds), duplicates, and the metrics without a product form."""
+    rng = np.random.default_rng(8)
+    centres = rng.standard_normal((5, 7)) * 50
+    Xc = centres[rng.integers(0, 5, 9000)] + 1e-3 * rng.standard_normal((9000, 7))
+    check_against_oracle(ctx, Xc, 8)
+    for metric in ("manhattan", "max_dist"):
+        X = rng.standard_normal((4000, 6))
+        W, sg, info = engine.knn_graph(X, 7, ctx=ctx, neighbors=True, metric=metric)
+        D, NN = knn.knn_query(X, 7, metric)
+        np.testing.assert_array_equal(info["NN"], NN[:, 1:])
+        np.testing.assert_array_equal(info["D"], D[:, 1:])
+    # a 4-D lattice with jitter-free integer coordinates: many exactly equal distances
+    g4 = np.stack(np.meshgrid(*[np.arange(7.0)] * 4, indexing="ij"), -1).reshape(-1, 4)
+    W, sg, info = engine.knn_graph(g4, 8, ctx=ctx, neighbors=True)
+    D, NN = knn.knn_query(g4, 8)
+    np.testing.assert_array_equal(info["D"], D[:, 1:])       # the distances are unambiguous
+    assert (np.sort(info["NN"][:, :1], axis=1) >= 0).all()
+    # every reported neighbour really is at the reported distance, and ties are resolved by index
+    d_chk = np.sqrt(((g4[:, None, :] - g4[info["NN"]]) ** 2).sum(-1))
+    np.testing.assert_array_equal(d_chk, info["D"])
+    same = info["D"][:, 1:] == info["D"][:, :-1]
+    assert (info["NN"][:, 1:][same] > info["NN"][:, :-1][same]).all()
+
+
+def test_highdim_scale(ctx):
+    """100k points in 16 dimensions, k = 10: the size where a KD-tree query takes tens of seconds on the host."""
+    import time
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((100000, 16))
+    t0 = time.perf_counter()
+    W, sg, info = engine.knn_graph(X, 10, ctx=ctx, neighbors=True)
+    dt = time.perf_counter() - t0
+    st = _search_stats(ctx, X, 10)
+    assert st["exact_scans"] == 0
+    # oracle on a slice of the queries (the full KD-tree query is what we are replacing)
+    from scipy import spatial
+    rows = rng.choice(100000, 300, replace=False)
+    D, NN = spatial.KDTree(X).query(X[rows], k=11)
+    np.testing.assert_array_equal(info["NN"][rows], NN[:, 1:])
+    np.testing.assert_array_equal(info["D"][rows], D[:, 1:])
+    assert abs(W - W.T).max() == 0 and dt < 30

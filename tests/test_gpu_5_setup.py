@@ -53,7 +53,8 @@ def test_device_setup_equals_host_route(ctx, dtype):
     assert rep["locality_curve"] > rep["locality_own"] + 0.05
     assert not G.is_directed() and G.n_edges == W.nnz // 2 and G.N == 50000
     L = orc.laplacian(W).astype(dtype)
-    assert _same_csr(G.L, L) if dtype == np.float64 else abs(G.L - L).max() < 1e-6
+    # (float32: the device sums a row's weights in float32, the oracle in float64 and then rounds)
+    assert _same_csr(G.L, L) if dtype == np.float64 else abs(G.L - L).max() < 5e-6
     assert np.array_equal(G._internal_order(), engine.auto_order(W, coords, ctx=ctx))
     # the host route on the same matrix (a COO input does not qualify for the fast path)
     H = graphs.Graph(sparse.coo_matrix(W), coords=coords, compute_dtype=dtype)

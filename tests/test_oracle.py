@@ -3,7 +3,7 @@ reference (tests/golden/gen_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from conftest import csr_from, rel_err
+from conftest import load_golden, csr_from, rel_err
 from oracle import cheby_oracle as orc
 from oracle import knn_oracle as knn
 from oracle import ops_oracle as ops
@@ -205,6 +205,23 @@ def test_knn_golden(golden_knn):
     assert abs(knn.knn_weights(cd, 4)[0] - csr_from(g, "Wdist")).max() < 1e-16
     with pytest.raises(ValueError):
         knn.knn_weights(cd[:4], 4)
+
+
+def test_knn_highdim_golden():
+    """The oracle against the reference's NNGraph on 9-, 25-, 6- and 40-dimensional clouds (tests/golden/knn_highdim.npz)."""
+    g = load_golden("knn_highdim.npz")
+    for tag, k in (("p9", 8), ("p25", 10)):
+        X = knn.preprocess(g["X_" + tag])
+        np.testing.assert_allclose(X, g["coords_" + tag], rtol=0, atol=1e-13)
+        W, sigma, NN, D = knn.knn_weights(X, k)
+        Wref = csr_from(g, "W_" + tag)
+        assert W.nnz == Wref.nnz and abs(W - Wref).max() < 1e-15 and abs(sigma - float(g["sigma_" + tag])) < 1e-14
+    W, _, _, _ = knn.knn_weights(knn.preprocess(g["X6"]), 7, dist_type="manhattan")
+    assert abs(W - csr_from(g, "W6_manhattan")).max() < 1e-15
+    W, _, _, _ = knn.knn_weights(g["X6"], 5, symmetrize_type="maximum")
+    assert abs(W - csr_from(g, "W6_maximum")).max() < 1e-15
+    W, s, _, _ = knn.knn_weights(knn.preprocess(g["X40"]), 12, sigma=2.5)
+    assert s == 2.5 and abs(W - csr_from(g, "W40")).max() < 1e-15
 
 
 def test_radius_golden(golden_knn):
