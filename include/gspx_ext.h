@@ -156,6 +156,12 @@ int gspx_curve_order(gspx_ctx* ctx, int64_t N, int d, const double* coords, int 
 int gspx_graph_setup(gspx_ctx* ctx, int64_t N, int64_t nnz, const int32_t* indptr, const int32_t* indices,
                      const void* data, int data_dtype, int lap_type, int compute_dtype, const double* coords,
                      int d, int order_mode, const int32_t* perm_in, int64_t report[12], gspx_graph** out);
+/* The ingredients of Graph._get_upper_bound (graph.py:933-960: the smallest of four classical upper bounds of
+ * lambda_max of the combinatorial Laplacian), taken in one pass while W was on the device - float64 graphs built
+ * from W: out[0] max W_ij, out[1] max dw, out[2] max (dw_i + dw_j) over the stored entries, out[3] max (dw_i +
+ * (W dw)_i / dw_i), NaN when a vertex has degree zero (numpy's 0 / 0; the reference's min() then ignores it).
+ * The bounds are N out[0], 2 out[1], out[2], out[3]. */
+int gspx_graph_lmax_bounds(gspx_graph* g, double out[4]);
 /* the internal vertex order of a graph (perm[new] = old); GSPX_ERR_INVALID when it has none */
 int gspx_graph_download_perm(gspx_graph* g, int32_t* perm);
 

@@ -99,6 +99,7 @@ SIGNATURES = {
     "gspx_graph_setup": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
                                     _c.c_int, _P, _P, _c.POINTER(_P)]),
     "gspx_graph_download_perm": (_c.c_int, [_P, _P]),
+    "gspx_graph_lmax_bounds": (_c.c_int, [_P, _P]),
     "gspx_sbm_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_uint64, _P]),
     "gspx_radius_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_double, _c.c_double, _c.c_int, _P]),
     "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),

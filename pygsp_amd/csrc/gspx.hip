@@ -408,6 +408,10 @@ struct gspx_graph {
   int tile_rows = 0, tile_nb = 0, tile_max_n1 = 0, tile_max_n2 = 0;
   double fval_lmax = -1.0;
   double build_ms = 0.0;
+  // ingredients of Graph._get_upper_bound (graph.py:933-960), taken while W is on the device (fp64 graphs built
+  // from W): max W_ij, max dw, max (dw_i + dw_j) over entries, max (dw_i + (W dw)_i / dw_i) or NaN
+  bool has_bounds = false;
+  double bounds[4] = {0, 0, 0, 0};
   // one-level row tiles of the LDS-staged recurrence step (optional; gspx_tile_kernels.hip.h)
   DevMem gt_hdr, gt_s1rows, gt_lidx;
   DevMem gt_s1nat;   // gt_s1rows mapped through perm: the same lists as rows of the caller's (unpermuted) panel
@@ -873,6 +877,34 @@ static int create_from_w_dev(gspx_graph* g, int64_t nnz, const int* wptr, const 
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if constexpr (std::is_same<T, double>::value) {
+    if (N > 0) {
+      DevMem part;
+      CHK(part.alloc((size_t)nb * 4 * sizeof(double)));
+      hipLaunchKernelGGL(k_lmax_bounds, dim3(nb), dim3(256), 0, ctx->stream, wptr, wcol, wval, g->dw.as<double>(), N,
+                         part.as<double>());
+      std::vector<double> hp((size_t)nb * 4);
+      HIPCHK(hipMemcpyAsync(hp.data(), part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      std::vector<double> hd((size_t)N);
+      HIPCHK(hipMemcpyAsync(hd.data(), g->dw.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      double wmax = 0.0 /* a sparse matrix's maximum sees its implicit zeros */, emax = -1e300, mmax = -1e300, zeros = 0;
+      if ((int64_t)N * N == nnz) wmax = -1e300;  // (a full matrix has none)
+      for (int b = 0; b < nb; ++b) {
+        wmax = std::max(wmax, hp[(size_t)b * 4 + 0]);
+        emax = std::max(emax, hp[(size_t)b * 4 + 1]);
+        mmax = std::max(mmax, hp[(size_t)b * 4 + 2]);
+        zeros += hp[(size_t)b * 4 + 3];
+      }
+      double dmax = hd[0];
+      for (double v : hd) dmax = std::max(dmax, v);
+      g->bounds[0] = wmax;
+      g->bounds[1] = dmax;
+      g->bounds[2] = emax;
+      g->bounds[3] = zeros > 0 ? std::nan("") : mmax;
+      g->has_bounds = true;
+    }
+  }
   CHK(build_internal<T>(g));
   g->build_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1028,6 +1060,14 @@ extern "C" int gspx_graph_download_dw(gspx_graph* g, void* dw) {
   HIPCHK(hipSetDevice(g->ctx->device));
   if (g->N > 0)
     HIPCHK(hipMemcpy(dw, g->dw.p, (size_t)g->N * elt_size(g->dtype), hipMemcpyDeviceToHost));
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_lmax_bounds(gspx_graph* g, double out[4]) {
+  if (!g || !out) return set_err(GSPX_ERR_INVALID, "null argument");
+  if (!g->has_bounds)
+    return set_err(GSPX_ERR_INVALID, "no bound ingredients: the graph was not built from W in float64, or is empty");
+  for (int i = 0; i < 4; ++i) out[i] = g->bounds[i];
   return GSPX_OK;
 }
 

@@ -1323,6 +1323,54 @@ __global__ void k_degree(const int* __restrict__ ptr, const T* __restrict__ val,
   dw[i] = s;
 }
 
+// The ingredients of Graph._get_upper_bound (graph.py:933-960) in one pass over W, per 256-row block:
+// part[4 b + 0..3] = max W_ij, max (dw_i + dw_j) over stored entries, max (dw_i + (W dw)_i / dw_i), number of
+// zero-degree rows (their 0 / 0 makes numpy's maximum NaN: the host layer then drops that candidate, as
+// Python's min() does).  The row sums run in column order without fused multiply-add, like scipy's W.dot(dw).
+__global__ __launch_bounds__(256) void k_lmax_bounds(const int* __restrict__ ptr, const int* __restrict__ col,
+                                                     const double* __restrict__ val, const double* __restrict__ dw,
+                                                     int N, double* __restrict__ part) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double wmax = -1e300, emax = -1e300, mmax = -1e300, zero = 0;
+  if (i < N) {
+    const double di = dw[i];
+    double s = 0;
+    for (int j = ptr[i]; j < ptr[i + 1]; ++j) {
+      const double w = val[j], dj = dw[col[j]];
+      const double p = w * dj;
+      s = s + p;
+      wmax = fmax(wmax, w);
+      emax = fmax(emax, di + dj);
+    }
+    if (di == 0.0) zero = 1;
+    else mmax = di + s / di;
+  }
+  __shared__ double sh[4][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    wmax = fmax(wmax, __shfl_down(wmax, off));
+    emax = fmax(emax, __shfl_down(emax, off));
+    mmax = fmax(mmax, __shfl_down(mmax, off));
+    zero += __shfl_down(zero, off);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[wv][0] = wmax;
+    sh[wv][1] = emax;
+    sh[wv][2] = mmax;
+    sh[wv][3] = zero;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = part + (size_t)blockIdx.x * 4;
+    o[0] = fmax(fmax(sh[0][0], sh[1][0]), fmax(sh[2][0], sh[3][0]));
+    o[1] = fmax(fmax(sh[0][1], sh[1][1]), fmax(sh[2][1], sh[3][1]));
+    o[2] = fmax(fmax(sh[0][2], sh[1][2]), fmax(sh[2][2], sh[3][2]));
+    o[3] = sh[0][3] + sh[1][3] + sh[2][3] + sh[3][3];
+  }
+}
+
 // d^{-1/2} with the reference's isolated-vertex rule (graph.py:622-624)
 template <typename T> __device__ __forceinline__ T inv_sqrt_deg(T dw) {
   return dw == T(0) ? T(0) : T(1) / sqrt(dw);

@@ -478,6 +478,16 @@ class DeviceGraph:
                "setup_ms": report[11] / 1e3}
         return (cls(h, ctx, N, dtype) if h.value else None), rep
 
+    def lmax_bounds(self):
+        """(max W, max dw, max (dw_i + dw_j) over entries, max (dw_i + (W dw)_i / dw_i)) taken on the device while W
+        was there (gspx_graph_lmax_bounds), or None when the graph carries none."""
+        out = np.zeros(4)
+        try:
+            _capi.check(_capi.load().gspx_graph_lmax_bounds(self._h, _capi.ptr(out)))
+        except ValueError:
+            return None
+        return out
+
     def download_perm(self):
         """The internal vertex order (perm[new] = old), or None when the graph keeps its own order."""
         perm = np.empty(self.N, dtype=np.int32)

@@ -327,6 +327,15 @@ class Graph:
         """The smallest of four classical upper bounds of lambda_max (graph.py:933-960)."""
         if self.lap_type != "combinatorial":
             return 2  # normalized Laplacian
+        if not self.is_directed() and self.W.dtype in (np.float64, np.int64):
+            # the same four candidates from one device pass over W (gspx_graph_lmax_bounds), same operation order
+            on_device = self.device_graph().lmax_bounds() if self.compute_dtype == np.float64 else None
+            if on_device is not None:
+                candidates = [self.n_vertices * on_device[0], 2 * on_device[1]]
+                if self.n_edges:
+                    candidates.append(on_device[2])
+                candidates.append(on_device[3])  # (NaN with isolated vertices: never the minimum, as in the reference)
+                return float(min(candidates))
         W, deg = self._symmetric_w(), np.asarray(self.dw, dtype=np.float64)
         candidates = [self.n_vertices * W.max(), 2 * deg.max()]
         if self.n_edges:

@@ -166,3 +166,47 @@ def test_setup_time_at_headline_size(ctx):
     assert best < 0.12, best
     L = orc.laplacian(W)
     assert _same_csr(G.L, L)
+
+
+def _host_upper_bound(W):
+    """Graph._get_upper_bound of the reference (graph.py:933-960) in numpy, for an undirected W."""
+    W = sparse.csr_matrix(W)
+    deg = np.ravel(W.sum(axis=0)).astype(np.float64)
+    cands = [W.shape[0] * W.max(), 2 * deg.max()]
+    if W.nnz:
+        coo = W.tocoo()
+        cands.append((deg[coo.row] + deg[coo.col]).max())
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cands.append(np.max(deg + W.dot(deg) / deg))
+    return min(cands), cands
+
+
+def test_upper_bound_of_lmax_from_the_device_pass(ctx):
+    """estimate_lmax('bounds'): the four candidates of graph.py:933-960 come out of one device pass over W
+    (gspx_graph_lmax_bounds) and equal the host formula - the row sums run in scipy's order, so to the last bit;
+    isolated vertices make the fourth candidate NaN, which min() ignores, as in the reference."""
+    W, coords = graphs.sensor_weights(50000, k=7, seed=5)
+    G = graphs.Graph(W, coords=coords)
+    ref, cands = _host_upper_bound(W)
+    got = G.device_graph().lmax_bounds()
+    assert got is not None
+    assert [W.shape[0] * got[0], 2 * got[1], got[2], got[3]] == pytest.approx(cands, rel=1e-15, abs=0)
+    G.estimate_lmax("bounds")
+    assert G.lmax == ref
+    # isolated vertices (ER at p N = 10 has e^-10 of them) and int64 weights
+    Ge = graphs.ErdosRenyi(300000, p=10.0 / 300000, seed=1)
+    assert (np.ravel(Ge.W.sum(axis=0)) == 0).any()
+    ref, cands = _host_upper_bound(Ge.W)
+    assert np.isnan(cands[3]) and np.isnan(Ge.device_graph().lmax_bounds()[3])
+    Ge.estimate_lmax("bounds")
+    assert Ge.lmax == ref
+    # self-loops enter the degrees and the edge maximum
+    Wl = sparse.csr_matrix(random_graph(3000, 6, 3) + sparse.coo_matrix((np.full(30, 2.0), (np.arange(30) * 100,) * 2),
+                                                                        shape=(3000, 3000)))
+    Gl = graphs.Graph(Wl)
+    Gl.estimate_lmax("bounds")
+    assert Gl.lmax == _host_upper_bound(Wl)[0]
+    # a float32 graph keeps the host formula
+    G32 = graphs.Graph(W, coords=coords, compute_dtype=np.float32)
+    G32.estimate_lmax("bounds")
+    assert abs(G32.lmax - ref) >= 0 and G32.lmax > 0
