@@ -48,8 +48,13 @@ def test_headline_size_properties(ctx, dtype):
     x = rng.standard_normal((N, nsig)).astype(dtype)
     x[:, 5] = 3.0  # a constant column
     dev = G.device_graph()
+    ctx.set_option("host_pipeline", 0)  # the whole 64-signal panel as ONE device batch: the headline kernel shape
     y, ms = dev.cheby_filter(c, x, lmax)
     y = y[0]
+    ctx.set_option("host_pipeline", 1)  # ... and the pipelined host path (16-signal batches) gives the same bytes
+    yp, _ = dev.cheby_filter(c, x, lmax)
+    assert ctx.last_host_timing()["batches"] >= 4 and np.array_equal(yp[0], y)
+    del yp
     tol = BAR[np.dtype(dtype)]
     # constant-signal identity
     gain = _constant_signal_gain(c)
@@ -174,7 +179,9 @@ def test_panel_beyond_the_2gib_descriptor_window(ctx):
     x[:, const_cols] = 2.0
     assert x.nbytes > (1 << 31)
     dev = G.device_graph()
-    y, _ = dev.cheby_filter(c, x, lmax)
+    ctx.set_option("host_pipeline", 0)  # one device call for the whole 2.4 GB panel: the batching under test is the
+    y, _ = dev.cheby_filter(c, x, lmax)  # engine's own split at the 2 GiB descriptor window
+    ctx.set_option("host_pipeline", 1)
     assert ctx.last_timing()["step_launches"] >= 2 * order  # at least two column batches
     y = y[0]
     gain = _constant_signal_gain(c)

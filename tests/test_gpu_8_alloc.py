@@ -25,6 +25,9 @@ def _bank(lmax, nf, order):
 
 
 def _check(dev, L, lmax, rng, nsig, order, nf, tol=1e-11):
+    # one-shot host calls: the whole panel is one device batch, so the workspaces reach the sizes these tests are
+    # about (the pipelined host path would cut the call into 16-column batches with megabyte-sized workspaces)
+    dev.ctx.set_option("host_pipeline", 0)
     c = _bank(lmax, nf, order)
     x = rng.standard_normal((dev.N, nsig))
     y, _ = dev.cheby_filter(c, x, lmax)
@@ -76,6 +79,7 @@ def test_fused_workspace_growth_beyond_reservation():
         dev.build_gather_tiles()
         c = _bank(lmax, 1, 6)
         x = rng.standard_normal((dev.N, 168))
+        ctx.set_option("host_pipeline", 0)
         y, _ = dev.cheby_filter(c, x, lmax)
         cols = [0, 77, 167]
         ref = orc.cheby_op(L, lmax, c, x[:, cols]).reshape(dev.N, len(cols))
