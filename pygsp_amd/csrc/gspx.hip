@@ -2498,11 +2498,14 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
     if (widths.size() >= 2) {
       if (!ctx->pipe) ctx->pipe = new HostPipe();
       replay_reset(ctx);
-      return g->dtype == GSPX_F32
-                 ? filter_host_pipelined<float>(g, lmax, Nf, M, coeffs, Nsig, (const float*)x_host, (float*)y_host,
-                                                mode, widths, threads, kernel_ms)
-                 : filter_host_pipelined<double>(g, lmax, Nf, M, coeffs, Nsig, (const double*)x_host,
-                                                 (double*)y_host, mode, widths, threads, kernel_ms);
+      const int rc = g->dtype == GSPX_F32
+                         ? filter_host_pipelined<float>(g, lmax, Nf, M, coeffs, Nsig, (const float*)x_host,
+                                                        (float*)y_host, mode, widths, threads, kernel_ms)
+                         : filter_host_pipelined<double>(g, lmax, Nf, M, coeffs, Nsig, (const double*)x_host,
+                                                         (double*)y_host, mode, widths, threads, kernel_ms);
+      if (rc != GSPX_HOSTPIPE_UNAVAILABLE) return rc;
+      // no pinned / device staging memory to be had: release what the attempt got and take the one-shot form
+      ctx->pipe->destroy();
     }
     if (ctx->pipe) ctx->pipe->timing[6] = 0;  // the last host call was not pipelined
   }

@@ -48,6 +48,8 @@ static inline void copy_rows(unsigned char* dst, size_t dpitch, const unsigned c
   }
 }
 
+#define GSPX_HOSTPIPE_UNAVAILABLE (-1) /* internal: the pipeline could not get its staging buffers */
+
 // `widths`: the signal columns of each batch, in order (they add up to Nsig)
 template <typename T>
 static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs, int64_t Nsig,
@@ -55,7 +57,10 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
                                  double* kernel_ms) {
   gspx_ctx* ctx = g->ctx;
   HostPipe& hp = *ctx->pipe;
-  CHK(hp.init());
+  if (hp.init() != GSPX_OK) {
+    (void)hipGetLastError();
+    return GSPX_HOSTPIPE_UNAVAILABLE;
+  }
   const int64_t N = g->N;
   const bool analysis = mode == GSPX_ANALYSIS;
   const int in_planes = analysis ? 1 : Nf, out_planes = analysis ? Nf : 1;
@@ -72,10 +77,12 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
   }
   const size_t in_cap = (size_t)in_planes * N * w * sizeof(T), out_cap = (size_t)out_planes * N * w * sizeof(T);
   for (int s = 0; s < 2; ++s) {
-    CHK(hp.pin_in[s].ensure(in_cap));
-    CHK(hp.pin_out[s].ensure(out_cap));
-    CHK(hp.dx[s].ensure(in_cap));
-    CHK(hp.dy[s].ensure(out_cap));
+    // (no staging memory - pinned or device - is not an error of the call: the caller falls back to the one-shot form)
+    if (hp.pin_in[s].ensure(in_cap) != GSPX_OK || hp.pin_out[s].ensure(out_cap) != GSPX_OK ||
+        hp.dx[s].ensure(in_cap) != GSPX_OK || hp.dy[s].ensure(out_cap) != GSPX_OK) {
+      (void)hipGetLastError();
+      return GSPX_HOSTPIPE_UNAVAILABLE;
+    }
   }
   const int P = std::max(1, nthreads), Q = std::max(1, nthreads);
   const auto wall0 = std::chrono::steady_clock::now();

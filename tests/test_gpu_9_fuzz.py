@@ -21,7 +21,8 @@ def test_fuzz_against_oracle(seed):
         _run(cases, rng, ctx)
     finally:
         for k, v in (("kernel", 0), ("tile_gather", 1), ("graph_launch", 2), ("xcd_remap", 1), ("alternate_sweep", 1),
-                     ("combine", 0), ("synthesis", 0), ("max_batch", 0)):
+                     ("combine", 0), ("synthesis", 0), ("max_batch", 0), ("host_pipeline", 1), ("host_batch", 0),
+                     ("host_edge", 0), ("host_threads", 0)):
             ctx.set_option(k, v)
 
 
@@ -48,7 +49,11 @@ def _run(cases, rng, ctx):
             (dev.build_gather_tiles if rng.integers(2) else dev.enable_gather_tiles)()
         opts = {"kernel": int(rng.choice([0, 0, 1, 2, 5, 5])), "tile_gather": int(rng.integers(2)), "graph_launch": int(rng.integers(3)),
                 "xcd_remap": int(rng.integers(2)), "alternate_sweep": int(rng.integers(2)), "combine": int(rng.integers(3)),
-                "synthesis": int(rng.integers(2)), "max_batch": int(rng.choice([0, 0, 0, 8, 20]))}
+                "synthesis": int(rng.integers(2)), "max_batch": int(rng.choice([0, 0, 0, 8, 20])),
+                # the host-array calls below: one-shot, or pipelined in column batches of any width / thread count
+                # (ragged and 1-column batches included: against the oracle, not bit for bit)
+                "host_pipeline": int(rng.choice([0, 1, 2, 2])), "host_batch": int(rng.choice([0, 1, 3, 4, 8, 16, 24])),
+                "host_edge": int(rng.choice([0, 0, 2, 8])), "host_threads": int(rng.choice([0, 1, 2, 5]))}
         for k, v in opts.items():
             ctx.set_option(k, v)
         nsig = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 17, 32, 33, 64, 100, 130]))
