@@ -67,6 +67,29 @@ def test_argument_errors_need_no_device():
     n = ctypes.c_int64()
     with pytest.raises(ValueError):
         _capi.check(lib.gspx_graph_n(None, ctypes.byref(n)))
+    # the round-3 entry points refuse null handles / outputs the same way (also run under ASan, tests/test_asan.py)
+    rep = np.zeros(12, dtype=np.int64)
+    h = ctypes.c_void_p()
+    ptr2 = np.array([0, 0], dtype=np.int32)
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_graph_setup(None, 1, 0, _capi.ptr(ptr2), None, None, _capi.F64, 0, _capi.F64, None, 0, 0, None,
+                                         _capi.ptr(rep), ctypes.byref(h)))
+    d4 = np.zeros(4)
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_graph_lmax_bounds(None, _capi.ptr(d4)))
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_graph_download_perm(None, None))
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_curve_order(None, 10, 2, _capi.ptr(np.zeros((10, 2))), 1, _capi.ptr(np.zeros(10, dtype=np.int32))))
+    ms, gb = ctypes.c_double(), ctypes.c_double()
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_bench_gather(None, 1000, 64, 1000, 8, 1, 0.0, 8, 1, ctypes.byref(ms), ctypes.byref(gb)))
+    d9 = (ctypes.c_double * 9)()
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_last_host_timing(None, d9))
+    with pytest.raises(ValueError):
+        _capi.check(lib.gspx_knn_search_stats(None, _capi.ptr(d4)))
+    assert lib.gspx_comm_destroy(None) == 0
 
 
 @pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7, 30, 31, 32, 50])
