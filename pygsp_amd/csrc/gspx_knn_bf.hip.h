@@ -28,7 +28,7 @@ namespace gspx {
 typedef double bf_d4 __attribute__((ext_vector_type(4)));
 
 // X (N x d, row major) -> Xop[tile][t][lane] = X[16 tile + (lane & 15)][4 t + (lane >> 4)] (zero beyond N / d),
-// norm[i] = sum_j x_ij^2
+// norm[i] = sum_j x_ij^2 (padded to whole tiles with 1e300)
 __global__ void k_bf_prepare(const double* __restrict__ x, int N, int d, int DT, double* __restrict__ xop,
                              double* __restrict__ norm) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -46,6 +46,8 @@ __global__ void k_bf_prepare(const double* __restrict__ x, int N, int d, int DT,
     double s = 0;
     for (int j = 0; j < d; ++j) s += x[gid * d + j] * x[gid * d + j];
     norm[gid] = s;
+  } else if (gid < (long long)((N + 15) / 16) * 16) {
+    norm[gid] = 1e300;  // the padding points of the last tile are infinitely far away
   }
 }
 
@@ -117,32 +119,50 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
         lim[qt][e] = -1e300;
       }
     }
-  double b[DT], bn_next[DT];
+  // Software pipeline: a tile's operands AND its norms are loaded one tile ahead, so no load issued in an
+  // iteration is waited for in that iteration (the first version loaded the norm at the top of the tile and
+  // paid an L2 round trip per tile: the matrix cores idled two thirds of the time).  The four query tiles'
+  // product chains are interleaved (four independent accumulators in flight, no stall on a chain's own result),
+  // and the 16 (query, point) tests of a lane are folded into one mask: a single wave-wide branch per tile
+  // guards the rare appends.  (The point itself is not filtered here: k_bf_select skips it.)
+  double b[DT], b_next[DT], n_next;
+  {
+    n_next = norm[cq];
 #pragma unroll
-  for (int t = 0; t < DT; ++t) bn_next[t] = xop[((long long)0 * DT + t) * 64 + lane];
+    for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)0 * DT + t) * 64 + lane];
+  }
   for (int ct = 0; ct < ntiles; ++ct) {
+    const double nc = n_next;
 #pragma unroll
-    for (int t = 0; t < DT; ++t) b[t] = bn_next[t];
-    if (ct + 1 < ntiles) {  // the next tile's operands travel during this tile's products
+    for (int t = 0; t < DT; ++t) b[t] = b_next[t];
+    if (ct + 1 < ntiles) {
+      n_next = norm[(ct + 1) * 16 + cq];  // (padded: no bounds test between the load and its use a tile later)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) bn_next[t] = xop[((long long)(ct + 1) * DT + t) * 64 + lane];
+      for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)(ct + 1) * DT + t) * 64 + lane];
     }
-    const int c = ct * 16 + cq;
-    const double nc = c < N ? norm[c] : 1e300;
+    bf_d4 acc[4];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      bf_d4 acc = {0, 0, 0, 0};
+    for (int qt = 0; qt < 4; ++qt) acc[qt] = bf_d4{0, 0, 0, 0};
 #pragma unroll
-      for (int t = 0; t < DT; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][t], b[t], acc, 0, 0, 0);
-      // D layout: lane (kq, cq) holds query rows kq + 4 e, point column cq
+    for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double s = nc - 2.0 * acc[e];
-        if (s <= lim[qt][e] && c != qi[qt][e]) {
-          const int slot = atomicAdd(&cnt[qi[qt][e]], 1);
-          if (slot < cap) buf[(size_t)qi[qt][e] * cap + slot] = c;
-        }
-      }
+      for (int qt = 0; qt < 4; ++qt) acc[qt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][t], b[t], acc[qt], 0, 0, 0);
+    // D layout: lane (kq, cq) holds query rows kq + 4 e, point column cq
+    unsigned hits = 0;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hits |= (nc - 2.0 * acc[qt][e] <= lim[qt][e]) ? (1u << (qt * 4 + e)) : 0u;
+    if (__builtin_amdgcn_ballot_w64(hits != 0) != 0) {
+      const int c = ct * 16 + cq;
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (hits & (1u << (qt * 4 + e))) {
+            const int slot = atomicAdd(&cnt[qi[qt][e]], 1);
+            if (slot < cap) buf[(size_t)qi[qt][e] * cap + slot] = c;
+          }
     }
   }
 }
@@ -238,10 +258,11 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   const int stride = std::max(1, N / want);
   const int M = (N + stride - 1) / stride;
   // expected candidates per query ~ k N / M; room for four times that (clustered clouds), at least 8 k
-  const int cap = (int)std::min<int64_t>(std::max<int64_t>(4 * (int64_t)k * N / std::max(M - 1, 1), 8 * k), N);
+  // (+ 1: the point itself passes its own bound and is skipped by the selection)
+  const int cap = (int)std::min<int64_t>(std::max<int64_t>(4 * (int64_t)k * N / std::max(M - 1, 1), 8 * k) + 1, N);
   DevMem xop, norm, tau, cnt, buf, pmax;
   CHK(xop.alloc((size_t)ntiles * DT * 64 * sizeof(double)));
-  CHK(norm.alloc((size_t)N * sizeof(double)));
+  CHK(norm.alloc((size_t)ntiles * 16 * sizeof(double)));
   CHK(tau.alloc((size_t)N * sizeof(double)));
   CHK(cnt.alloc((size_t)N * sizeof(int)));
   CHK(buf.alloc((size_t)N * cap * sizeof(int)));
