@@ -51,16 +51,29 @@ def device_graph_for(G, ctx=None):
         if (cached is not None and cached[0] is G.L and cached[1] is G.W and cached[2] == conf
                 and cached[4] is ctx and getattr(cached[3], "_h", None)):
             return cached[3]
-        perm = None
-        if _config["reorder"] == "auto" and G.N >= 4096:
-            perm = engine.auto_order(G.W, _finite_coords(G), ctx=ctx)
-        elif _config["reorder"] == "rcm":
-            perm = engine.locality_order(G.W, None)
-        if _config["laplacian"] == "device":
-            W = G.W if not G.is_directed() else sparse.csr_matrix((G.W + G.W.T) / 2)
-            dev = engine.DeviceGraph.from_w(W, G.lap_type, dtype=_config["dtype"], perm=perm, ctx=ctx)
-        else:  # bit-parity mode: upload the Laplacian the reference built
-            dev = engine.DeviceGraph.from_l(G.L, dtype=_config["dtype"], perm=perm, ctx=ctx)
+        dev = None
+        coords = _finite_coords(G)
+        order = _config["reorder"]
+        one_call = (_config["laplacian"] == "device" and sparse.isspmatrix_csr(G.W) and order in ("auto", "none", None, False)
+                    and not (order == "auto" and coords is None and G.N >= 4096))  # (no coordinates: RCM is host work)
+        if one_call:
+            # checks, directedness, vertex order and Laplacian in one device call on the uploaded G.W
+            # (gspx_graph_setup); a directed graph / explicit zeros come back as None and take the route below
+            try:
+                dev, _ = engine.DeviceGraph.setup(G.W, G.lap_type, _config["dtype"], coords, order, ctx=ctx)
+            except ValueError:
+                dev = None
+        if dev is None:
+            perm = None
+            if order == "auto" and G.N >= 4096:
+                perm = engine.auto_order(G.W, coords, ctx=ctx)
+            elif order == "rcm":
+                perm = engine.locality_order(G.W, None)
+            if _config["laplacian"] == "device":
+                W = G.W if not G.is_directed() else sparse.csr_matrix((G.W + G.W.T) / 2)
+                dev = engine.DeviceGraph.from_w(W, G.lap_type, dtype=_config["dtype"], perm=perm, ctx=ctx)
+            else:  # bit-parity mode: upload the Laplacian the reference built
+                dev = engine.DeviceGraph.from_l(G.L, dtype=_config["dtype"], perm=perm, ctx=ctx)
         if _config.get("tiles", "auto"):
             dev.auto_gather_tiles()
         cache[id(ctx)] = (G.L, G.W, conf, dev, ctx)
