@@ -12,9 +12,10 @@
 //   2. k_bf_tau       per query an UPPER BOUND tau of its k-th neighbour distance: the exact k-th smallest
 //                     squared distance to a strided sample of M points (a subset's order statistics bound the
 //                     full set's from above)
-//   3. k_bf_collect   MFMA sweep of every 64-query block over all points: every pair whose approximate squared
-//                     distance is <= tau (+ a rounding margin) is appended to the query's candidate list
-//                     (about k N / M entries)
+//   3. k_bf_collect   MFMA sweep of every 64-query block over the points: every pair whose approximate squared
+//                     distance is <= tau (+ a rounding margin) is appended to the query's candidate list.  Two
+//                     sweeps: a strided subset of sqrt(N M) points, then - after k_bf_refine tightened every bound to the
+//                     exact k-th smallest of the candidates so far - the rest: k (N1 / M + N / N1) entries per query
 //   4. k_bf_select    candidates re-evaluated in the KD-tree's own arithmetic (knn_sqdist: per-dimension
 //                     differences, no fused multiply-add; correctly rounded square root) and the k smallest by
 //                     (distance, index) kept - so neighbours and distances equal scipy's bit for bit, exactly
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(128) void k_bf_tau(const double* __restrict__ x, in
 // MFMAs per point tile, then 16 (query, point) pairs per lane are tested against the query's bound.
 template <int DT>
 __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ xop, const double* __restrict__ norm,
-                                                    const double* __restrict__ tau, int N, double margin_scale,
-                                                    double norm_max, int cap, int* __restrict__ cnt,
-                                                    int* __restrict__ buf) {
+                                                    const double* __restrict__ tau, int N, int phase, int step,
+                                                    int count, double margin_scale, double norm_max, int cap,
+                                                    int* __restrict__ cnt, int* __restrict__ buf) {
   const int lane = threadIdx.x & 63, kq = lane >> 4, cq = lane & 15;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q0 = wave * 64;
@@ -126,19 +127,25 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
   // and the 16 (query, point) tests of a lane are folded into one mask: a single wave-wide branch per tile
   // guards the rare appends.  (The point itself is not filtered here: k_bf_select skips it.)
   double b[DT], b_next[DT], n_next;
+  // the j-th point tile of this sweep: phase 0 takes every step-th tile (a strided subset of the cloud: a fair
+  // sample whatever order the points come in), phase 1 the tiles in between
+  auto tile_of = [&](int j) { return phase == 0 ? j * step : (j / (step - 1)) * step + 1 + j % (step - 1); };
+  int ct_next = tile_of(0);
   {
-    n_next = norm[cq];
+    n_next = norm[ct_next * 16 + cq];
 #pragma unroll
-    for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)0 * DT + t) * 64 + lane];
+    for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)ct_next * DT + t) * 64 + lane];
   }
-  for (int ct = 0; ct < ntiles; ++ct) {
+  for (int j = 0; j < count; ++j) {
+    const int ct = ct_next;
     const double nc = n_next;
 #pragma unroll
     for (int t = 0; t < DT; ++t) b[t] = b_next[t];
-    if (ct + 1 < ntiles) {
-      n_next = norm[(ct + 1) * 16 + cq];  // (padded: no bounds test between the load and its use a tile later)
+    if (j + 1 < count) {
+      ct_next = tile_of(j + 1);
+      n_next = norm[ct_next * 16 + cq];  // (padded: no bounds test between the load and its use a tile later)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)(ct + 1) * DT + t) * 64 + lane];
+      for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)ct_next * DT + t) * 64 + lane];
     }
     bf_d4 acc[4];
 #pragma unroll
@@ -165,6 +172,41 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
           }
     }
   }
+}
+
+// Between the two sweeps: the exact k-th smallest key among a query's candidates so far (all from the first
+// point range) is a tighter upper bound of its k-th neighbour's key than the sample gave
+template <int KMAX>
+__global__ __launch_bounds__(128) void k_bf_refine(const double* __restrict__ x, int N, int d, int k, int cap,
+                                                   const int* __restrict__ cnt, const int* __restrict__ buf,
+                                                   double* __restrict__ tau) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  double q[64];
+  for (int j = 0; j < d; ++j) q[j] = x[(size_t)i * d + j];
+  double bd[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) bd[t] = 1e300;
+  const int n = min(cnt[i], cap);
+  for (int a = 0; a < n; ++a) {
+    const int idx = buf[(size_t)i * cap + a];
+    if (idx == i) continue;
+    double cd = knn_sqdist(q, x + (size_t)idx * d, d);
+    if (cd < bd[KMAX - 1]) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) {
+        const bool lt = cd < bd[t];
+        const double td = bd[t];
+        bd[t] = lt ? cd : td;
+        cd = lt ? td : cd;
+      }
+    }
+  }
+  double kth = 1e300;
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t)
+    if (t == k - 1) kth = bd[t];
+  if (kth < tau[i]) tau[i] = kth;
 }
 
 // exact evaluation of the candidates (or of every point when the list overflowed / no list was made) and
@@ -227,6 +269,16 @@ static void launch_bf_kmax(gspx_ctx* ctx, const double* x, int N, int d, int k, 
     hipLaunchKernelGGL((gspx::k_bf_select<KMAX>), grid, dim3(128), 0, ctx->stream, x, N, d, k, metric, cap, cnt, buf, nn,
                        dist, n_scans);
 }
+static void launch_bf_refine(gspx_ctx* ctx, const double* x, int N, int d, int k, int cap, const int* cnt, const int* buf,
+                             double* tau) {
+  const dim3 grid((unsigned)((N + 127) / 128));
+#define GSPX_RF(K_) hipLaunchKernelGGL((gspx::k_bf_refine<K_>), grid, dim3(128), 0, ctx->stream, x, N, d, k, cap, cnt, buf, tau)
+  if (k <= 8) GSPX_RF(8);
+  else if (k <= 16) GSPX_RF(16);
+  else if (k <= 32) GSPX_RF(32);
+  else GSPX_RF(64);
+#undef GSPX_RF
+}
 static void launch_bf(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int stride, double* tau, int cap,
                       const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, bool tau_pass) {
   if (k <= 8) launch_bf_kmax<8>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
@@ -257,9 +309,18 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   const int want = std::max(std::max(2048, N / 128), 4 * k + 1);
   const int stride = std::max(1, N / want);
   const int M = (N + stride - 1) / stride;
-  // expected candidates per query ~ k N / M; room for four times that (clustered clouds), at least 8 k
-  // (+ 1: the point itself passes its own bound and is skipped by the selection)
-  const int cap = (int)std::min<int64_t>(std::max<int64_t>(4 * (int64_t)k * N / std::max(M - 1, 1), 8 * k) + 1, N);
+  // Two sweeps.  The sample's bound admits about k N / M points per query; sweeping only N1 points (every step-th
+  // tile of the cloud) with it (k N1 / M candidates), tightening every bound to the exact k-th smallest of those (the k-th neighbour among
+  // N1 points: admits about k N / N1 of all points), then sweeping the rest, appends k (N1 / M + N / N1) candidates
+  // per query - least at N1 = sqrt(N M), a fifth of the single sweep's at N = 200k.  (The appends, one atomic and
+  // one scattered store each, were what the single sweep spent its time on, not the products.)
+  int step = (int)std::floor((double)ntiles / std::max(1.0, std::ceil(std::sqrt((double)N * (double)M) / 16.0)));
+  if (step < 2) step = 1;                        // small clouds: one sweep over every tile
+  const int t1 = (ntiles + step - 1) / step;     // tiles 0, step, 2 step, ...: the first sweep
+  const double n1 = std::min<double>((double)t1 * 16.0, (double)N);
+  const double expect = (double)k * (n1 / std::max(M - 1, 1) + (step > 1 ? (double)N / n1 : 0.0));
+  // room for four times the expectation (clustered clouds), at least 8 k (+ 1: the point itself passes its own bound)
+  const int cap = (int)std::min<int64_t>(std::max<int64_t>((int64_t)(4.0 * expect), 8 * k) + 1, N);
   DevMem xop, norm, tau, cnt, buf, pmax;
   CHK(xop.alloc((size_t)ntiles * DT * 64 * sizeof(double)));
   CHK(norm.alloc((size_t)ntiles * 16 * sizeof(double)));
@@ -279,12 +340,19 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   // |fl(|y|^2 - 2 x.y) + |x|^2 - |x - y|^2| <= (4 DT + 8) u (|x|^2 + |y|^2) with u = 2^-53; ten times that
   const double margin = 10.0 * (4.0 * DT + 8.0) * 1.1102230246251565e-16;
   const dim3 grid((unsigned)((N + 255) / 256));
-#define GSPX_BF(D_)                                                                                                      \
+#define GSPX_BF(D_, PH_, CNT_)                                                                                           \
   hipLaunchKernelGGL((gspx::k_bf_collect<D_>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),              \
-                     tau.as<double>(), N, margin, nmax, cap, cnt.as<int>(), buf.as<int>())
-  if (DT == 4) GSPX_BF(4);
-  else if (DT == 8) GSPX_BF(8);
-  else GSPX_BF(16);
+                     tau.as<double>(), N, PH_, step, CNT_, margin, nmax, cap, cnt.as<int>(), buf.as<int>())
+  auto sweep = [&](int phase, int count) {
+    if (DT == 4) GSPX_BF(4, phase, count);
+    else if (DT == 8) GSPX_BF(8, phase, count);
+    else GSPX_BF(16, phase, count);
+  };
+  sweep(0, t1);
+  if (step > 1) {
+    launch_bf_refine(ctx, x, N, d, k, cap, cnt.as<int>(), buf.as<int>(), tau.as<double>());
+    sweep(1, ntiles - t1);
+  }
 #undef GSPX_BF
   launch_bf(ctx, x, N, d, k, metric, stride, nullptr, cap, cnt.as<int>(), buf.as<int>(), nn, dist, n_scans.as<int>(), false);
   HIPCHK(hipGetLastError());

@@ -352,6 +352,7 @@ def test_highdim_scale(ctx):
     import time
     rng = np.random.default_rng(1)
     X = rng.standard_normal((100000, 16))
+    X = X[np.argsort(X[:, 0])]  # an ORDERED cloud (like patches in raster order): the first sweep's subset is strided
     t0 = time.perf_counter()
     W, sg, info = engine.knn_graph(X, 10, ctx=ctx, neighbors=True)
     dt = time.perf_counter() - t0
