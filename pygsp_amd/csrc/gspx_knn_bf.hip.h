@@ -28,6 +28,56 @@ namespace gspx {
 
 typedef double bf_d4 __attribute__((ext_vector_type(4)));
 
+// knn_sqdist / knn_key (the KD-tree's arithmetic, gspx_knn.hip.h) with the query in REGISTERS: q is indexed with
+// compile-time constants only (4 DT >= d values, fully unrolled, the real dimension d guards each block), so it
+// never goes to scratch memory - the runtime-indexed q[64] of the first version did, and a scratch read per
+// multiply made these kernels several times slower than their arithmetic.
+template <int DT>
+__device__ __forceinline__ double knn_sqdist_reg(const double (&q)[4 * DT], const double* __restrict__ p, int d) {
+#pragma clang fp contract(off)
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+  for (int b = 0; b < DT; ++b)
+    if (4 * b + 4 <= d) {
+      const double d0 = q[4 * b] - p[4 * b], d1 = q[4 * b + 1] - p[4 * b + 1], d2 = q[4 * b + 2] - p[4 * b + 2],
+                   d3 = q[4 * b + 3] - p[4 * b + 3];
+      const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+      a0 = a0 + s0;
+      a1 = a1 + s1;
+      a2 = a2 + s2;
+      a3 = a3 + s3;
+    }
+  double s = ((a0 + a1) + a2) + a3;
+#pragma unroll
+  for (int b = 0; b < DT; ++b)
+    if (4 * b < d && 4 * b + 4 > d) {  // the block that holds the last d % 4 dimensions
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (4 * b + r < d) {
+          const double df = q[4 * b + r] - p[4 * b + r];
+          const double sq = df * df;
+          s = s + sq;
+        }
+    }
+  return s;
+}
+template <int DT>
+__device__ __forceinline__ double knn_key_reg(const double (&q)[4 * DT], const double* __restrict__ p, int d, int metric) {
+  if (metric == 0) return knn_sqdist_reg<DT>(q, p, d);
+  double s = 0;
+#pragma unroll
+  for (int j = 0; j < 4 * DT; ++j)
+    if (j < d) {
+      const double a = fabs(q[j] - p[j]);
+      s = metric == 1 ? s + a : fmax(s, a);
+    }
+  return s;
+}
+template <int DT> __device__ __forceinline__ void bf_load_query(double (&q)[4 * DT], const double* __restrict__ row, int d) {
+#pragma unroll
+  for (int j = 0; j < 4 * DT; ++j) q[j] = j < d ? row[j] : 0.0;
+}
+
 // X (N x d, row major) -> Xop[tile][t][lane] = X[16 tile + (lane & 15)][4 t + (lane >> 4)] (zero beyond N / d),
 // norm[i] = sum_j x_ij^2 (padded to whole tiles with 1e300)
 __global__ void k_bf_prepare(const double* __restrict__ x, int N, int d, int DT, double* __restrict__ xop,
@@ -54,19 +104,19 @@ __global__ void k_bf_prepare(const double* __restrict__ x, int N, int d, int DT,
 
 // tau[i] = k-th smallest exact key (squared euclidean distance in the KD-tree's arithmetic) from point i to the
 // sample {0, stride, 2 stride, ...} without i itself: an upper bound of its k-th neighbour's key
-template <int KMAX>
+template <int KMAX, int DT>
 __global__ __launch_bounds__(128) void k_bf_tau(const double* __restrict__ x, int N, int d, int k, int stride,
                                                 double* __restrict__ tau) {
   const int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= N) return;
-  double q[64];
-  for (int j = 0; j < d; ++j) q[j] = x[(size_t)i * d + j];
+  double q[4 * DT];
+  bf_load_query<DT>(q, x + (size_t)i * d, d);
   double bd[KMAX];
 #pragma unroll
   for (int t = 0; t < KMAX; ++t) bd[t] = 1e300;
   for (int c = 0; c < N; c += stride) {
     if (c == i) continue;
-    double cd = knn_sqdist(q, x + (size_t)c * d, d);
+    double cd = knn_sqdist_reg<DT>(q, x + (size_t)c * d, d);
     if (cd < bd[KMAX - 1]) {
 #pragma unroll
       for (int t = 0; t < KMAX; ++t) {
@@ -155,18 +205,19 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) acc[qt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][t], b[t], acc[qt], 0, 0, 0);
     // D layout: lane (kq, cq) holds query rows kq + 4 e, point column cq
-    unsigned hits = 0;
+    // (the tests are folded with a scalar OR of the compare masks: two vector instructions per pair)
+    bool any = false;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) hits |= (nc - 2.0 * acc[qt][e] <= lim[qt][e]) ? (1u << (qt * 4 + e)) : 0u;
-    if (__builtin_amdgcn_ballot_w64(hits != 0) != 0) {
+      for (int e = 0; e < 4; ++e) any |= nc - 2.0 * acc[qt][e] <= lim[qt][e];
+    if (__builtin_amdgcn_ballot_w64(any) != 0) {
       const int c = ct * 16 + cq;
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (hits & (1u << (qt * 4 + e))) {
+          if (nc - 2.0 * acc[qt][e] <= lim[qt][e]) {
             const int slot = atomicAdd(&cnt[qi[qt][e]], 1);
             if (slot < cap) buf[(size_t)qi[qt][e] * cap + slot] = c;
           }
@@ -176,14 +227,14 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
 
 // Between the two sweeps: the exact k-th smallest key among a query's candidates so far (all from the first
 // point range) is a tighter upper bound of its k-th neighbour's key than the sample gave
-template <int KMAX>
+template <int KMAX, int DT>
 __global__ __launch_bounds__(128) void k_bf_refine(const double* __restrict__ x, int N, int d, int k, int cap,
                                                    const int* __restrict__ cnt, const int* __restrict__ buf,
                                                    double* __restrict__ tau) {
   const int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= N) return;
-  double q[64];
-  for (int j = 0; j < d; ++j) q[j] = x[(size_t)i * d + j];
+  double q[4 * DT];
+  bf_load_query<DT>(q, x + (size_t)i * d, d);
   double bd[KMAX];
 #pragma unroll
   for (int t = 0; t < KMAX; ++t) bd[t] = 1e300;
@@ -191,7 +242,7 @@ __global__ __launch_bounds__(128) void k_bf_refine(const double* __restrict__ x,
   for (int a = 0; a < n; ++a) {
     const int idx = buf[(size_t)i * cap + a];
     if (idx == i) continue;
-    double cd = knn_sqdist(q, x + (size_t)idx * d, d);
+    double cd = knn_sqdist_reg<DT>(q, x + (size_t)idx * d, d);
     if (cd < bd[KMAX - 1]) {
 #pragma unroll
       for (int t = 0; t < KMAX; ++t) {
@@ -211,15 +262,15 @@ __global__ __launch_bounds__(128) void k_bf_refine(const double* __restrict__ x,
 
 // exact evaluation of the candidates (or of every point when the list overflowed / no list was made) and
 // selection of the k smallest by (key, index); nearest first
-template <int KMAX>
+template <int KMAX, int DT>
 __global__ __launch_bounds__(128) void k_bf_select(const double* __restrict__ x, int N, int d, int k, int metric,
                                                    int cap, const int* __restrict__ cnt, const int* __restrict__ buf,
                                                    int* __restrict__ nn, double* __restrict__ dist,
                                                    int* __restrict__ n_scans) {
   const int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= N) return;
-  double q[64];
-  for (int j = 0; j < d; ++j) q[j] = x[(size_t)i * d + j];
+  double q[4 * DT];
+  bf_load_query<DT>(q, x + (size_t)i * d, d);
   double bd[KMAX];
   int bi[KMAX];
 #pragma unroll
@@ -234,7 +285,7 @@ __global__ __launch_bounds__(128) void k_bf_select(const double* __restrict__ x,
   for (int a = 0; a < n; ++a) {
     const int idx = scan ? a : buf[(size_t)i * cap + a];
     if (idx == i) continue;
-    double cd = knn_key(q, x + (size_t)idx * d, d, metric);
+    double cd = knn_key_reg<DT>(q, x + (size_t)idx * d, d, metric);
     int ci = idx;
     if (cd < bd[KMAX - 1] || (cd == bd[KMAX - 1] && ci < bi[KMAX - 1])) {
 #pragma unroll
@@ -259,32 +310,32 @@ __global__ __launch_bounds__(128) void k_bf_select(const double* __restrict__ x,
 
 }  // namespace gspx
 
-template <int KMAX>
-static void launch_bf_kmax(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int stride, double* tau,
-                           int cap, const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, bool tau_pass) {
+template <int KMAX, int DT>
+static void launch_bf_kd(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int stride, double* tau,
+                         int cap, const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, int what) {
   const dim3 grid((unsigned)((N + 127) / 128));
-  if (tau_pass)
-    hipLaunchKernelGGL((gspx::k_bf_tau<KMAX>), grid, dim3(128), 0, ctx->stream, x, N, d, k, stride, tau);
+  if (what == 0)
+    hipLaunchKernelGGL((gspx::k_bf_tau<KMAX, DT>), grid, dim3(128), 0, ctx->stream, x, N, d, k, stride, tau);
+  else if (what == 1)
+    hipLaunchKernelGGL((gspx::k_bf_refine<KMAX, DT>), grid, dim3(128), 0, ctx->stream, x, N, d, k, cap, cnt, buf, tau);
   else
-    hipLaunchKernelGGL((gspx::k_bf_select<KMAX>), grid, dim3(128), 0, ctx->stream, x, N, d, k, metric, cap, cnt, buf, nn,
-                       dist, n_scans);
+    hipLaunchKernelGGL((gspx::k_bf_select<KMAX, DT>), grid, dim3(128), 0, ctx->stream, x, N, d, k, metric, cap, cnt, buf,
+                       nn, dist, n_scans);
 }
-static void launch_bf_refine(gspx_ctx* ctx, const double* x, int N, int d, int k, int cap, const int* cnt, const int* buf,
-                             double* tau) {
-  const dim3 grid((unsigned)((N + 127) / 128));
-#define GSPX_RF(K_) hipLaunchKernelGGL((gspx::k_bf_refine<K_>), grid, dim3(128), 0, ctx->stream, x, N, d, k, cap, cnt, buf, tau)
-  if (k <= 8) GSPX_RF(8);
-  else if (k <= 16) GSPX_RF(16);
-  else if (k <= 32) GSPX_RF(32);
-  else GSPX_RF(64);
-#undef GSPX_RF
+template <int KMAX>
+static void launch_bf_k(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int stride, double* tau, int cap,
+                        const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, int what) {
+  if (d <= 16) launch_bf_kd<KMAX, 4>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, what);
+  else if (d <= 32) launch_bf_kd<KMAX, 8>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, what);
+  else launch_bf_kd<KMAX, 16>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, what);
 }
+// what: 0 the sample bounds (k_bf_tau), 1 their refinement between the sweeps (k_bf_refine), 2 the selection
 static void launch_bf(gspx_ctx* ctx, const double* x, int N, int d, int k, int metric, int stride, double* tau, int cap,
-                      const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, bool tau_pass) {
-  if (k <= 8) launch_bf_kmax<8>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
-  else if (k <= 16) launch_bf_kmax<16>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
-  else if (k <= 32) launch_bf_kmax<32>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
-  else launch_bf_kmax<64>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, tau_pass);
+                      const int* cnt, const int* buf, int* nn, double* dist, int* n_scans, int what) {
+  if (k <= 8) launch_bf_k<8>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, what);
+  else if (k <= 16) launch_bf_k<16>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, what);
+  else if (k <= 32) launch_bf_k<32>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, what);
+  else launch_bf_k<64>(ctx, x, N, d, k, metric, stride, tau, cap, cnt, buf, nn, dist, n_scans, what);
 }
 
 // x: N x d doubles on the device; nn / dist: N x k outputs (nearest first, the point itself excluded).
@@ -297,7 +348,7 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   CHK(n_scans.alloc(64));
   HIPCHK(hipMemsetAsync(n_scans.p, 0, 64, st));
   if (metric != 0 || N <= 4 * k + 64) {  // no product form (or too few points to bother): exact scan for everybody
-    launch_bf(ctx, x, N, d, k, metric, 1, nullptr, 0, nullptr, nullptr, nn, dist, n_scans.as<int>(), false);
+    launch_bf(ctx, x, N, d, k, metric, 1, nullptr, 0, nullptr, nullptr, nn, dist, n_scans.as<int>(), 2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     if (stats) stats[0] = 0, stats[1] = 0, stats[2] = (double)N, stats[3] = (double)N;
@@ -331,7 +382,7 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   const long long total = (long long)ntiles * DT * 64;
   hipLaunchKernelGGL(gspx::k_bf_prepare, dim3((unsigned)((std::max<long long>(total, N) + 255) / 256)), dim3(256), 0, st, x,
                      N, d, DT, xop.as<double>(), norm.as<double>());
-  launch_bf(ctx, x, N, d, k, metric, stride, tau.as<double>(), 0, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  launch_bf(ctx, x, N, d, k, metric, stride, tau.as<double>(), 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   std::vector<double> hn((size_t)N);
   HIPCHK(hipMemcpyAsync(hn.data(), norm.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -350,11 +401,11 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   };
   sweep(0, t1);
   if (step > 1) {
-    launch_bf_refine(ctx, x, N, d, k, cap, cnt.as<int>(), buf.as<int>(), tau.as<double>());
+    launch_bf(ctx, x, N, d, k, metric, stride, tau.as<double>(), cap, cnt.as<int>(), buf.as<int>(), nullptr, nullptr, nullptr, 1);
     sweep(1, ntiles - t1);
   }
 #undef GSPX_BF
-  launch_bf(ctx, x, N, d, k, metric, stride, nullptr, cap, cnt.as<int>(), buf.as<int>(), nn, dist, n_scans.as<int>(), false);
+  launch_bf(ctx, x, N, d, k, metric, stride, nullptr, cap, cnt.as<int>(), buf.as<int>(), nn, dist, n_scans.as<int>(), 2);
   HIPCHK(hipGetLastError());
   int scans = 0;
   HIPCHK(hipMemcpyAsync(&scans, n_scans.p, sizeof(int), hipMemcpyDeviceToHost, st));
