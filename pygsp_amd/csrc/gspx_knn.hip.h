@@ -266,7 +266,24 @@ __global__ void k_knn_row_rank(const int* __restrict__ rowptr, int N, const int*
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int lo = rowptr[i], hi = rowptr[i + 1];
+  if (hi - lo > 64) return;  // long rows (hubs - common in high dimensions): a whole wave each, below
   for (int a = lo; a < hi; ++a) {
+    const int c = col[a];
+    int rank = 0;
+    for (int b = lo; b < hi; ++b) rank += col[b] < c;
+    col2[lo + rank] = c;
+    val2[lo + rank] = val[a];
+  }
+}
+// rows longer than 64 entries: one wave per row, every lane ranks its share of the entries
+__global__ __launch_bounds__(256) void k_knn_row_rank_long(const int* __restrict__ rowptr, int N,
+                                                           const int* __restrict__ col, const double* __restrict__ val,
+                                                           int* __restrict__ col2, double* __restrict__ val2) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= N) return;
+  const int lo = rowptr[i], hi = rowptr[i + 1];
+  if (hi - lo <= 64) return;
+  for (int a = lo + lane; a < hi; a += 64) {
     const int c = col[a];
     int rank = 0;
     for (int b = lo; b < hi; ++b) rank += col[b] < c;
@@ -581,6 +598,8 @@ extern "C" int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coo
     KCHK(val2.alloc((size_t)std::max(nnz, 1) * sizeof(double)));
     hipLaunchKernelGGL(k_knn_row_rank, dim3(nbN), dim3(256), 0, st, h->rowptr.as<int>(), n, h->col.as<int>(),
                        h->val.as<double>(), col2.as<int>(), val2.as<double>());
+    hipLaunchKernelGGL(k_knn_row_rank_long, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, h->rowptr.as<int>(), n,
+                       h->col.as<int>(), h->val.as<double>(), col2.as<int>(), val2.as<double>());
     KHIP(hipGetLastError());
     KHIP(hipStreamSynchronize(st));
     std::swap(h->col.p, col2.p);      // the sorted arrays become the result; the unsorted ones go with col2 / val2
