@@ -126,7 +126,9 @@ def _replicas(G, group):
     for ctx in group.ctxs:
         hit = cache.get(id(ctx))
         if mirror:
-            if hit is not None and hit[0] == stamp and getattr(hit[1], "_h", None):
+            # (the entry remembers the context object itself: an id() can be recycled by a later context)
+            if (hit is not None and hit[0] == stamp and hit[2] is ctx and getattr(ctx, "_h", None)
+                    and getattr(hit[1], "_h", None)):
                 reps.append(hit[1])
                 continue
             own = G.device_graph()
@@ -139,7 +141,7 @@ def _replicas(G, group):
                     dev.auto_gather_tiles()
                 elif G.tiles:
                     dev.enable_gather_tiles()
-            cache[id(ctx)] = (stamp, dev)
+            cache[id(ctx)] = (stamp, dev, ctx)
         else:
             from . import plugin
             dev = plugin.device_graph_for(G, ctx=ctx)
