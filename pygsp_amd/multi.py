@@ -149,12 +149,16 @@ def _replicas(G, group):
     return reps
 
 
-def filter_columns(G, coeffs, x, devices, mode=_capi.ANALYSIS, root=0, timings=None):
+def filter_columns(G, coeffs, x, devices, mode=_capi.ANALYSIS, root=0, timings=None, collect="device"):
     """cheby_op of ONE graph with the signal columns split over `devices`.
 
     coeffs (Nf, M) float64; analysis: x (N, Nsig) -> (Nf, N, Nsig); synthesis: x (Nf, N, Nsig) -> (N, Nsig).
     Columns come back in the caller's order.  `timings` (a dict, optional) receives per-device kernel
-    milliseconds, the gather time and its implementation."""
+    milliseconds, the gather time and its implementation.  `collect`: "device" (default; what the north star
+    describes) - every GPU's block travels to the root GPU over xGMI (gspx_gather: RCCL) and the root ships the
+    panel to the host; "host" - every GPU ships its own columns to the host itself through the pipelined
+    host-pointer path (N PCIe links in parallel, no collective: the better choice when the result is wanted on
+    the host anyway)."""
     group = devices if isinstance(devices, DeviceGroup) else DeviceGroup(devices)
     c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))
     Nf = c.shape[0]
@@ -173,6 +177,26 @@ def filter_columns(G, coeffs, x, devices, mode=_capi.ANALYSIS, root=0, timings=N
     lmax = float(G.lmax)
     elt = np.dtype(dtype).itemsize
     kernel_ms = [0.0] * n
+    if collect not in ("device", "host"):
+        raise ValueError("collect must be 'device' or 'host'")
+    if collect == "host":
+        def direct(i, ctx):
+            cr = cols[i]
+            if len(cr) == 0:
+                return None
+            y, kernel_ms[i] = reps[i].cheby_filter(c, x[..., cr.start:cr.stop], lmax, mode)
+            return y
+
+        blocks = group.run(direct)
+        out = np.empty((Nf, G.N, nsig) if analysis else (G.N, nsig), dtype=dtype)
+        for cr, y in zip(cols, blocks):
+            if y is not None:
+                out[..., cr.start:cr.stop] = y
+        if timings is not None:
+            timings.update(kernel_ms=list(kernel_ms), gather_ms=0.0, columns=[len(cr) for cr in cols],
+                           gather_impl="none: every GPU ships its columns to the host itself",
+                           devices=list(group.devices))
+        return out, max(kernel_ms)
 
     def work(i, ctx):
         cr = cols[i]

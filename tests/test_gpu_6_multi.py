@@ -279,6 +279,9 @@ def test_filter_columns_split_over_two_contexts(ctx, dtype):
     assert tm["columns"] == [1, 1, 0] and y.shape == (1, G.N, 2)
     assert rel_err(y[0], orc.filter_chebyshev(L, G.lmax, [orc.heat_kernel(10, G.lmax)],
                                               x.astype(dtype).astype(np.float64), 10)) < tol
+    # every GPU shipping its own columns to the host (no collective) gives the same panel
+    yh, _ = multi.filter_columns(G, filters.compute_cheby_coeff(filters.Heat(G, 10), m=10), x, [0, 0, 0], collect="host")
+    assert np.array_equal(yh, y)
     # the replicas are cached on the graph: a second call builds nothing
     reps = dict(G._gspx_replicas)
     bank.filter(s, order=12, devices=[0, 0])
