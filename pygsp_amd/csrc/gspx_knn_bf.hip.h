@@ -176,6 +176,10 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
   // product chains are interleaved (four independent accumulators in flight, no stall on a chain's own result),
   // and the 16 (query, point) tests of a lane are folded into one mask: a single wave-wide branch per tile
   // guards the rare appends.  (The point itself is not filtered here: k_bf_select skips it.)
+  __shared__ unsigned long long queue_all[4][128];  // (query << 32) | point
+  volatile unsigned long long* queue = queue_all[threadIdx.x >> 6];
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int queued = 0;  // wave-uniform
   double b[DT], b_next[DT], n_next;
   // the j-th point tile of this sweep: phase 0 takes every step-th tile (a strided subset of the cloud: a fair
   // sample whatever order the points come in), phase 1 the tiles in between
@@ -212,16 +216,46 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) any |= nc - 2.0 * acc[qt][e] <= lim[qt][e];
     if (__builtin_amdgcn_ballot_w64(any) != 0) {
+      // Hits are parked in the wave's LDS queue and appended 64 at a time: an append is an atomic (whose return the
+      // wave must wait for) plus a scattered store, and about 60 % of the tiles hit something - appending on the
+      // spot stalled the wave a memory round trip per tile.
       const int c = ct * 16 + cq;
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (nc - 2.0 * acc[qt][e] <= lim[qt][e]) {
-            const int slot = atomicAdd(&cnt[qi[qt][e]], 1);
-            if (slot < cap) buf[(size_t)qi[qt][e] * cap + slot] = c;
+        for (int e = 0; e < 4; ++e) {
+          const bool hit = nc - 2.0 * acc[qt][e] <= lim[qt][e];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+          if (m != 0) {
+            if (hit) {
+              const int pos = queued + __popcll(m & lt_mask);
+              queue[pos] = ((unsigned long long)(unsigned)qi[qt][e] << 32) | (unsigned)c;
+            }
+            queued += __popcll(m);
+            if (queued >= 64) {  // at most 127 parked: room for one more round of 64
+              __builtin_amdgcn_wave_barrier();
+              const unsigned long long it = queue[lane];
+              const int iq = (int)(it >> 32), ic = (int)(unsigned)it;
+              const int slot = atomicAdd(&cnt[iq], 1);
+              if (slot < cap) buf[(size_t)iq * cap + slot] = ic;
+              const int rest = queued - 64;
+              unsigned long long mv = 0;
+              if (lane < rest) mv = queue[64 + lane];
+              __builtin_amdgcn_wave_barrier();
+              if (lane < rest) queue[lane] = mv;
+              __builtin_amdgcn_wave_barrier();
+              queued = rest;
+            }
           }
+        }
     }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < queued) {  // what is still parked
+    const unsigned long long it = queue[lane];
+    const int iq = (int)(it >> 32), ic = (int)(unsigned)it;
+    const int slot = atomicAdd(&cnt[iq], 1);
+    if (slot < cap) buf[(size_t)iq * cap + slot] = ic;
   }
 }
 
