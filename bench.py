@@ -454,6 +454,90 @@ class RankWork:
         self.G._dev = {}
 
 
+def run_signal_parallel(group, a, dtype, no_parity=False):
+    """SURVEY 8(e)(2), strong scaling of the HEADLINE call: ONE 1M-vertex graph replicated on every context of the
+    group, its 64 signal columns split over them (device resident), one gather of the column blocks onto context 0
+    (gspx_gather).  The same machinery as Filter.filter(..., devices=[...]) (pygsp_amd.multi), timed like the
+    headline: thread barrier, K steps, device syncs, first start to last finish."""
+    import threading
+
+    from pygsp_amd import dist as gdist
+    from pygsp_amd import engine, filters, graphs
+    n = len(group)
+    N, nsig, K = a.n, a.nsig, a.order
+    coords = np.random.default_rng(42).uniform(0, 1, (N, 2))
+    W, _, _ = engine.knn_graph(coords, a.knn, ctx=group.ctxs[0])
+    G = graphs.Graph(W, coords=coords, compute_dtype=dtype, ctx=group.ctxs[0], reorder=a.reorder,
+                     tiles="auto" if a.tiles == "auto" else False)
+    G.estimate_lmax("bounds")
+    lmax = float(G.lmax)
+    c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, a.scale), m=K))
+    x = np.random.default_rng(1234).standard_normal((N, nsig)).astype(dtype)
+    cols = [gdist.shard_units(nsig, r, n) for r in range(n)]
+    state = [None] * n
+
+    def setup(i, ctx):
+        if len(cols[i]) == 0:
+            return
+        dev = G.device_graph() if i == 0 else engine.DeviceGraph.from_w(G.W, G.lap_type, dtype=dtype,
+                                                                       perm=G._internal_order(), ctx=ctx)
+        if i > 0 and a.tiles == "auto":
+            dev.auto_gather_tiles()
+        xs = np.ascontiguousarray(x[:, cols[i].start:cols[i].stop])
+        bx, by = ctx.upload(xs), ctx.alloc(xs.nbytes)
+        state[i] = (dev, bx, by, xs.shape[1])
+        for _ in range(max(a.warmup, 1)):
+            dev.cheby_filter_dev(c, bx.ptr, by.ptr, xs.shape[1], lmax)
+        ctx.sync()
+
+    group.run(setup)
+    bar = threading.Barrier(n)
+
+    def timed(i, ctx):
+        bar.wait()
+        t0 = time.perf_counter()
+        if state[i] is not None:
+            dev, bx, by, w = state[i]
+            for _ in range(a.steps):
+                dev.cheby_filter_dev(c, bx.ptr, by.ptr, w, lmax)
+            ctx.sync()
+        return t0, time.perf_counter()
+
+    spans = group.run(timed)
+    elapsed = max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans)
+    root_buf, t_g, impl = group.gather([st[2] if st else None for st in state], 0)
+    root_buf.free()
+    root_buf, t_g, impl = group.gather([st[2] if st else None for st in state], 0)
+    err = None
+    if not no_parity:
+        from oracle import cheby_oracle as orc
+        flat = root_buf.download((N * nsig,), dtype)
+        y = np.empty((N, nsig), dtype=dtype)
+        off = 0
+        for cr in cols:
+            w = len(cr)
+            y[:, cr.start:cr.stop] = flat[off:off + N * w].reshape(N, w)
+            off += N * w
+        check = sorted({0, nsig - 1})  # the first column of the first GPU and the last of the last
+        ref = orc.cheby_op(G.L.astype(np.float64), lmax, c[0], x[:, check].astype(np.float64))
+        err = float(np.max(np.abs(y[:, check] - ref)) / np.max(np.abs(ref)))
+    root_buf.free()
+    for i, st in enumerate(state):
+        if st is not None:
+            st[1].free()
+            st[2].free()
+            if i > 0:
+                st[0].destroy()
+    for g_ in list(G._dev.values()):
+        g_.destroy()
+    G._dev = {}
+    return {"workload": "ONE Sensor(N={}, k={}) graph replicated on {} GPU(s), its {} signals split {} (strong scaling of "
+                        "the headline call)".format(N, a.knn, n, nsig, "/".join(str(len(cr)) for cr in cols)),
+            "n_gpus": n, "ms_per_step": elapsed / a.steps * 1e3, "value": N * nsig * K * a.steps / elapsed,
+            "unit": "vertex*signal*order/s", "gather_ms": t_g * 1e3, "gather_impl": impl,
+            "parity_vs_oracle": {"max_rel_err": err, "columns": 2, "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}}
+
+
 def run_batch_config_threads(group, no_parity=False):
     """BASELINE.json configs[4] from ONE process: the batch of 8 independent Sensor(N=500000) graphs x 32 signals,
     Heat order 30, sharded over the group's contexts (one driver thread each, no data-path collective), the 8
@@ -637,8 +721,12 @@ def main_threads(a):
         r.free()
     if not a.no_configs:
         try:
-            out["batch_config4"] = run_batch_config_threads(group, no_parity=a.no_cpu)
+            out["signal_parallel"] = run_signal_parallel(group, a, dtype, no_parity=a.no_cpu)
         except Exception as e:  # an extra: never a reason to lose the headline measurement
+            out["signal_parallel"] = {"error": repr(e)}
+        try:
+            out["batch_config4"] = run_batch_config_threads(group, no_parity=a.no_cpu)
+        except Exception as e:
             out["batch_config4"] = {"error": repr(e)}
     try:
         import ctypes

@@ -215,6 +215,9 @@ def test_bench_threads_two_contexts_on_this_gpu():
     b5 = out["batch_config4"]
     assert b5["n_gpus"] == 2 and b5["n_graphs"] == 8 and "4/4" in b5["workload"] and b5["value"] > 0
     assert b5["parity_vs_oracle"]["max_rel_err"] < 1e-11 and b5["parity_vs_oracle"]["graphs_checked"] == 2
+    sp = out["signal_parallel"]  # one graph, its 16 signals split 8 / 8 over the two contexts
+    assert sp["n_gpus"] == 2 and "8/8" in sp["workload"] and sp["value"] > 0 and sp["gather_ms"] > 0
+    assert sp["parity_vs_oracle"]["max_rel_err"] < 1e-11
 
 
 def test_bench_all_visible_gpus_through_rccl():
