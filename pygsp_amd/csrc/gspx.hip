@@ -2504,8 +2504,7 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
                          : filter_host_pipelined<double>(g, lmax, Nf, M, coeffs, Nsig, (const double*)x_host,
                                                          (double*)y_host, mode, widths, threads, kernel_ms);
       if (rc != GSPX_HOSTPIPE_UNAVAILABLE) return rc;
-      // no pinned / device staging memory to be had: release what the attempt got and take the one-shot form
-      ctx->pipe->destroy();
+      // an in-place call, or no pinned / device staging memory to be had: the one-shot form below
     }
     if (ctx->pipe) ctx->pipe->timing[6] = 0;  // the last host call was not pipelined
   }

@@ -68,6 +68,12 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
   std::vector<int64_t> col0((size_t)nb, 0);
   for (int b = 1; b < nb; ++b) col0[(size_t)b] = col0[(size_t)b - 1] + widths[(size_t)b - 1];
   const int64_t w = *std::max_element(widths.begin(), widths.end());
+  {  // an in-place call (y overlapping x): the one-shot form reads all of x before it writes y and is safe; the
+     // pipeline writes - and pre-faults - columns of y while later columns of x are still to be read
+    const uintptr_t xa = (uintptr_t)x, xb = xa + (size_t)in_planes * N * Nsig * sizeof(T);
+    const uintptr_t ya = (uintptr_t)y, yb = ya + (size_t)out_planes * N * Nsig * sizeof(T);
+    if (xa < yb && ya < xb) return GSPX_HOSTPIPE_UNAVAILABLE;
+  }
   {  // the result array is usually fresh from the allocator (mmap): ask for huge pages before the unpacking
      // threads fault it in (131k page faults of 4 KB for a 512 MB result cost them several milliseconds)
     const size_t bytes = (size_t)out_planes * N * Nsig * sizeof(T);

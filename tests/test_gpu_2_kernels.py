@@ -524,6 +524,16 @@ def test_host_pipeline_equals_one_shot_call(ctx, dtype):
             assert tm is not None and tm["batches"] >= 4
         ctx.set_option("host_pipeline", 0)
         assert np.array_equal(dev.cheby_filter(c1, big, lmax)[0], yb)
+        # an in-place call through the C-ABI (y_host == x_host): the pipeline steps aside (it would overwrite - and
+        # pre-fault - columns that are still to be read), the one-shot form reads everything first
+        import ctypes
+        ctx.set_option("host_pipeline", 2)
+        inplace = big.copy()
+        ms = ctypes.c_double(0)
+        cc = np.ascontiguousarray(c1, dtype=np.float64)
+        _capi.check(_capi.load().gspx_cheby_filter(dev._h, lmax, 1, cc.shape[1], _capi.ptr(cc), big.shape[1],
+                                                   _capi.ptr(inplace), _capi.ptr(inplace), _capi.ANALYSIS, ctypes.byref(ms)))
+        assert ctx.last_host_timing() is None and np.array_equal(inplace, yb[0])
     finally:
         for k, v in (("host_pipeline", 1), ("host_batch", 0), ("host_threads", 0)):
             ctx.set_option(k, v)
