@@ -99,6 +99,8 @@ class Graph:
             return False
         if order == "auto" and getattr(self, "coords", None) is None and adjacency.shape[0] >= 4096:
             return False  # no coordinates: reverse Cuthill-McKee is a host (scipy) algorithm
+        if order in ("morton", "hilbert") and adjacency.shape[0] < 4096:
+            return False  # an explicitly requested curve on a small graph: the numpy curves of engine.locality_order
         try:
             dev, rep = engine.DeviceGraph.setup(adjacency, self.lap_type, self.compute_dtype,
                                                 getattr(self, "coords", None), order, ctx=self.context)
