@@ -198,27 +198,24 @@ def filter_columns(G, coeffs, x, devices, mode=_capi.ANALYSIS, root=0, timings=N
                            devices=list(group.devices))
         return out, max(kernel_ms)
 
+    parts = [None] * n  # filled by the driver threads; released below also when one of them failed
+
     def work(i, ctx):
         cr = cols[i]
         w = len(cr)
         if w == 0:
-            return None
+            return
         xs = np.ascontiguousarray(x[..., cr.start:cr.stop], dtype=dtype)
         bx = ctx.upload(xs)
         try:
-            by = ctx.alloc((Nf if analysis else 1) * G.N * w * elt)
-            try:
-                kernel_ms[i] = reps[i].cheby_filter_dev(c, bx.ptr, by.ptr, w, lmax, mode)
-            except BaseException:
-                by.free()
-                raise
+            parts[i] = ctx.alloc((Nf if analysis else 1) * G.N * w * elt)
+            kernel_ms[i] = reps[i].cheby_filter_dev(c, bx.ptr, parts[i].ptr, w, lmax, mode)
         finally:
             bx.free()
-        return by
 
-    parts = group.run(work)
     root_buf = None
     try:
+        group.run(work)
         root_buf, t_gather, impl = group.gather(parts, root)
         total = sum(p.nbytes for p in parts if p is not None)
         flat = root_buf.download((max(total, 16),), np.uint8)[:total]
