@@ -382,10 +382,45 @@ def locality_score(W, perm=None, reach=None, sample=None):
     return float(np.mean(np.abs(r.astype(np.int64) - c.astype(np.int64)) <= reach))
 
 
+def expander_like(W, seeds=12):
+    """True when balls around sample vertices grow like in a random graph: the number of NEW vertices at distance 3
+    is about (mean degree) x the number at distance 2 - Erdos-Renyi, block models, small-world graphs - instead of
+    the r^(d-1) of a graph embedded in a few dimensions (k-NN graphs, meshes: a ratio of 1.5-2.5).  No vertex order
+    gives such a graph locality, so reverse Cuthill-McKee (a host algorithm, ~1 s at 10M entries) is not worth
+    running on it.  Looks at a few hundred rows of the CSR arrays only; `W` need not be validated."""
+    W = W if sparse.isspmatrix_csr(W) else sparse.csr_matrix(W)
+    N = W.shape[0]
+    if N < 64 or W.nnz == 0:
+        return False
+    indptr, indices = W.indptr, W.indices
+    mean_deg = W.nnz / N
+    ratios = []
+    for s in np.linspace(0, N - 1, seeds).astype(np.int64):
+        ball = frontier = np.array([s], dtype=np.int64)
+        sizes = []
+        for _ in range(3):
+            if frontier.size == 0 or frontier.size > 20000:
+                break
+            nbrs = np.unique(np.concatenate([indices[indptr[v]:indptr[v + 1]] for v in frontier]).astype(np.int64))
+            nbrs = nbrs[(nbrs >= 0) & (nbrs < N)]
+            new = np.setdiff1d(nbrs, ball, assume_unique=True)
+            ball = np.union1d(ball, new)
+            frontier = new
+            sizes.append(new.size)
+        if len(sizes) == 3 and sizes[1] > 0:
+            ratios.append(sizes[2] / sizes[1])
+    if len(ratios) < max(3, seeds // 3):
+        return False
+    return mean_deg >= 4 and float(np.median(ratios)) > 0.5 * mean_deg
+
+
 def auto_order(W, coords=None, device=0, ctx=None):
     """The internal order `reorder='auto'` picks: Morton order when coordinates exist, otherwise
     reverse Cuthill-McKee - but only if it beats the graph's own order on `locality_score`
     (block-structured graphs such as a sorted SBM are already local; RCM would scramble them)."""
+    has_coords = coords is not None and np.ndim(coords) == 2 and np.shape(coords)[0] == W.shape[0] and np.shape(coords)[1] >= 2
+    if not has_coords and expander_like(W):
+        return None  # a random-like graph: no order helps, skip the reverse Cuthill-McKee pass
     perm = locality_order(W, coords, device=device, ctx=ctx)
     if perm is None:
         return None

@@ -98,7 +98,11 @@ class Graph:
         if isinstance(order, str) and order == "rcm":
             return False
         if order == "auto" and getattr(self, "coords", None) is None and adjacency.shape[0] >= 4096:
-            return False  # no coordinates: reverse Cuthill-McKee is a host (scipy) algorithm
+            # no coordinates: the candidate order is reverse Cuthill-McKee, a host (scipy) algorithm - unless the graph
+            # is random-like (ER / SBM: balls grow by the mean degree per hop), where no order helps
+            if not engine.expander_like(adjacency):
+                return False
+            order = "none"
         if order in ("morton", "hilbert") and adjacency.shape[0] < 4096:
             return False  # an explicitly requested curve on a small graph: the numpy curves of engine.locality_order
         try:

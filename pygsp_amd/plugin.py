@@ -54,6 +54,8 @@ def device_graph_for(G, ctx=None):
         dev = None
         coords = _finite_coords(G)
         order = _config["reorder"]
+        if order == "auto" and coords is None and G.N >= 4096 and sparse.isspmatrix_csr(G.W) and engine.expander_like(G.W):
+            order = "none"  # a random-like graph (ER / SBM): no order helps, skip reverse Cuthill-McKee
         one_call = (_config["laplacian"] == "device" and sparse.isspmatrix_csr(G.W) and order in ("auto", "none", None, False)
                     and not (order == "auto" and coords is None and G.N >= 4096))  # (no coordinates: RCM is host work)
         if one_call:

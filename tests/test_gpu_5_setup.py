@@ -144,6 +144,11 @@ def test_int64_adjacency_and_small_graphs(ctx):
         G = graphs.Graph(Wi, lap_type=lap)
         assert G.setup_report["built"]
         assert abs(G.L - orc.laplacian(Wi.astype(np.float64), lap)).max() < 1e-14
+    # a large random graph without coordinates: recognised as random-like (engine.expander_like), so the one-call
+    # route is taken without a reverse Cuthill-McKee pass, in the graph's own order
+    Ge = graphs.ErdosRenyi(50000, p=10.0 / 50000, seed=3)
+    assert Ge.setup_report["built"] and not Ge.setup_report["reordered"] and Ge._internal_order() is None
+    assert abs(Ge.L - orc.laplacian(Ge.W.astype(np.float64))).max() < 1e-14
     for W in (sparse.csr_matrix((6, 6)), sparse.identity(6, format="csr"), sparse.csr_matrix((1, 1))):
         for lap in ("combinatorial", "normalized"):
             G = graphs.Graph(W, lap_type=lap)

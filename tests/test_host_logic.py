@@ -253,3 +253,22 @@ def test_bench_refuses_gpus_it_cannot_see():
         pytest.skip("two devices visible here")
     assert res.returncode != 0 and "refusing" in res.stderr
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_expander_like_tells_random_graphs_from_embedded_ones():
+    """engine.expander_like: balls of a random graph (ER, SBM) grow by the mean degree per hop, those of a k-NN graph
+    or a grid by a factor near 2 - the test that lets random graphs skip the reverse Cuthill-McKee pass."""
+    W_er, _ = graphs.sbm_weights(60000, k=1, p=10 / 60000, seed=0)
+    W_sbm, _ = graphs.sbm_weights(60000, k=8, p=8 * 12 / 60000, q=4.0 * 8 / (60000 * 7), seed=0)
+    W_knn, _ = graphs.sensor_weights(60000, k=8, seed=1)
+    assert engine.expander_like(W_er) and engine.expander_like(W_sbm)
+    assert not engine.expander_like(W_knn)
+    perm = np.random.default_rng(1).permutation(60000)
+    assert not engine.expander_like(W_knn[perm][:, perm].tocsr())  # a scrambled vertex order does not fool it
+    n = 200
+    idx = np.arange(n * n).reshape(n, n)
+    r = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()])
+    c = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()])
+    grid = sparse.csr_matrix((np.ones(r.size), (r, c)), shape=(n * n, n * n))
+    assert not engine.expander_like(sparse.csr_matrix(grid + grid.T))
+    assert not engine.expander_like(sparse.csr_matrix((100, 100)))  # empty / tiny graphs: no opinion
