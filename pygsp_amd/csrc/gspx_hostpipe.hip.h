@@ -117,7 +117,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
     fail(set_err(GSPX_ERR_HIP, "%s failed in the host pipeline: %s", what, hipGetErrorString(e)));
     return true;
   };
-  std::vector<double> pack_ms((size_t)P, 0.0), unpack_ms((size_t)Q, 0.0), prefault_ms((size_t)Q, 0.0);
+  std::vector<double> pack_ms((size_t)P, 0.0), unpack_ms((size_t)Q, 0.0);
   double h2d_ms = 0, d2h_ms = 0;
   auto width_of = [&](int b) { return widths[(size_t)b]; };
 
@@ -178,14 +178,12 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
     {  // While the first batch is still being packed, shipped and computed this thread has nothing to do: it faults
        // its rows of the result in now (y is usually fresh from the allocator; it is output-only, so touching it is
        // harmless), which takes the page faults and the kernel's page zeroing off the critical path.
-      const auto t0 = std::chrono::steady_clock::now();
       for (int pl = 0; pl < out_planes; ++pl) {
         volatile unsigned char* base = (volatile unsigned char*)(y + (size_t)pl * N * Nsig);
         const size_t lo = (size_t)r0 * Nsig * sizeof(T), hi = (size_t)r1 * Nsig * sizeof(T);
         for (size_t off = lo; off < hi; off += 4096) base[off] = 0;
         if (hi > lo) base[hi - 1] = 0;
       }
-      prefault_ms[(size_t)q] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     for (int b = 0; b < nb; ++b) {
       const int s = b & 1;

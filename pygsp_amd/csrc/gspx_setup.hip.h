@@ -194,7 +194,6 @@ static int radix_argsort(gspx_ctx* ctx, const unsigned long long* keys, int n, i
   const int* vin = nullptr;
   for (int p = 0; p < passes; ++p) {
     unsigned long long* kout = (p & 1) ? k3.as<unsigned long long>() : k2.as<unsigned long long>();
-    const bool last = p == passes - 1;
     // payload buffers alternate between v2 and order so that the final pass writes `order`
     int* vout = ((passes - 1 - p) & 1) ? v2.as<int>() : order;
     hipLaunchKernelGGL(gspx::k_radix_hist, dim3(ntiles), dim3(64), 0, st, kin, n, 8 * p, ntiles, hist.as<int>());
@@ -204,7 +203,6 @@ static int radix_argsort(gspx_ctx* ctx, const unsigned long long* keys, int n, i
     HIPCHK(hipGetLastError());
     kin = kout;
     vin = vout;
-    (void)last;
   }
   HIPCHK(hipStreamSynchronize(st));
   return GSPX_OK;

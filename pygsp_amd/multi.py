@@ -65,7 +65,7 @@ class DeviceGroup:
     def __len__(self):
         return len(self.ctxs)
 
-    def run(self, fn, barrier_timing=False):
+    def run(self, fn):
         """fn(i, ctx) on one thread per context; returns the list of results.  The first exception of any
         thread is re-raised here (after every thread has finished)."""
         n = len(self.ctxs)
