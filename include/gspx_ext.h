@@ -116,7 +116,9 @@ int gspx_knn_download_neighbors(gspx_knn* h, int32_t* nn, double* dist);
 /* Radius graphs: NNtype='radius' of NNGraph (nngraph.py:228-287) - neighbours within epsilon (the
  * KD-tree's ball query, squared distance <= epsilon^2), weights exp(-d^2 / sigma), sigma == 0 selects
  * the mean neighbour distance ("No neighbors found" -> GSPX_ERR_INVALID, as the reference's ValueError).
- * Result read with gspx_knn_info / gspx_knn_download_w, freed with gspx_knn_destroy. */
+ * 1 to 64 dimensions: a grid of epsilon-sized cells up to 3-D; beyond that the candidate pairs come from an MFMA
+ * distance sweep (a counting pass, then a filling pass into rows of exactly those lengths) and are tested in the
+ * KD-tree's arithmetic.  Result read with gspx_knn_info / gspx_knn_download_w, freed with gspx_knn_destroy. */
 int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, double epsilon,
                       double sigma, int metric, gspx_knn** out);
 

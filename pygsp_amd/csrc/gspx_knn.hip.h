@@ -935,13 +935,15 @@ extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* 
   *out = nullptr;
   if (metric < 0 || metric > 2) return set_err(GSPX_ERR_INVALID, "metric: 0 euclidean, 1 manhattan, 2 max_dist");
   if (N < 1 || N >= ((int64_t)1 << 31) / 64) return set_err(GSPX_ERR_INVALID, "gspx_radius_build: bad N");
-  if (d < 1 || d > 3)
-    return set_err(GSPX_ERR_INVALID, "gspx_radius_build: the device search covers 1 to 3 dimensions (got %d)", d);
+  if (d < 1 || d > 64)
+    return set_err(GSPX_ERR_INVALID, "gspx_radius_build: the device search covers 1 to 64 dimensions (got %d)", d);
   if (!coords) return set_err(GSPX_ERR_INVALID, "null coordinates");
   if (!(epsilon > 0) || !std::isfinite(epsilon)) return set_err(GSPX_ERR_INVALID, "epsilon must be positive");
   if (!(sigma >= 0) || !std::isfinite(sigma)) return set_err(GSPX_ERR_INVALID, "sigma must be >= 0 (0: mean distance)");
   KnnGrid g{};
-  g.d = d;
+  const bool grid_search = d <= 3;  // beyond three dimensions: MFMA candidate sweep + exact test (gspx_knn_bf.hip.h)
+  const int dg = grid_search ? d : 0;
+  g.d = dg;
   g.metric = metric;
   double hi[3] = {0, 0, 0};
   for (int j = 0; j < 3; ++j) {
@@ -949,19 +951,21 @@ extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* 
     g.inv_h[j] = 1;
     g.n[j] = 1;
   }
-  for (int j = 0; j < d; ++j) g.lo[j] = hi[j] = coords[j];
+  for (int j = 0; j < dg; ++j) g.lo[j] = hi[j] = coords[j];
   for (int64_t i = 0; i < N; ++i)
     for (int j = 0; j < d; ++j) {
       const double v = coords[i * d + j];
       if (!std::isfinite(v)) return set_err(GSPX_ERR_INVALID, "non-finite coordinate");
-      g.lo[j] = std::min(g.lo[j], v);
-      hi[j] = std::max(hi[j], v);
+      if (j < dg) {
+        g.lo[j] = std::min(g.lo[j], v);
+        hi[j] = std::max(hi[j], v);
+      }
     }
   // cells of at least epsilon (a little more, against rounding at the walls), at most `cap` per axis
   const int cap = d == 1 ? (1 << 21) : (d == 2 ? 2048 : 128);
   int64_t ncells = 1;
   g.h_min = 1e300;
-  for (int j = 0; j < d; ++j) {
+  for (int j = 0; j < dg; ++j) {
     const double ext = hi[j] - g.lo[j];
     int n = ext > 0 ? (int)std::min<double>((double)cap, std::floor(ext / (epsilon * 1.0000001))) : 1;
     n = std::max(n, 1);
@@ -1008,6 +1012,15 @@ extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* 
   KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)ncells + 1) * sizeof(int), st));
   KHIP(hipMemsetAsync(cnt.p, 0, ((size_t)N + 1) * sizeof(int), st));
   const int nbN = (n + 255) / 256;
+  const double eps2 = metric == 0 ? epsilon * epsilon : epsilon;  // threshold on the comparison key
+  DevMem c_off, c_buf;  // candidate lists of the brute-force search
+  const bool swept = !grid_search && metric == 0 && N > 256;
+  if (!grid_search) {
+    KHIP(hipStreamSynchronize(st));
+    if (swept) KCHK(radius_candidates(ctx, x.as<double>(), n, d, eps2, c_off, c_buf));
+    launch_bf_radius<0>(ctx, x.as<double>(), n, d, metric, eps2, swept ? c_off.as<int>() : nullptr,
+                        swept ? c_buf.as<int>() : nullptr, cnt.as<int>(), nullptr, nullptr, nullptr);
+  } else {
   hipLaunchKernelGGL(k_knn_cell_count, dim3(nbN), dim3(256), 0, st, x.as<double>(), n, g, cell.as<int>(),
                      count.as<int>());
   KCHK(scan_exclusive(ctx, count.as<int>(), start.as<int>(), (int)ncells + 1));
@@ -1015,10 +1028,10 @@ extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* 
                      cursor.as<int>(), order.as<int>());
   hipLaunchKernelGGL(k_knn_cell_sort, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st,
                      start.as<int>(), (int)ncells, order.as<int>(), x.as<double>(), d, sorted.as<double>());
-  const double eps2 = metric == 0 ? epsilon * epsilon : epsilon;  // threshold on the comparison key
   hipLaunchKernelGGL((k_radius_query<0>), dim3((n + 127) / 128), dim3(128), 0, st, sorted.as<double>(),
                      order.as<int>(), start.as<int>(), n, g, eps2, cnt.as<int>(), (const int*)nullptr,
                      (int*)nullptr, (double*)nullptr);
+  }
   KCHK(scan_exclusive(ctx, cnt.as<int>(), h->rowptr.as<int>(), n + 1));
   int nnz = 0;
   KHIP(hipMemcpyAsync(&nnz, h->rowptr.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1029,6 +1042,11 @@ extern "C" int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* 
   KCHK(h->val.alloc((size_t)std::max(nnz, 1) * sizeof(double)));
   KCHK(h->dist.alloc((size_t)std::max(nnz, 1) * sizeof(double)));
   if (nnz > 0) {
+    if (!grid_search)
+      launch_bf_radius<1>(ctx, x.as<double>(), n, d, metric, eps2, swept ? c_off.as<int>() : nullptr,
+                          swept ? c_buf.as<int>() : nullptr, nullptr, h->rowptr.as<int>(), h->col.as<int>(),
+                          h->dist.as<double>());
+    else
     hipLaunchKernelGGL((k_radius_query<1>), dim3((n + 127) / 128), dim3(128), 0, st, sorted.as<double>(),
                        order.as<int>(), start.as<int>(), n, g, eps2, (int*)nullptr, h->rowptr.as<int>(),
                        h->col.as<int>(), h->dist.as<double>());

@@ -134,13 +134,26 @@ __global__ __launch_bounds__(128) void k_bf_tau(const double* __restrict__ x, in
   tau[i] = kth;
 }
 
+// candidate lists: either N fixed-capacity rows (off == null; cap == 0: count only), or rows of their own lengths
+// (off[q] .. off[q + 1], from a counting sweep: the radius search, whose neighbourhoods have no common bound)
+__device__ __forceinline__ void bf_append(const int* __restrict__ off, int cap, int q, int slot, int c,
+                                          int* __restrict__ buf) {
+  if (off) {
+    const int lo = off[q];
+    if (slot < off[q + 1] - lo) buf[(size_t)lo + slot] = c;
+  } else if (slot < cap) {
+    buf[(size_t)q * cap + slot] = c;
+  }
+}
+
 // One wave = 64 queries (four 16-query tiles, their operands in registers), sweeping all point tiles: 4 x DT
 // MFMAs per point tile, then 16 (query, point) pairs per lane are tested against the query's bound.
 template <int DT>
 __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ xop, const double* __restrict__ norm,
                                                     const double* __restrict__ tau, int N, int phase, int step,
                                                     int count, double margin_scale, double norm_max, int cap,
-                                                    int* __restrict__ cnt, int* __restrict__ buf) {
+                                                    const int* __restrict__ off, int* __restrict__ cnt,
+                                                    int* __restrict__ buf) {
   const int lane = threadIdx.x & 63, kq = lane >> 4, cq = lane & 15;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q0 = wave * 64;
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
               const unsigned long long it = queue[lane];
               const int iq = (int)(it >> 32), ic = (int)(unsigned)it;
               const int slot = atomicAdd(&cnt[iq], 1);
-              if (slot < cap) buf[(size_t)iq * cap + slot] = ic;
+              bf_append(off, cap, iq, slot, ic, buf);
               const int rest = queued - 64;
               unsigned long long mv = 0;
               if (lane < rest) mv = queue[64 + lane];
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
     const unsigned long long it = queue[lane];
     const int iq = (int)(it >> 32), ic = (int)(unsigned)it;
     const int slot = atomicAdd(&cnt[iq], 1);
-    if (slot < cap) buf[(size_t)iq * cap + slot] = ic;
+    bf_append(off, cap, iq, slot, ic, buf);
   }
 }
 
@@ -427,7 +440,8 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   const dim3 grid((unsigned)((N + 255) / 256));
 #define GSPX_BF(D_, PH_, CNT_)                                                                                           \
   hipLaunchKernelGGL((gspx::k_bf_collect<D_>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),              \
-                     tau.as<double>(), N, PH_, step, CNT_, margin, nmax, cap, cnt.as<int>(), buf.as<int>())
+                     tau.as<double>(), N, PH_, step, CNT_, margin, nmax, cap, (const int*)nullptr, cnt.as<int>(),  \
+                     buf.as<int>())
   auto sweep = [&](int phase, int count) {
     if (DT == 4) GSPX_BF(4, phase, count);
     else if (DT == 8) GSPX_BF(8, phase, count);
@@ -457,5 +471,100 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
     stats[2] = s / N;
     stats[3] = scans;
   }
+  return GSPX_OK;
+}
+
+// ---- radius search in more than three dimensions (NNtype='radius', nngraph.py:228-287) -------------------------
+namespace gspx {
+
+// PASS 0: count the points within the radius (key <= eps2, the KD-tree's ball-query criterion in its own
+// arithmetic), PASS 1: write them at rowptr[i].  Candidates from the MFMA sweep (off / buf), or every point.
+template <int PASS, int DT>
+__global__ __launch_bounds__(128) void k_bf_radius(const double* __restrict__ x, int N, int d, int metric, double eps2,
+                                                   const int* __restrict__ off, const int* __restrict__ buf,
+                                                   int* __restrict__ cnt, const int* __restrict__ rowptr,
+                                                   int* __restrict__ col, double* __restrict__ dist) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  double q[4 * DT];
+  bf_load_query<DT>(q, x + (size_t)i * d, d);
+  const int lo = off ? off[i] : 0, n = off ? off[i + 1] - lo : N;
+  const int o = PASS ? rowptr[i] : 0;
+  int m = 0;
+  for (int a = 0; a < n; ++a) {
+    const int idx = off ? buf[(size_t)lo + a] : a;
+    if (idx == i) continue;
+    const double key = knn_key_reg<DT>(q, x + (size_t)idx * d, d, metric);
+    if (key <= eps2) {
+      if (PASS) {
+        col[o + m] = idx;
+        dist[o + m] = metric == 0 ? knn_sqrt(key) : key;
+      }
+      ++m;
+    }
+  }
+  if (!PASS) cnt[i] = m;
+}
+
+}  // namespace gspx
+
+template <int PASS>
+static void launch_bf_radius(gspx_ctx* ctx, const double* x, int N, int d, int metric, double eps2, const int* off,
+                             const int* buf, int* cnt, const int* rowptr, int* col, double* dist) {
+  const dim3 grid((unsigned)((N + 127) / 128));
+#define GSPX_BR(D_)                                                                                                   \
+  hipLaunchKernelGGL((gspx::k_bf_radius<PASS, D_>), grid, dim3(128), 0, ctx->stream, x, N, d, metric, eps2, off, buf, cnt, \
+                     rowptr, col, dist)
+  if (d <= 16) GSPX_BR(4);
+  else if (d <= 32) GSPX_BR(8);
+  else GSPX_BR(16);
+#undef GSPX_BR
+}
+
+// Candidate lists of the radius search: per query every point whose product-form squared distance is within
+// eps2 (+ the rounding margin).  Two sweeps with the same bound: one counts, one fills rows of exactly those lengths.
+// Leaves off (N + 1) and buf; euclidean only (the other metrics scan every point in k_bf_radius).
+static int radius_candidates(gspx_ctx* ctx, const double* x, int N, int d, double eps2, DevMem& off, DevMem& buf) {
+  hipStream_t st = ctx->stream;
+  const int DT = d <= 16 ? 4 : (d <= 32 ? 8 : 16);
+  const int ntiles = (N + 15) / 16;
+  DevMem xop, norm, tau, cnt;
+  CHK(xop.alloc((size_t)ntiles * DT * 64 * sizeof(double)));
+  CHK(norm.alloc((size_t)ntiles * 16 * sizeof(double)));
+  CHK(tau.alloc((size_t)N * sizeof(double)));
+  CHK(cnt.alloc(((size_t)N + 1) * sizeof(int)));
+  CHK(off.alloc(((size_t)N + 1) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(cnt.p, 0, ((size_t)N + 1) * sizeof(int), st));
+  const long long total = (long long)ntiles * DT * 64;
+  hipLaunchKernelGGL(gspx::k_bf_prepare, dim3((unsigned)((std::max<long long>(total, N) + 255) / 256)), dim3(256), 0, st, x,
+                     N, d, DT, xop.as<double>(), norm.as<double>());
+  hipLaunchKernelGGL((k_fill<double>), dim3(1024), dim3(256), 0, st, tau.as<double>(), (size_t)N, eps2);
+  std::vector<double> hn((size_t)N);
+  HIPCHK(hipMemcpyAsync(hn.data(), norm.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double nmax = 0;
+  for (double v : hn) nmax = std::max(nmax, v);
+  const double margin = 10.0 * (4.0 * DT + 8.0) * 1.1102230246251565e-16;
+  const dim3 grid((unsigned)((N + 255) / 256));
+  auto sweep = [&](const int* offp, int* bufp) {
+#define GSPX_BF(D_)                                                                                                  \
+  hipLaunchKernelGGL((gspx::k_bf_collect<D_>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),          \
+                     tau.as<double>(), N, 0, 1, ntiles, margin, nmax, 0, offp, cnt.as<int>(), bufp)
+    if (DT == 4) GSPX_BF(4);
+    else if (DT == 8) GSPX_BF(8);
+    else GSPX_BF(16);
+#undef GSPX_BF
+  };
+  sweep(nullptr, nullptr);  // count only
+  CHK(scan_exclusive(ctx, cnt.as<int>(), off.as<int>(), N + 1));
+  int total_c = 0;
+  HIPCHK(hipMemcpyAsync(&total_c, off.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (total_c < 0) return set_err(GSPX_ERR_INVALID, "gspx_radius_build: more than 2^31 candidate pairs (epsilon too large)");
+  CHK(buf.alloc((size_t)std::max(total_c, 1) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(cnt.p, 0, ((size_t)N + 1) * sizeof(int), st));
+  sweep(off.as<int>(), buf.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
   return GSPX_OK;
 }

@@ -933,7 +933,8 @@ def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False, metric="euclidea
 
 def radius_graph(coords, epsilon, sigma=None, ctx=None, metric="euclidean"):
     """Radius-graph weights on the device (gspx_radius_build): NNtype='radius' of NNGraph
-    (nngraph.py:228-287), euclidean, 1-3 dimensions.  Returns (W csr float64, sigma, info)."""
+    (nngraph.py:228-287) in 1 to 64 dimensions (a grid of epsilon-sized cells up to 3-D; beyond that the candidates of
+    an MFMA distance sweep, tested in the KD-tree's arithmetic).  Returns (W csr float64, sigma, info)."""
     ctx = ctx or default_context()
     X = np.ascontiguousarray(coords, dtype=np.float64)
     if X.ndim != 2:

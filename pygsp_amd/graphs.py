@@ -413,7 +413,7 @@ _MINKOWSKI = {1: "manhattan", 2: "euclidean", np.inf: "max_dist"}
 
 class NNGraph(Graph):
     """Nearest-neighbour graph from a point cloud (nngraphs/nngraph.py:13-313), built on the device
-    (NNtype='knn', the KD-tree query: 1 to 64 dimensions; NNtype='radius', the ball query: 1 to 3 dimensions), dist_type
+    (NNtype='knn', the KD-tree query, and NNtype='radius', the ball query: 1 to 64 dimensions), dist_type
     'euclidean' / 'manhattan' / 'max_dist', every symmetrize_type of utils.symmetrize.  Other settings
     raise NotImplementedError (no host fallback)."""
 

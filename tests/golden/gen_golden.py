@@ -257,6 +257,12 @@ def knn_highdim():
     G = graphs.NNGraph(X40, k=12, sigma=2.5)
     out["X40"] = X40
     out.update(csr_parts(G.W, "W40"))
+    # radius graphs beyond three dimensions (nngraph.py:228-287): about eight neighbours per point
+    G = graphs.NNGraph(X6, NNtype="radius", epsilon=0.125)
+    out.update(csr_parts(G.W, "W6_radius"))
+    out["sigma6_radius"] = np.float64(G.sigma)
+    G = graphs.NNGraph(out["X_p9"], NNtype="radius", epsilon=0.3, dist_type="manhattan")
+    out.update(csr_parts(G.W, "Wp9_radius_manhattan"))
     np.savez_compressed(os.path.join(OUT, "knn_highdim.npz"), **out)
 
 

@@ -305,6 +305,29 @@ def test_highdim_golden(ctx):
     assert abs(G.W - csr_from(g, "W6_maximum")).max() < 1e-14
     G = graphs.NNGraph(g["X40"], k=12, sigma=2.5)
     assert abs(G.W - csr_from(g, "W40")).max() < 1e-14
+    # radius graphs beyond three dimensions (nngraph.py:228-287)
+    G = graphs.NNGraph(g["X6"], NNtype="radius", epsilon=0.125)
+    Wref = csr_from(g, "W6_radius")
+    assert G.W.nnz == Wref.nnz and abs(G.W - Wref).max() < 1e-12 and abs(G.sigma - float(g["sigma6_radius"])) < 1e-13
+    G = graphs.NNGraph(g["X_p9"], NNtype="radius", epsilon=0.3, dist_type="manhattan")
+    Wref = csr_from(g, "Wp9_radius_manhattan")
+    assert G.W.nnz == Wref.nnz and abs(G.W - Wref).max() < 1e-12
+
+
+def test_highdim_radius_oracle(ctx):
+    """Ball queries in 5 to 40 dimensions against the KD-tree oracle: identical neighbour sets (the membership test runs
+    in the KD-tree's arithmetic on the candidates of the MFMA sweep), weights to 1e-12; a radius that catches nobody is
+    the reference's ValueError."""
+    rng = np.random.default_rng(17)
+    for N, d, eps in ((8000, 5, 0.6), (5000, 12, 2.2), (3000, 40, 6.4), (200, 6, 1.5)):
+        X = rng.standard_normal((N, d))
+        W, sg, _ = engine.radius_graph(X, eps, ctx=ctx)
+        Wr, sr = knn.radius_weights(X, eps)
+        assert W.nnz == Wr.nnz and W.nnz > 0, (N, d, W.nnz, Wr.nnz)
+        assert np.array_equal(W.indptr, Wr.indptr) and np.array_equal(W.indices, Wr.indices)
+        assert abs(sg - sr) <= 1e-12 * sr and np.max(np.abs(W.data - Wr.data) / Wr.data) < 1e-11
+    with pytest.raises(ValueError, match="No neighbors"):
+        engine.radius_graph(rng.standard_normal((500, 8)), 1e-3, ctx=ctx)
 
 
 @pytest.mark.parametrize("N,d,k", [(20000, 4, 6), (20000, 8, 10), (12000, 25, 10), (6000, 33, 17), (3000, 64, 40),

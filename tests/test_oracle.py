@@ -222,6 +222,11 @@ def test_knn_highdim_golden():
     assert abs(W - csr_from(g, "W6_maximum")).max() < 1e-15
     W, s, _, _ = knn.knn_weights(knn.preprocess(g["X40"]), 12, sigma=2.5)
     assert s == 2.5 and abs(W - csr_from(g, "W40")).max() < 1e-15
+    W, sg = knn.radius_weights(knn.preprocess(g["X6"]), 0.125)
+    Wref = csr_from(g, "W6_radius")
+    assert W.nnz == Wref.nnz and abs(W - Wref).max() < 1e-15 and abs(sg - float(g["sigma6_radius"])) < 1e-15
+    W, _ = knn.radius_weights(knn.preprocess(g["X_p9"]), 0.3, dist_type="manhattan")
+    assert W.nnz == csr_from(g, "Wp9_radius_manhattan").nnz and abs(W - csr_from(g, "Wp9_radius_manhattan")).max() < 1e-15
 
 
 def test_radius_golden(golden_knn):
