@@ -419,7 +419,9 @@ class RankWork:
                               tiles="auto" if a.tiles == "auto" else False)
         self.t_graph = time.perf_counter() - t0
         self.dev = self.G.device_graph()
+        t0 = time.perf_counter()
         self.G.estimate_lmax("bounds")
+        self.t_lmax_bounds = time.perf_counter() - t0
         self.lmax = float(self.G.lmax)
         # Heat(scale) coefficients, compute_cheby_coeff (approximations.py:9-55)
         self.c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(self.G, a.scale), m=K))
@@ -805,6 +807,12 @@ def main():
         assert np.array_equal(ch, coords)
         knn_diff = float(abs(Wh - W).max()) if Wh.nnz == W.nnz else float("inf")
         del Wh
+    t_lanczos = lanczos_ratio = None
+    if world == 1:  # the default estimate of Graph.lmax (graph.py:858-931): Lanczos on the device, beside the bound
+        t0 = time.perf_counter()
+        ritz, _ = dev.lanczos_lmax(max_iter=80, tol=5e-4)
+        t_lanczos = time.perf_counter() - t0
+        lanczos_ratio = ritz * 1.01 / lmax
     from pygsp_amd import filters
     if torch is not None:
         ty = torch.empty((1, N, nsig), dtype=torch.float64 if a.dtype == "f64" else torch.float32,
@@ -1075,7 +1083,9 @@ def main():
             "setup_s": {"graph_generation_host": t_gen, "graph_generation_device_knn": t_gen_dev,
                         "device_knn_build_ms": knn_info["build_ms"], "device_knn_max_abs_diff_vs_host": knn_diff,
                         "graph_object_incl_device_laplacian": t_graph,
-                        "device_laplacian_build_ms": dev.build_ms},
+                        "device_laplacian_build_ms": dev.build_ms,
+                        "estimate_lmax_bounds": rw.t_lmax_bounds, "estimate_lmax_lanczos_device": t_lanczos,
+                        "lanczos_ritz_over_bound": lanczos_ratio},
         }
 
     # ---- end to end through the mirrored API: numpy in -> Filter.filter -> numpy out (PCIe both ways,
