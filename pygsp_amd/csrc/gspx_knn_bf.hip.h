@@ -169,13 +169,11 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
   // this lane's 16 queries: q0 + 16 qt + kq + 4 e; bound minus the query's own norm (what is compared is
   // |y|^2 - 2 x.y), with the rounding margin of the product form
   double lim[4][4];
-  int qi[4][4];
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int q = q0 + 16 * qt + kq + 4 * e;
-      qi[qt][e] = q;
       if (q < N) {
         const double nq = norm[q];
         lim[qt][e] = tau[q] - nq + margin_scale * (nq + norm_max);
@@ -242,7 +240,7 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
           if (m != 0) {
             if (hit) {
               const int pos = queued + __popcll(m & lt_mask);
-              queue[pos] = ((unsigned long long)(unsigned)qi[qt][e] << 32) | (unsigned)c;
+              queue[pos] = ((unsigned long long)(unsigned)(q0 + 16 * qt + kq + 4 * e) << 32) | (unsigned)c;
             }
             queued += __popcll(m);
             if (queued >= 64) {  // at most 127 parked: room for one more round of 64
