@@ -182,7 +182,9 @@ int gspx_cheby_filter_dev(gspx_graph* g, double lmax, int Nf, int M, const doubl
  * over.  Large calls are cut into signal-column batches and pipelined over pinned staging buffers - host
  * threads pack batch b+2, DMA of b+1, kernels of b, DMA of b-1 and unpacking of b-2 overlap - so the call
  * costs about max(PCIe, kernels) instead of their sum; small calls are one copy in, the kernels, one copy
- * out (option "host_pipeline").  Bit-identical either way.  kernel_ms: device time of the kernels alone. */
+ * out (option "host_pipeline").  The automatic schedule returns the bytes of the one-shot call (every batch
+ * runs the same kernel family; an explicit "host_batch" below 32-byte rows is equal to rounding only).
+ * kernel_ms: device time of the kernels alone. */
 int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                       int64_t Nsig, const void* x_host, void* y_host, int mode,
                       double* kernel_ms);

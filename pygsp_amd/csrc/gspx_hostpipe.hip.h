@@ -289,6 +289,14 @@ static void host_pipeline_shape(const Options& opt, size_t elt, int64_t N, int64
   } else {
     for (int64_t c = 0; c < Nsig; c += w) widths->push_back(std::min<int64_t>(w, Nsig - c));
   }
+  // a ragged tail of less than 32-byte rows would run the sub-wave kernel, which sums a row's entries in another
+  // order than the tile / panel kernels: merged into its neighbour, so that the automatic schedule returns the
+  // bytes of the one-shot call
+  if (opt.host_batch <= 0 && widths->size() >= 2 && (size_t)widths->back() * elt < 32) {
+    const int64_t tail = widths->back();
+    widths->pop_back();
+    widths->back() += tail;
+  }
   int t = (int)opt.host_threads;
   if (t <= 0) {
     const unsigned hc = std::thread::hardware_concurrency();

@@ -511,10 +511,19 @@ def test_host_pipeline_equals_one_shot_call(ctx, dtype):
             assert same(p1, y1), (batch, threads)
             assert same(dev.cheby_filter(c3, x, lmax)[0], y3), (batch, threads)
             assert same(dev.cheby_filter(c3, s3, lmax, _capi.SYNTHESIS)[0], ys), (batch, threads)
-        # auto mode: a call of this size (25 MB in + out at fp64) stays on the one-shot path, a large one pipelines
-        ctx.set_option("host_pipeline", 1)
+        # the automatic schedule never leaves a ragged tail of under 32-byte rows (it is merged into the batch
+        # before it): identical bytes for every width
         ctx.set_option("host_batch", 0)
         ctx.set_option("host_threads", 0)
+        for w in (52, 50, 36):
+            xs = np.ascontiguousarray(x[:, :w])
+            ctx.set_option("host_pipeline", 0)
+            one = dev.cheby_filter(c1, xs, lmax)[0]
+            ctx.set_option("host_pipeline", 2)
+            assert np.array_equal(dev.cheby_filter(c1, xs, lmax)[0], one), w
+            assert ctx.last_host_timing() is not None
+        # auto mode: a call of this size (25 MB in + out at fp64) stays on the one-shot path, a large one pipelines
+        ctx.set_option("host_pipeline", 1)
         dev.cheby_filter(c1, x[:, :8].copy(), lmax)
         assert ctx.last_host_timing() is None
         big = rng.standard_normal((G.N, 128)).astype(dtype)
