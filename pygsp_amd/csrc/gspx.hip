@@ -315,7 +315,10 @@ struct Options {
   int64_t pair_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
   int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
-  int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
+  int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU; what fits for the small builds)
+  int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
+  int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
+  int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (2 / 4 / 8), 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
   int64_t tile_nt = -1;         // k_step_tile non-temporal accesses: bit 0 matrix entries, bit 2 T_{k-2} loads (each
@@ -418,6 +421,7 @@ struct gspx_graph {
   int gt_ns1 = 0;
   int gt_rows = 0, gt_nb = 0, gt_slow = 0;
   size_t gt_lds = 0;
+  int gt_entmax = 0;  // most stored entries of a staged block (sizes the LDS of the narrow builds)
   // differential operator (built on first use; gspx_ops.hip.h)
   int lap_type = GSPX_LAP_COMBINATORIAL;
   bool edges_built = false;
@@ -532,6 +536,9 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_gather")) return &o.tile_gather;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
+  if (!strcmp(key, "tile_lg")) return &o.tile_lg;
+  if (!strcmp(key, "tile_min_row")) return &o.tile_min_row;
+  if (!strcmp(key, "tile_pad")) return &o.tile_pad;
   if (!strcmp(key, "tile_nt")) return &o.tile_nt;
   if (!strcmp(key, "fuse_input")) return &o.fuse_input;
   if (!strcmp(key, "edge_vertex_walk")) return &o.edge_vertex_walk;
@@ -1226,7 +1233,7 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
   const size_t lds = (size_t)52 * 1024;
   const size_t esz = elt_size(g->dtype);
   std::vector<int> hdr((size_t)nb * 4);
-  int slow = 0;
+  int slow = 0, entmax = 0;
   for (int b = 0; b < nb; ++b) {
     const int lo = s1ptr[b], n1 = s1ptr[b + 1] - lo;
     const int r0 = b * block_rows, r1 = (int)std::min<int64_t>((int64_t)r0 + block_rows, g->N);
@@ -1239,6 +1246,7 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
                         (((size_t)ent * 2 + 15) & ~(size_t)15) + 32;
     const bool fast = n1 <= GSPX_TILE_MAXN1 && n1 < 65535 && need <= lds;
     slow += !fast;
+    if (fast) entmax = std::max(entmax, ent);
     hdr[(size_t)b * 4 + 0] = lo;
     hdr[(size_t)b * 4 + 1] = fast ? n1 : -1;
     hdr[(size_t)b * 4 + 2] = rp[r0];
@@ -1268,6 +1276,7 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
   g->gt_s1nat.release();
   g->gt_slow = slow;
   g->gt_lds = lds;
+  g->gt_entmax = entmax;
   if (stats) {
     stats[0] = nb;
     stats[1] = slow;
@@ -1309,8 +1318,11 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
                      tmp.as<int>(), n1.as<int>(), s1lo.as<int>(), (int)elt_size(g->dtype), (int)lds,
                      g->gt_s1rows.as<int>(), g->gt_lidx.as<unsigned char>(), g->gt_hdr.as<int>(),
                      nslow.as<int>());
-  int slow = 0;
+  int slow = 0, entmax = 0;
   HIPCHK(hipMemcpyAsync(&slow, nslow.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemsetAsync(nslow.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_tiles_entmax, dim3((nb + 255) / 256), dim3(256), 0, st, g->gt_hdr.as<int>(), nb, nslow.as<int>());
+  HIPCHK(hipMemcpyAsync(&entmax, nslow.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   g->gt_rows = GSPX_TILE_BR;
@@ -1319,6 +1331,7 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   g->gt_s1nat.release();
   g->gt_slow = slow;
   g->gt_lds = lds;
+  g->gt_entmax = entmax;
   if (stats) {
     stats[0] = nb;
     stats[1] = slow;
@@ -1575,7 +1588,7 @@ static void launch_permute_in(const T* x, unsigned ldx, T* out, unsigned ld, int
 template <typename T, int VEC>
 static void launch_combine_v(const T* slots, int nslots, size_t slot_stride, const T* cf, int M,
                              int nf, int N, unsigned ld, T* y, unsigned ldy, size_t plane_y,
-                             const int* perm, hipStream_t st) {
+                             const int* perm, hipStream_t st, unsigned pitch) {
   const size_t total = (size_t)N * (ld / VEC);
   const unsigned nb = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
   if (nb == 0) return;
@@ -1583,24 +1596,25 @@ static void launch_combine_v(const T* slots, int nslots, size_t slot_stride, con
   for (int f0 = 0; f0 < nf; f0 += NFB) {
     const int here = std::min(NFB, nf - f0);
     hipLaunchKernelGGL((k_combine<T, VEC, NFB>), dim3(nb), dim3(256), 0, st, slots, nslots,
-                       slot_stride, cf, M, f0, here, N, ld, y, ldy, plane_y, perm, 0);
+                       slot_stride, cf, M, f0, here, N, ld, y, ldy, plane_y, perm, 0, pitch);
   }
 }
 
 template <typename T>
 static void launch_combine(const T* slots, int nslots, size_t slot_stride, const T* cf, int M,
                            int nf, int N, unsigned ld, T* y, unsigned ldy, size_t plane_y,
-                           const int* perm, int vec, hipStream_t st) {
+                           const int* perm, int vec, hipStream_t st, unsigned pitch = 0) {
+  if (!pitch) pitch = ld;
   if constexpr (sizeof(T) == 4) {
     if (vec == 4)
       return launch_combine_v<T, 4>(slots, nslots, slot_stride, cf, M, nf, N, ld, y, ldy, plane_y,
-                                    perm, st);
+                                    perm, st, pitch);
   }
   if (vec == 2)
     return launch_combine_v<T, 2>(slots, nslots, slot_stride, cf, M, nf, N, ld, y, ldy, plane_y,
-                                  perm, st);
+                                  perm, st, pitch);
   return launch_combine_v<T, 1>(slots, nslots, slot_stride, cf, M, nf, N, ld, y, ldy, plane_y,
-                                perm, st);
+                                perm, st, pitch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1656,48 +1670,71 @@ static int ensure_s1nat(gspx_graph* g, hipStream_t st) {
   return GSPX_OK;
 }
 
+// a work panel of row pitch ld can take the tile kernels
+template <typename T> static bool tile_geometry(const gspx_graph* g, const Options& opt, unsigned ld) {
+  constexpr int TVEC = 16 / (int)sizeof(T);
+  const size_t U = (size_t)g->N * ld;
+  return opt.tile_gather && g->gt_rows == GSPX_TILE_BR && (size_t)ld * sizeof(T) >= (size_t)opt.tile_min_row &&
+         (ld % TVEC) == 0 && U * sizeof(T) < ((size_t)1 << 31) && (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31);
+}
+// ... and the final flush can store 16-byte pieces straight into y
 template <typename T>
 static bool tile_usable(const gspx_graph* g, const Options& opt, unsigned ld, const T* y, unsigned ldy) {
   constexpr int TVEC = 16 / (int)sizeof(T);
-  const size_t U = (size_t)g->N * ld;
-  // (rows of 16 bytes - 2 fp64 / 4 fp32 signals - stay with the narrow kernel, which measured faster there)
-  return opt.tile_gather && g->gt_rows == GSPX_TILE_BR && (size_t)ld * sizeof(T) >= 32 && (ld % TVEC) == 0 &&
-         (ldy % TVEC) == 0 &&
-         (((uintptr_t)y / sizeof(T)) % TVEC) == 0 && U * sizeof(T) < ((size_t)1 << 31) &&
-         (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31);
+  return tile_geometry<T>(g, opt, ld) && (ldy % TVEC) == 0 && (((uintptr_t)y / sizeof(T)) % TVEC) == 0;
 }
 // fills the graph / geometry fields of t and launches; the caller sets cur, old, out, racc, y,
 // ldy, perm, scale, gamma, beta, flush, final, wn, wc, wo
 template <typename T>
 static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, unsigned ld, hipStream_t st,
                             const T* vals = nullptr) {
-  // narrow panels (rows of at most 128 bytes): 8-lane row groups, or half of every 16-lane group idles
-  const bool narrow = (size_t)ld * sizeof(T) <= 128;
-  const int ncol = narrow ? 1 : (int)(((size_t)ld * sizeof(T) + 255) / 256);
-  void (*kern)(const TileArgs<T>) = narrow      ? k_step_tile<T, 1, 8>
-                                    : ncol == 1 ? k_step_tile<T, 1>
-                                    : ncol == 2 ? k_step_tile<T, 2>
-                                                : k_step_tile<T, 0>;
-  if (t.old_rows)  // T_{k-2} read from the caller's unpermuted panel (step 2 of a fused-input filter)
-    kern = narrow      ? k_step_tile<T, 1, 8, true>
-           : ncol == 1 ? k_step_tile<T, 1, 16, true>
-           : ncol == 2 ? k_step_tile<T, 2, 16, true>
-                       : k_step_tile<T, 0, 16, true>;
-  if (t.nin > 0)  // extra input panels (synthesis): never together with old_rows
-    kern = narrow      ? k_step_tile<T, 1, 8, false, true>
-           : ncol == 1 ? k_step_tile<T, 1, 16, false, true>
-           : ncol == 2 ? k_step_tile<T, 2, 16, false, true>
-                       : k_step_tile<T, 0, 16, false, true>;
-  {  // once per kernel build and device (a driver call per launch would cost microseconds each)
-    static std::map<std::pair<const void*, int>, size_t> lds_set;
+  // narrow panels (rows of at most 128 bytes): 8- / 4- / 2-lane row groups in workgroups of 512 / 256 / 128
+  // threads - every lane holds a piece of a row, and the smaller workgroups keep more blocks in flight per CU
+  const size_t rowb = (size_t)ld * sizeof(T);
+  int lg = rowb <= 32 ? 2 : rowb <= 64 ? 4 : rowb <= 128 ? 8 : 16;
+  if (opt.tile_lg == 8 || opt.tile_lg == 4) lg = rowb <= 128 ? std::max(lg, (int)opt.tile_lg) : 16;  // (tuning)
+  // (several column chunks per block with the small builds lose to the 16-lane build: 96- / 192-byte rows 4.1 / 6.7 ms
+  // against 2.7 / 4.9 ms on the headline graph - a pass per chunk costs more than the idle lanes of a last chunk)
+  const bool narrow = lg < 16;
+  const int ncol = narrow ? 1 : (int)((rowb + 255) / 256);
+  const int flavour = t.old_rows ? 1 : t.nin > 0 ? 2 : 0;  // plain | T_{k-2} from the caller's unpermuted panel
+                                                           // (step 2 of a fused-input filter) | extra input panels
+                                                           // (synthesis); never both
+  typedef void (*kern_t)(const TileArgs<T>);
+  static const kern_t wide[3][3] = {
+      {k_step_tile<T, 0>, k_step_tile<T, 1>, k_step_tile<T, 2>},
+      {k_step_tile<T, 0, 16, true>, k_step_tile<T, 1, 16, true>, k_step_tile<T, 2, 16, true>},
+      {k_step_tile<T, 0, 16, false, true>, k_step_tile<T, 1, 16, false, true>, k_step_tile<T, 2, 16, false, true>}};
+  static const kern_t slim[3][3] = {
+      {k_step_tile<T, 1, 2, false, false, 128>, k_step_tile<T, 1, 4, false, false, 256>, k_step_tile<T, 1, 8>},
+      {k_step_tile<T, 1, 2, true, false, 128>, k_step_tile<T, 1, 4, true, false, 256>, k_step_tile<T, 1, 8, true>},
+      {k_step_tile<T, 1, 2, false, true, 128>, k_step_tile<T, 1, 4, false, true, 256>, k_step_tile<T, 1, 8, false, true>}};
+  const kern_t kern = narrow ? slim[flavour][lg == 2 ? 0 : lg == 4 ? 1 : 2] : wide[flavour][ncol <= 2 ? ncol : 0];
+  const unsigned threads = narrow ? 64u * (unsigned)lg : 512u;
+  // dynamic LDS: the wide builds take the tile budget the blocks were classified with; a narrow build's tile
+  // rows are 16 lg bytes, so the largest staged block needs far less - and more workgroups fit a CU
+  size_t lds = g->gt_lds;
+  if (lg < 8)
+    lds = std::min(lds, (size_t)GSPX_TILE_MAXN1 * 16 * lg + (((size_t)g->gt_entmax * sizeof(T) + 15) & ~(size_t)15) +
+                            (((size_t)g->gt_entmax + 15) & ~(size_t)15) + 64);
+  int per_cu = 2;
+  {  // once per kernel build, device and LDS size (a driver call per launch would cost microseconds each)
+    static std::map<std::pair<const void*, int>, std::pair<size_t, int>> lds_set;
     static std::mutex lds_mu;
     std::lock_guard<std::mutex> lock(lds_mu);
     const auto key = std::make_pair((const void*)kern, g->ctx->device);
     auto it = lds_set.find(key);
-    if (it == lds_set.end() || it->second != g->gt_lds) {
-      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gt_lds));
-      lds_set[key] = g->gt_lds;
+    if (it == lds_set.end() || it->second.first != lds) {
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int fit = 2;
+      if (lg < 8) {  // resident workgroups of the small builds: what registers and LDS allow
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (const void*)kern, (int)threads, lds));
+        fit = std::max(2, std::min(fit, 16));
+      }
+      lds_set[key] = std::make_pair(lds, fit);
+      it = lds_set.find(key);
     }
+    per_cu = it->second.second;
   }
   t.rowptr = g->rptr.as<int>();
   t.col = g->rcol.as<int>();
@@ -1713,12 +1750,12 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   t.nb = g->gt_nb;
   t.ncol = ncol;
   t.per_xcd = (t.nb + 7) / 8;
-  t.lds_bytes = (int)g->gt_lds;
-  unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)g->ctx->cu_count) / 8 * 8);
+  t.lds_bytes = (int)lds;
+  unsigned nwg = (unsigned)std::max<int64_t>(8, ((int64_t)per_cu * g->ctx->cu_count) / 8 * 8);
   if (opt.tile_workgroups > 0)
     nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
   t.nt = opt.tile_nt >= 0 ? (int)opt.tile_nt : ((size_t)g->N * ld * sizeof(T) >= ((size_t)192 << 20) ? 5 : 0);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), g->gt_lds, st, t);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), lds, st, t);
   return GSPX_OK;
 }
 
@@ -1745,7 +1782,15 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const int K = M - 1;
-  const size_t U = (size_t)N * ld;  // elements per panel
+  // Rows that are not made of 16-byte pieces (or a y the final flush cannot store such pieces into): the work
+  // panels get padded rows of pitch ldw, so that the tile kernels take them all the same - zero columns cost
+  // little next to kernels that are several times faster - and the result leaves through a copy.
+  constexpr unsigned TVEC = 16 / (unsigned)sizeof(T);
+  const unsigned ldp = (ld + TVEC - 1) / TVEC * TVEC;
+  const bool tile_direct = (deferred || nf == 1) && tile_usable<T>(g, opt, ld, y, ldy);
+  const bool padded = !tile_direct && (deferred || nf == 1) && opt.tile_pad && tile_geometry<T>(g, opt, ldp);
+  const unsigned ldw = padded ? ldp : ld;
+  const size_t U = (size_t)N * ldw;  // elements per panel
   // vector stores into y need aligned rows: cap the lane vector width accordingly
   int veccap = 4;
   while (veccap > 1 && ((ldy % veccap) != 0 || (((uintptr_t)y / sizeof(T)) % veccap) != 0))
@@ -1794,7 +1839,7 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   }
   // LDS-staged gather: one filter with the fused flush
   // (or a filterbank's deferred combine, whose steps are plain recurrence steps into kept slots)
-  const bool tile_ok = (deferred || nf == 1) && tile_usable<T>(g, opt, ld, y, ldy);
+  const bool tile_ok = tile_direct || padded;
   // Fused input: step 1 gathers straight from the caller's panel (the tile lists mapped through the
   // vertex order) and step 2 reads T_0 from it, so the copy into the internal order never happens.
   // Needs every block on the LDS path, the panel in the internal row pitch, and x not aliasing y
@@ -1802,11 +1847,14 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   const unsigned char* xb = (const unsigned char*)x;
   const unsigned char* yb = (const unsigned char*)y;
   const size_t xbytes = (size_t)N * ldx * sizeof(T), ybytes = (size_t)nf * N * ldy * sizeof(T);
-  const bool fuse_in = tile_ok && !deferred && opt.fuse_input && g->gt_slow == 0 && ldx == ld &&
+  const bool fuse_in = tile_direct && !deferred && opt.fuse_input && g->gt_slow == 0 && ldx == ld &&
                        ((uintptr_t)x % 16) == 0 && (xb + xbytes <= yb || yb + ybytes <= xb) &&
                        (!g->has_perm || (g->gt_ns1 > 0 && (!cap || g->gt_s1nat.p)));
   if (fuse_in) {
     CHK(ensure_s1nat(g, st));
+  } else if (padded) {
+    const unsigned nb = (unsigned)std::min<size_t>((U + 255) / 256, 65536);
+    hipLaunchKernelGGL((k_permute_in_pad<T>), dim3(nb), dim3(256), 0, st, x, ldx, slots, ldw, ld, N, perm);
   } else {
     // permute-in vector width: x rows must be aligned too
     int pvec = shape.vec;
@@ -1857,14 +1905,14 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
       t.gamma = (T)ps.gamma;
       t.beta = T(0);
       t.flush = ps.flush;
-      t.final = ps.final;
+      t.final = padded ? 0 : ps.final;  // padded rows: the last flush stays in the accumulator panel, copied out below
       t.reverse = (opt.alternate_sweep && (k & 1)) ? 1 : 0;
       if (ps.flush) {
         t.wn = (T)ps.w[0];
         t.wc = (T)ps.w[1];
         t.wo = (T)ps.w[2];
       }
-      CHK(launch_step_tile<T>(g, opt, t, ld, st));
+      CHK(launch_step_tile<T>(g, opt, t, ldw, st));
       continue;
     }
     if (deferred) {
@@ -1890,7 +1938,10 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
     int cvec = shape.vec;
     while (cvec > 1 && ((ldy % cvec) != 0 || (((uintptr_t)y / sizeof(T)) % cvec) != 0)) cvec /= 2;
     launch_combine<T>(slots, M, SU, ctx->ws_w.as<T>(), M, nf, N, ld, y, ldy, (size_t)N * ldy, perm,
-                      cvec, st);
+                      padded ? 1 : cvec, st, ldw);
+  } else if (padded && final_to_y) {
+    const unsigned nb = (unsigned)std::min<size_t>(((size_t)N * ld + 255) / 256, 65536);
+    hipLaunchKernelGGL((k_permute_out_pad<T>), dim3(nb), dim3(256), 0, st, racc, ldw, y, ldy, ld, N, perm);
   }
   if (!cap) {
     HIPCHK(hipEventRecord(e3, st));

@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_combine(const T* __restrict__ slots, in
                                                  size_t slot_stride, const T* __restrict__ cf,
                                                  int M, int f0, int nf_here, int N, u32 ld, T* y,
                                                  u32 ldy, size_t plane_y, const int* __restrict__ perm,
-                                                 int accumulate) {
+                                                 int accumulate, u32 pitch) {  // pitch: slot row pitch (>= ld)
   typedef typename VT<T, VEC>::t V;
   const u32 cpr = ld / VEC;  // vector chunks per row
   const size_t total = (size_t)N * cpr;
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_combine(const T* __restrict__ slots, in
        idx += (size_t)gridDim.x * 256) {
     const u32 row = (u32)(idx / cpr);
     const u32 ch = (u32)(idx - (size_t)row * cpr);
-    const size_t o = (size_t)row * ld + (size_t)ch * VEC;
+    const size_t o = (size_t)row * pitch + (size_t)ch * VEC;
     V acc[NFB];
 #pragma unroll
     for (int f = 0; f < NFB; ++f) acc[f] = 0;
@@ -1305,6 +1305,33 @@ __global__ __launch_bounds__(256) void k_permute_in(const T* __restrict__ x, u32
     const size_t src = perm ? (size_t)perm[row] : (size_t)row;
     *(V*)(out + (size_t)row * ld + (size_t)ch * VEC) =
         *(const V*)(x + src * ldx + (size_t)ch * VEC);
+  }
+}
+
+// Panels whose rows are not made of 16-byte pieces (an odd number of fp64 signals, fp32 signals not in fours, a
+// misaligned y) are worked on with padded rows, so that they take the tile kernels too:
+//   in:  T_0[i][c] = c < ld ? x[perm[i]][c] : 0      (row pitch ldw of the work panel)
+//   out: y[perm[i]][c] = r[i][c], c < ld
+template <typename T>
+__global__ __launch_bounds__(256) void k_permute_in_pad(const T* __restrict__ x, u32 ldx, T* __restrict__ out,
+                                                        u32 ldw, u32 ld, int N, const int* __restrict__ perm) {
+  const size_t total = (size_t)N * ldw;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const u32 row = (u32)(idx / ldw);
+    const u32 c = (u32)(idx - (size_t)row * ldw);
+    const size_t src = perm ? (size_t)perm[row] : (size_t)row;
+    out[idx] = c < ld ? x[src * ldx + c] : T(0);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_permute_out_pad(const T* __restrict__ r, u32 ldw, T* __restrict__ y, u32 ldy,
+                                                         u32 ld, int N, const int* __restrict__ perm) {
+  const size_t total = (size_t)N * ld;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const u32 row = (u32)(idx / ld);
+    const u32 c = (u32)(idx - (size_t)row * ld);
+    const size_t dst = perm ? (size_t)perm[row] : (size_t)row;
+    y[dst * ldy + c] = r[(size_t)row * ldw + c];
   }
 }
 

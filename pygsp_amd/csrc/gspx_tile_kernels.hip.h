@@ -62,8 +62,10 @@ template <typename T> struct TileArgs {
 constexpr int GSPX_TILE_BR = 64;      // rows per block
 constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group)
 
-// LG = lanes per row group: 16 (256-byte column chunks; 32 groups x 2 rows) or 8 (128-byte chunks for
-// narrow panels; 64 groups x 1 row).  NCOL = 1, 2: that many column chunks per row; 0: a.ncol chunks
+// LG = lanes per row group: 16 (256-byte column chunks; 32 groups x 2 rows) or, for narrow panels, 8 / 4 / 2
+// (128- / 64- / 32-byte rows; 64 groups x 1 row, NT = 64 LG threads per workgroup: every lane has a piece of a
+// row, and the smaller workgroups keep more blocks in flight per CU - a narrow pass moves little data per
+// memory round trip).  NCOL = 1, 2: that many column chunks per row; 0: a.ncol chunks
 // OLDNAT: T_{k-2} rows are read through a.old_rows (step 2 of a filter whose input panel was not
 // copied into the internal order first)
 // Software pipelining of a pass (round 2; measured per panel shape on one box against the previous build,
@@ -90,8 +92,9 @@ template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
 
 // INS: the step adds extra input panels to the row (synthesis by Clenshaw, a.nin > 0) - its own build, so
 // that the analysis path does not carry their registers across the row products
-template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false>
-__global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
+template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false, int NT = 512>
+__global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
+  static_assert(NT == 512 || (NT == 64 * LG && NCOL == 1), "narrow builds: one row per group, one chunk per row");
   constexpr bool PF = TileSchedule<T, NCOL, LG, OLDNAT>::PF;
   constexpr bool META_AFTER = TileSchedule<T, NCOL, LG, OLDNAT>::META_AFTER;
   constexpr bool TILE_LAST = TileSchedule<T, NCOL, LG, OLDNAT>::TILE_LAST;
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gspx_smem[];
 
   const int tid = threadIdx.x;
-  constexpr int NG = 512 / LG;             // row groups per workgroup
+  constexpr int NG = NT / LG;              // row groups per workgroup
+  constexpr int NE = 512 / NT;             // 16-byte pieces of matrix values a thread prefetches
   constexpr int RPG = GSPX_TILE_BR / NG;   // rows of the block per group
   constexpr int ST = (GSPX_TILE_MAXN1 + NG - 1) / NG;  // tile rows a group stages
   constexpr int RB = LG * 16;              // bytes of a tile row
@@ -172,7 +176,9 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   // entries.  By the time the pass reaches its first barrier they are as old as the tile loads, so the
   // barrier does not expose a fresh memory round trip every pass.
   V ov[RPG], ra[RPG];
-  u32x4 ev = 0, ei = 0;
+  u32x4 ev[NE], ei = 0;
+#pragma unroll
+  for (int q = 0; q < NE; ++q) ev[q] = 0;
   auto prefetch_rows = [&](const Meta& m, int blk, int c) {
     const int r0 = phys(blk) * GSPX_TILE_BR + grp * RPG;
     const u32 cb = chunk_off(c);
@@ -190,15 +196,16 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
   };
   auto prefetch_entries = [&](const int4& h) {  // the block's slice of matrix entries, coalesced 16-byte pieces
     const int nv16 = (h.w * (int)sizeof(T) + 15) >> 4, ni16 = (h.w + 15) >> 4;
-    const u32 vo = tid < nv16 ? (u32)h.z * (u32)sizeof(T) + tid * 16u : POISON;
     const u32 io = tid < ni16 ? (u32)h.z + tid * 16u : POISON;
-    if (a.nt & 1) {
-      ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 2);
-      ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 2);
-    } else {
-      ev = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0);
-      ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int i = tid + q * NT;
+      const u32 vo = i < nv16 ? (u32)h.z * (u32)sizeof(T) + i * 16u : POISON;
+      if (a.nt & 1) ev[q] = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 2);
+      else ev[q] = __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0);
     }
+    if (a.nt & 1) ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 2);
+    else ei = __builtin_amdgcn_raw_buffer_load_b128(ri, io, 0, 0);
   };
 
   int4 H = uniform(load_hdr(k0));
@@ -261,12 +268,14 @@ __global__ __launch_bounds__(512, 4) void k_step_tile(const TileArgs<T> a) {
     __builtin_amdgcn_sched_barrier(0);
     if (first && fast) {  // the entries (fetched one pass ahead) go to LDS, once for all chunks of the block
       const int nv16 = (ent * (int)sizeof(T) + 15) >> 4, ni16 = (ent + 15) >> 4;
-      if (tid < nv16) *(u32x4*)((unsigned char*)mval + tid * 16) = ev;
+#pragma unroll
+      for (int q = 0; q < NE; ++q)
+        if (tid + q * NT < nv16) *(u32x4*)((unsigned char*)mval + (tid + q * NT) * 16) = ev[q];
       if (tid < ni16) *(u32x4*)((unsigned char*)midx + tid * 16) = ei;
-      for (int i = tid + 512; i < nv16; i += 512)  // slices longer than 8 KiB of values: rare
+      for (int i = tid + 512; i < nv16; i += NT)  // slices longer than 8 KiB of values: rare
         *(u32x4*)((unsigned char*)mval + i * 16) =
             __builtin_amdgcn_raw_buffer_load_b128(rv, (u32)rp0 * (u32)sizeof(T) + i * 16u, 0, 0);
-      for (int i = tid + 512; i < ni16; i += 512)
+      for (int i = tid + NT; i < ni16; i += NT)
         *(u32x4*)((unsigned char*)midx + i * 16) =
             __builtin_amdgcn_raw_buffer_load_b128(ri, (u32)rp0 + i * 16u, 0, 0);
     }
@@ -509,6 +518,12 @@ __global__ __launch_bounds__(256) void k_tiles_fill(const int* __restrict__ rowp
   }
 }
 // kept rows per block for the scan (a slow block beyond the cap contributes none)
+// most stored entries of a staged block
+__global__ void k_tiles_entmax(const int* __restrict__ hdr, int nb, int* __restrict__ out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < nb && hdr[(size_t)b * 4 + 1] >= 0) atomicMax(out, hdr[(size_t)b * 4 + 3]);
+}
+
 __global__ void k_tiles_keep(const int* __restrict__ n1, int nb, int* __restrict__ keep) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b <= nb) keep[b] = (b < nb && n1[b] <= GSPX_TILE_TMPCAP) ? n1[b] : 0;

@@ -254,7 +254,9 @@ def test_tile_gather_kernel(ctx, dtype):
             assert stats["slow_blocks"] * 20 < stats["nb"], stats
         else:                 # vertex order of the generator: no locality, the plain-gather path
             assert stats["slow_blocks"] > stats["nb"] // 2, stats
-        for nsig in (4, 8, 32, 64, 100, 128):
+        # (1, 3, 5, 6, 10, 18: rows that are not made of 16-byte pieces take the tile kernels with padded rows;
+        # 2 / 4 / 8 / 16: the 2- / 4- / 8-lane builds)
+        for nsig in (1, 2, 3, 4, 5, 6, 8, 10, 16, 18, 32, 64, 100, 128):
             x = rng.standard_normal((W.shape[0], nsig))
             x64 = x.astype(dtype).astype(np.float64)
             for order in (30, 7, 3, 2, 1):
@@ -286,6 +288,14 @@ def test_tile_gather_kernel(ctx, dtype):
         yb, _ = dev.cheby_filter(cb, x, lmax)
         refb = orc.cheby_op(L, lmax, cb, x.astype(dtype).astype(np.float64)).reshape(3, -1, 8)
         assert rel_err(yb, refb) < tol
+        for w in (1, 3, 7):  # padded rows through the deferred combine
+            yw, _ = dev.cheby_filter(cb, np.ascontiguousarray(x[:, :w]), lmax)
+            assert rel_err(yw, refb[:, :, :w]) < tol, w
+            if perm is not None:  # (same kernels, same order of operations: the padded columns change nothing)
+                ctx.set_option("tile_pad", 0)
+                y_plain, _ = dev.cheby_filter(cb, np.ascontiguousarray(x[:, :w]), lmax)
+                ctx.set_option("tile_pad", 1)
+                assert rel_err(y_plain, refb[:, :, :w]) < tol, w
         # synthesis (vector-coefficient Clenshaw): the extra input panels are summed in the tile kernel
         s3 = rng.standard_normal((3, W.shape[0], 8))
         refs = sum(orc.cheby_op(L, lmax, cb[f], s3[f].astype(dtype).astype(np.float64)) for f in range(3))
