@@ -317,6 +317,7 @@ struct Options {
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU; what fits for the small builds)
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
+                                // (rows under 16 bytes only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (2 / 4 / 8), 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
@@ -1693,6 +1694,8 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   const size_t rowb = (size_t)ld * sizeof(T);
   int lg = rowb <= 32 ? 2 : rowb <= 64 ? 4 : rowb <= 128 ? 8 : 16;
   if (opt.tile_lg == 8 || opt.tile_lg == 4) lg = rowb <= 128 ? std::max(lg, (int)opt.tile_lg) : 16;  // (tuning)
+  // (the 8-lane build in 256-thread workgroups with two rows per group - four resident workgroups instead of two -
+  // measured within 3 % of the 512-thread build on 80- to 128-byte rows: those passes are not latency bound.)
   // (several column chunks per block with the small builds lose to the 16-lane build: 96- / 192-byte rows 4.1 / 6.7 ms
   // against 2.7 / 4.9 ms on the headline graph - a pass per chunk costs more than the idle lanes of a last chunk)
   const bool narrow = lg < 16;
@@ -1788,7 +1791,12 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   constexpr unsigned TVEC = 16 / (unsigned)sizeof(T);
   const unsigned ldp = (ld + TVEC - 1) / TVEC * TVEC;
   const bool tile_direct = (deferred || nf == 1) && tile_usable<T>(g, opt, ld, y, ldy);
-  const bool padded = !tile_direct && (deferred || nf == 1) && opt.tile_pad && tile_geometry<T>(g, opt, ldp);
+  // (rows under 16 bytes - one fp64 signal, up to three fp32 ones - on a graph whose matrix stays in the L2s: the
+  // sub-wave kernel is the faster one there, 0.125 against 0.150 ms for 30 orders at N = 50k; from ~20 MB of matrix
+  // on the padded tile path wins, 0.89 against 1.19 ms at N = 1M.  Wider odd rows: the tile path at every size.)
+  const bool pad_pays = opt.tile_pad == 2 || (size_t)ld * sizeof(T) >= 16 ||
+                        (size_t)g->nnz_int * (sizeof(T) + 4) >= ((size_t)20 << 20);
+  const bool padded = !tile_direct && (deferred || nf == 1) && opt.tile_pad && pad_pays && tile_geometry<T>(g, opt, ldp);
   const unsigned ldw = padded ? ldp : ld;
   const size_t U = (size_t)N * ldw;  // elements per panel
   // vector stores into y need aligned rows: cap the lane vector width accordingly

@@ -22,7 +22,7 @@ def test_fuzz_against_oracle(seed):
     finally:
         for k, v in (("kernel", 0), ("tile_gather", 1), ("graph_launch", 2), ("xcd_remap", 1), ("alternate_sweep", 1),
                      ("combine", 0), ("synthesis", 0), ("max_batch", 0), ("host_pipeline", 1), ("host_batch", 0),
-                     ("host_edge", 0), ("host_threads", 0)):
+                     ("host_edge", 0), ("host_threads", 0), ("tile_pad", 1), ("tile_min_row", 16), ("tile_lg", 0)):
             ctx.set_option(k, v)
 
 
@@ -50,6 +50,9 @@ def _run(cases, rng, ctx):
         opts = {"kernel": int(rng.choice([0, 0, 1, 2, 5, 5])), "tile_gather": int(rng.integers(2)), "graph_launch": int(rng.integers(3)),
                 "xcd_remap": int(rng.integers(2)), "alternate_sweep": int(rng.integers(2)), "combine": int(rng.integers(3)),
                 "synthesis": int(rng.integers(2)), "max_batch": int(rng.choice([0, 0, 0, 8, 20])),
+                # narrow / odd panels: padded rows on the tile kernels (always / by size / never), the 2- / 4- / 8-lane builds
+                "tile_pad": int(rng.choice([0, 1, 2, 2])), "tile_min_row": int(rng.choice([16, 16, 32])),
+                "tile_lg": int(rng.choice([0, 0, 4, 8])),
                 # the host-array calls below: one-shot, or pipelined in column batches of any width / thread count
                 # (ragged and 1-column batches included: against the oracle, not bit for bit)
                 "host_pipeline": int(rng.choice([0, 1, 2, 2])), "host_batch": int(rng.choice([0, 1, 3, 4, 8, 16, 24])),

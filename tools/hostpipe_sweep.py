@@ -46,7 +46,10 @@ def main():
         ctx.set_option("host_threads", threads)
         y = timed("auto schedule, threads {}".format(threads or "auto"))
         rows[-1]["identical_to_one_shot"] = bool(np.array_equal(y, y0))
-    for batch, edge in ((16, 4), (16, 8), (16, 16), (24, 8), (32, 16)):
+    elt = np.dtype(dtype).itemsize
+    # (batch, first / last batch) in bytes per row
+    for bb, eb in ((32, 32), (64, 32), (64, 64), (96, 32), (96, 64), (128, 32), (128, 64), (128, 128), (192, 64), (256, 128)):
+        batch, edge = bb // elt, eb // elt
         ctx.set_option("host_batch", batch)
         ctx.set_option("host_edge", edge)
         ctx.set_option("host_threads", 16)

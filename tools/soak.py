@@ -15,9 +15,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import cheby_oracle as orc  # noqa: E402
 from pygsp_amd import engine, graphs  # noqa: E402
 
-FULL = dict(sizes=(40000, 200000, 700000), widths=(4, 8, 12, 16, 20, 32, 36, 64, 72, 96, 128, 160),
+FULL = dict(sizes=(40000, 200000, 700000), widths=(1, 2, 3, 4, 5, 6, 8, 12, 16, 20, 32, 36, 64, 72, 96, 128, 160),
             orders=(1, 2, 3, 5, 11, 30))
-SLICE = dict(sizes=(40000, 200000), widths=(8, 12, 16, 36, 64, 128), orders=(2, 5, 30))
+SLICE = dict(sizes=(40000, 200000), widths=(2, 5, 8, 16, 64, 128), orders=(2, 5, 30))  # (2- / 4- / 8- / 16-lane builds, a padded one)
 
 
 def soak_kernel(rounds=3, sizes=FULL["sizes"], widths=FULL["widths"], orders=FULL["orders"], log=print):
