@@ -255,12 +255,13 @@ struct PinMem {
 };
 
 struct HostPipe {
+  static constexpr int NIN = 3;  // input slots: batch b is packed and shipped while batches b-1 and b-2 compute
   hipStream_t stream_in = nullptr, stream_out = nullptr;
-  hipEvent_t h2d_ev[2] = {nullptr, nullptr};
-  hipEvent_t t_in[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // per slot: H2D start / stop
+  hipEvent_t h2d_ev[NIN] = {nullptr, nullptr, nullptr};
+  hipEvent_t t_in[NIN][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per slot: H2D start / stop
   hipEvent_t t_out[2] = {nullptr, nullptr};                          // D2H start / stop (the shipper waits for each)
-  PinMem pin_in[2], pin_out[2];
-  DevMem dx[2], dy[2];
+  PinMem pin_in[NIN], pin_out[2];
+  DevMem dx[NIN], dy[2];
   // timings of the last pipelined call (ms): wall, pack (busiest worker), H2D (sum of DMA times), kernels
   // (sum of device times), D2H, unpack (busiest worker), batches, batch width, host threads per direction
   double timing[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -292,10 +293,12 @@ struct HostPipe {
     }
     stream_in = stream_out = nullptr;
     for (auto& e : h2d_ev) e = nullptr;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NIN; ++i) {
       pin_in[i].release();
-      pin_out[i].release();
       dx[i].release();
+    }
+    for (int i = 0; i < 2; ++i) {
+      pin_out[i].release();
       dy[i].release();
     }
     ready = false;

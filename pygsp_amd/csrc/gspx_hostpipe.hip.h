@@ -13,7 +13,9 @@
 //   D2H(b-1)     one contiguous DMA of the compact result into pinned memory        (stream_out)
 //   unpack(b-2)  host threads scatter it into columns [c0, c0+w) of y
 //
-// Two buffers per stage (slot = b & 1).  All hand-offs are host-side (a mutex, a condition variable and four
+// Three buffers on the input side (slot = b % 3: packing and shipping batch b overlaps the kernels of batches b-2
+// AND b-1 - with two, pack + H2D of a batch, 5 ms for 16 fp64 columns, had to fit behind ONE batch's kernels, 3 ms,
+// and the kernels starved), two on the output side (slot = b & 1).  All hand-offs are host-side (a mutex, a condition variable and four
 // counters), plus ONE device-side dependency: the kernels of batch b wait for the H2D event of batch b on
 // their stream, so the compute thread never blocks on a copy.  The staging buffers are pinned once per
 // context and grow only.  Per column the arithmetic is the device path's own, so the result equals the
@@ -82,10 +84,11 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
     if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
   }
   const size_t in_cap = (size_t)in_planes * N * w * sizeof(T), out_cap = (size_t)out_planes * N * w * sizeof(T);
-  for (int s = 0; s < 2; ++s) {
+  constexpr int NIN = HostPipe::NIN;
+  for (int s = 0; s < NIN; ++s) {
     // (no staging memory - pinned or device - is not an error of the call: the caller falls back to the one-shot form)
-    if (hp.pin_in[s].ensure(in_cap) != GSPX_OK || hp.pin_out[s].ensure(out_cap) != GSPX_OK ||
-        hp.dx[s].ensure(in_cap) != GSPX_OK || hp.dy[s].ensure(out_cap) != GSPX_OK) {
+    if (hp.pin_in[s].ensure(in_cap) != GSPX_OK || hp.dx[s].ensure(in_cap) != GSPX_OK ||
+        (s < 2 && (hp.pin_out[s].ensure(out_cap) != GSPX_OK || hp.dy[s].ensure(out_cap) != GSPX_OK))) {
       (void)hipGetLastError();
       return GSPX_HOSTPIPE_UNAVAILABLE;
     }
@@ -124,8 +127,8 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
   auto pack_worker = [&](int p) {
     const int64_t r0 = N * p / P, r1 = N * (p + 1) / P;
     for (int b = 0; b < nb; ++b) {
-      const int s = b & 1;
-      if (!wait_for([&] { return computed >= b - 1; })) return;  // slot s: batch b-2 consumed
+      const int s = b % NIN;
+      if (!wait_for([&] { return computed >= b - (NIN - 1); })) return;  // slot s: batch b - NIN consumed
       const auto t0 = std::chrono::steady_clock::now();
       const int64_t wl = width_of(b);
       for (int pl = 0; pl < in_planes; ++pl)
@@ -140,7 +143,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
       }
       if (last) {  // the panel is complete: one contiguous DMA
         if (hipfail(hipSetDevice(ctx->device), "hipSetDevice")) return;
-        if (b >= 2) {  // the slot's previous DMA (batch b-2) is complete: its kernels have run
+        if (b >= NIN) {  // the slot's previous DMA (batch b - NIN) is complete: its kernels have run
           float t = 0;
           if (hipEventElapsedTime(&t, hp.t_in[s][0], hp.t_in[s][1]) == hipSuccess) h2d_ms += t;
         }
@@ -216,10 +219,10 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
   // this thread: the kernels, batch by batch
   double k_ms = 0, tm[5] = {0, 0, 0, 0, 0};
   for (int b = 0; b < nb; ++b) {
-    const int s = b & 1;
+    const int s = b % NIN, so = b & 1;
     if (!wait_for([&] { return issued >= b + 1 && shipped >= b - 1; })) break;
     if (hipfail(hipStreamWaitEvent(ctx->stream, hp.h2d_ev[s], 0), "hipStreamWaitEvent")) break;
-    const int rc = filter_dev_t<T>(g, lmax, Nf, M, coeffs, width_of(b), (const T*)hp.dx[s].p, (T*)hp.dy[s].p, mode);
+    const int rc = filter_dev_t<T>(g, lmax, Nf, M, coeffs, width_of(b), (const T*)hp.dx[s].p, (T*)hp.dy[so].p, mode);
     if (rc != GSPX_OK) {
       fail(rc);
       break;
@@ -239,9 +242,9 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
     g_err = err_msg;
     return err;
   }
-  for (int b = std::max(0, nb - 2); b < nb; ++b) {  // the DMAs whose slot was not reused
+  for (int b = std::max(0, nb - NIN); b < nb; ++b) {  // the DMAs whose slot was not reused
     float t = 0;
-    if (hipEventElapsedTime(&t, hp.t_in[b & 1][0], hp.t_in[b & 1][1]) == hipSuccess) h2d_ms += t;
+    if (hipEventElapsedTime(&t, hp.t_in[b % NIN][0], hp.t_in[b % NIN][1]) == hipSuccess) h2d_ms += t;
   }
   (void)hipGetLastError();
   for (int i = 0; i < 5; ++i) ctx->timing[i] = tm[i];
