@@ -84,6 +84,9 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "tile_nt"       k_step_tile non-temporal accesses, bit 0 matrix entries, bit 1 accumulator, bit 2
  *                   T_{k-2} rows, bit 3 T_k stores; -1 (default): 5 for panels of 192 MiB and more
  *   "tile_workgroups" / "pair_workgroups"   persistent workgroups of k_step_tile / k_newton_pair (0: 2 per CU)
+ *   "tile_pad"      1 (default) panels whose rows are not made of 16-byte pieces take k_step_tile with padded
+ *                   rows (rows under 16 bytes only on graphs beyond the L2s); 2 always; 0 never.  "tile_min_row"
+ *                   (16) narrowest rows in bytes k_step_tile takes; "tile_lg" 4 / 8: no build narrower than that
  *   "vec", "rows_per_wave", "narrow_g_log2", "waves_per_block"   launch shapes of the plain gather
  *                   kernels (0 / -1 = auto)
  *   "newton_pair"   1 (default) Newton-form filtering runs two orders per launch when the graph carries
@@ -182,8 +185,8 @@ int gspx_cheby_filter_dev(gspx_graph* g, double lmax, int Nf, int M, const doubl
  * over.  Large calls are cut into signal-column batches and pipelined over pinned staging buffers - host
  * threads pack batch b+2, DMA of b+1, kernels of b, DMA of b-1 and unpacking of b-2 overlap - so the call
  * costs about max(PCIe, kernels) instead of their sum; small calls are one copy in, the kernels, one copy
- * out (option "host_pipeline").  The automatic schedule returns the bytes of the one-shot call (every batch
- * runs the same kernel family; an explicit "host_batch" below 32-byte rows is equal to rounding only).
+ * out (option "host_pipeline").  On a graph with gather tiles every batch runs the kernel family of the one-shot
+ * call: identical bytes (without tiles, batches under 32-byte rows are equal to rounding only).
  * kernel_ms: device time of the kernels alone. */
 int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, const double* coeffs,
                       int64_t Nsig, const void* x_host, void* y_host, int mode,
