@@ -2136,7 +2136,16 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const int K = M - 1;
-  const size_t U = (size_t)N * ld;
+  // (rows that are not made of 16-byte pieces: padded work panels on the tile kernels, as in run_batch)
+  constexpr unsigned TVEC = 16 / (unsigned)sizeof(T);
+  const unsigned ldp = (ld + TVEC - 1) / TVEC * TVEC;
+  const bool tile_direct = tile_usable<T>(g, opt, ld, y, ldy) && (size_t)nf * N * ld * sizeof(T) < ((size_t)1 << 31);
+  const bool pad_pays = opt.tile_pad == 2 || (size_t)ld * sizeof(T) >= 16 ||
+                        (size_t)g->nnz_int * (sizeof(T) + 4) >= ((size_t)20 << 20);
+  const bool padded = !tile_direct && opt.tile_pad && pad_pays && tile_geometry<T>(g, opt, ldp) &&
+                      (size_t)nf * N * ldp * sizeof(T) < ((size_t)1 << 31);
+  const unsigned ldw = padded ? ldp : ld;
+  const size_t U = (size_t)N * ldw;
   int veccap = 4;
   while (veccap > 1 && ((ldy % veccap) != 0 || (((uintptr_t)y / sizeof(T)) % veccap) != 0))
     veccap /= 2;
@@ -2161,6 +2170,11 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
   HIPCHK(hipEventRecord(e0, st));
   for (int f = 0; f < nf; ++f) {
     const T* xf = x + (size_t)f * plane_x;
+    if (padded) {
+      const unsigned nbp = (unsigned)std::min<size_t>((U + 255) / 256, 65536);
+      hipLaunchKernelGGL((k_permute_in_pad<T>), dim3(nbp), dim3(256), 0, st, xf, ldx, S + (size_t)f * U, ldw, ld, N, perm);
+      continue;
+    }
     int pvec = shape.vec;
     while (pvec > 1 && ((ldx % pvec) != 0 || (((uintptr_t)xf / sizeof(T)) % pvec) != 0)) pvec /= 2;
     launch_permute_in<T>(xf, ldx, S + (size_t)f * U, ld, N, perm, pvec, st);
@@ -2183,7 +2197,7 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
   a.perm = perm;
   a.beta = T(0);
   // (nf input panels: the buffer window of the tile kernel spans all of them)
-  const bool tile_ok = tile_usable<T>(g, opt, ld, y, ldy) && (size_t)nf * U * sizeof(T) < ((size_t)1 << 31);
+  const bool tile_ok = tile_direct || padded;
   for (int k = K; k >= 0; --k) {
     if (tile_ok) {
       TileArgs<T> t{};
@@ -2202,9 +2216,9 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
       t.wts = ctx->ws_w.as<T>() + (size_t)k * nf;
       t.nin = nf;
       t.flush = 0;
-      t.final = (k == 0) ? 1 : 0;
+      t.final = (k == 0 && !padded) ? 1 : 0;  // padded rows: b_0 stays in B[0] and is copied out below
       t.reverse = (opt.alternate_sweep && (k & 1)) ? 1 : 0;
-      CHK(launch_step_tile<T>(g, opt, t, ld, st));
+      CHK(launch_step_tile<T>(g, opt, t, ldw, st));
       continue;
     }
     a.wts = ctx->ws_w.as<T>() + (size_t)k * nf;
@@ -2228,6 +2242,10 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
     launch_step<T>(a, shape, opt, st, g->coff.as<unsigned>());
   }
   HIPCHK(hipEventRecord(e2, st));
+  if (padded) {
+    const unsigned nbp = (unsigned)std::min<size_t>(((size_t)N * ld + 255) / 256, 65536);
+    hipLaunchKernelGGL((k_permute_out_pad<T>), dim3(nbp), dim3(256), 0, st, B[0], ldw, y, ldy, ld, N, perm);
+  }
   HIPCHK(hipEventRecord(e3, st));
   HIPCHK(hipGetLastError());
   return GSPX_OK;

@@ -303,6 +303,11 @@ def test_tile_gather_kernel(ctx, dtype):
         refs = sum(orc.cheby_op(L, lmax, cb[f], s3[f].astype(dtype).astype(np.float64)) for f in range(3))
         ys, _ = dev.cheby_filter(cb, s3, lmax, mode=_capi.SYNTHESIS)
         assert rel_err(ys, refs) < tol
+        for w in (1, 3, 5):  # ... with padded rows
+            ctx.set_option("tile_pad", 2)
+            yw, _ = dev.cheby_filter(cb, np.ascontiguousarray(s3[:, :, :w]), lmax, mode=_capi.SYNTHESIS)
+            ctx.set_option("tile_pad", 1)
+            assert rel_err(yw, refs[:, :w]) < tol, w
         dev.disable_gather_tiles()
         dev.destroy()
     # a graph with isolated vertices, a hub and ragged rows; normalized Laplacian
