@@ -322,7 +322,7 @@ struct Options {
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
                                 // (rows under 16 bytes only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
-  int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (2 / 4 / 8), 4 or 8: at least that
+  int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
   int64_t tile_nt = -1;         // k_step_tile non-temporal accesses: bit 0 matrix entries, bit 2 T_{k-2} loads (each
@@ -1692,11 +1692,11 @@ static bool tile_usable(const gspx_graph* g, const Options& opt, unsigned ld, co
 template <typename T>
 static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, unsigned ld, hipStream_t st,
                             const T* vals = nullptr) {
-  // narrow panels (rows of at most 128 bytes): 8- / 4- / 2-lane row groups in workgroups of 512 / 256 / 128
+  // narrow panels (rows of at most 128 bytes): 8- / 4- / 2- / 1-lane row groups in workgroups of 512 / 256 / 128 / 64
   // threads - every lane holds a piece of a row, and the smaller workgroups keep more blocks in flight per CU
   const size_t rowb = (size_t)ld * sizeof(T);
-  int lg = rowb <= 32 ? 2 : rowb <= 64 ? 4 : rowb <= 128 ? 8 : 16;
-  if (opt.tile_lg == 8 || opt.tile_lg == 4) lg = rowb <= 128 ? std::max(lg, (int)opt.tile_lg) : 16;  // (tuning)
+  int lg = rowb <= 16 ? 1 : rowb <= 32 ? 2 : rowb <= 64 ? 4 : rowb <= 128 ? 8 : 16;
+  if (opt.tile_lg == 8 || opt.tile_lg == 4 || opt.tile_lg == 2) lg = rowb <= 128 ? std::max(lg, (int)opt.tile_lg) : 16;  // (tuning)
   // (the 8-lane build in 256-thread workgroups with two rows per group - four resident workgroups instead of two -
   // measured within 3 % of the 512-thread build on 80- to 128-byte rows: those passes are not latency bound.)
   // (several column chunks per block with the small builds lose to the 16-lane build: 96- / 192-byte rows 4.1 / 6.7 ms
@@ -1711,11 +1711,14 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
       {k_step_tile<T, 0>, k_step_tile<T, 1>, k_step_tile<T, 2>},
       {k_step_tile<T, 0, 16, true>, k_step_tile<T, 1, 16, true>, k_step_tile<T, 2, 16, true>},
       {k_step_tile<T, 0, 16, false, true>, k_step_tile<T, 1, 16, false, true>, k_step_tile<T, 2, 16, false, true>}};
-  static const kern_t slim[3][3] = {
-      {k_step_tile<T, 1, 2, false, false, 128>, k_step_tile<T, 1, 4, false, false, 256>, k_step_tile<T, 1, 8>},
-      {k_step_tile<T, 1, 2, true, false, 128>, k_step_tile<T, 1, 4, true, false, 256>, k_step_tile<T, 1, 8, true>},
-      {k_step_tile<T, 1, 2, false, true, 128>, k_step_tile<T, 1, 4, false, true, 256>, k_step_tile<T, 1, 8, false, true>}};
-  const kern_t kern = narrow ? slim[flavour][lg == 2 ? 0 : lg == 4 ? 1 : 2] : wide[flavour][ncol <= 2 ? ncol : 0];
+  static const kern_t slim[3][4] = {
+      {k_step_tile<T, 1, 1, false, false, 64>, k_step_tile<T, 1, 2, false, false, 128>,
+       k_step_tile<T, 1, 4, false, false, 256>, k_step_tile<T, 1, 8>},
+      {k_step_tile<T, 1, 1, true, false, 64>, k_step_tile<T, 1, 2, true, false, 128>,
+       k_step_tile<T, 1, 4, true, false, 256>, k_step_tile<T, 1, 8, true>},
+      {k_step_tile<T, 1, 1, false, true, 64>, k_step_tile<T, 1, 2, false, true, 128>,
+       k_step_tile<T, 1, 4, false, true, 256>, k_step_tile<T, 1, 8, false, true>}};
+  const kern_t kern = narrow ? slim[flavour][lg == 1 ? 0 : lg == 2 ? 1 : lg == 4 ? 2 : 3] : wide[flavour][ncol <= 2 ? ncol : 0];
   const unsigned threads = narrow ? 64u * (unsigned)lg : 512u;
   // dynamic LDS: the wide builds take the tile budget the blocks were classified with; a narrow build's tile
   // rows are 16 lg bytes, so the largest staged block needs far less - and more workgroups fit a CU

@@ -62,8 +62,8 @@ template <typename T> struct TileArgs {
 constexpr int GSPX_TILE_BR = 64;      // rows per block
 constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group)
 
-// LG = lanes per row group: 16 (256-byte column chunks; 32 groups x 2 rows) or, for narrow panels, 8 / 4 / 2
-// (128- / 64- / 32-byte rows; 64 groups x 1 row, NT = 64 LG threads per workgroup: every lane has a piece of a
+// LG = lanes per row group: 16 (256-byte column chunks; 32 groups x 2 rows) or, for narrow panels, 8 / 4 / 2 / 1
+// (128- / 64- / 32- / 16-byte rows; 64 groups x 1 row, NT = 64 LG threads per workgroup: every lane has a piece of a
 // row, and the smaller workgroups keep more blocks in flight per CU - a narrow pass moves little data per
 // memory round trip).  NCOL = 1, 2: that many column chunks per row; 0: a.ncol chunks
 // OLDNAT: T_{k-2} rows are read through a.old_rows (step 2 of a filter whose input panel was not

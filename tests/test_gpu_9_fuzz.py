@@ -52,7 +52,7 @@ def _run(cases, rng, ctx):
                 "synthesis": int(rng.integers(2)), "max_batch": int(rng.choice([0, 0, 0, 8, 20])),
                 # narrow / odd panels: padded rows on the tile kernels (always / by size / never), the 2- / 4- / 8-lane builds
                 "tile_pad": int(rng.choice([0, 1, 2, 2])), "tile_min_row": int(rng.choice([16, 16, 32])),
-                "tile_lg": int(rng.choice([0, 0, 4, 8])),
+                "tile_lg": int(rng.choice([0, 0, 0, 2, 4, 8])),
                 # the host-array calls below: one-shot, or pipelined in column batches of any width / thread count
                 # (ragged and 1-column batches included: against the oracle, not bit for bit)
                 "host_pipeline": int(rng.choice([0, 1, 2, 2])), "host_batch": int(rng.choice([0, 1, 3, 4, 8, 16, 24])),
