@@ -8,7 +8,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "sm
 timeout 1700 python -m pytest tests -m gpu -q --durations=6 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -12 $O/pytest_gpu.log
 SECONDS=0
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$? wall=${SECONDS}s"
-bash tools/gpu_prof.sh f64 --dtype f64 > $O/prof_f64.log 2>&1; grep -E "step-kernel launches|k_step_tile<double, 2, 16, false, false>.*calls" $O/prof_f64.log | head -3
+bash tools/gpu_prof.sh f64 --dtype f64 > $O/prof_f64.log 2>&1; grep -E "step-kernel launches|k_step_tile<double, 2, 16, false, false.*calls" $O/prof_f64.log | head -3
 timeout 600 python bench.py --gpus 2 --devices 0,0 --steps 5 --warmup 2 > $O/bench_threads2.json 2> $O/bench_threads2.err; echo "bench threads rc=$?"
 python - <<'PY'
 import json
