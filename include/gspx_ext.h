@@ -158,6 +158,13 @@ int gspx_curve_order(gspx_ctx* ctx, int64_t N, int d, const double* coords, int 
 int gspx_graph_setup(gspx_ctx* ctx, int64_t N, int64_t nnz, const int32_t* indptr, const int32_t* indices,
                      const void* data, int data_dtype, int lap_type, int compute_dtype, const double* coords,
                      int d, int order_mode, const int32_t* perm_in, int64_t report[12], gspx_graph** out);
+/* The same set-up for the W a device builder left on the device (gspx_knn_build / gspx_radius_build /
+ * gspx_sbm_build; the handle stays valid and still serves gspx_knn_download_w): the generator classes NNGraph /
+ * Sensor / StochasticBlockModel / ErdosRenyi (nngraph.py:289-313, stochasticblockmodel.py:144-181 end in
+ * Graph.__init__(W)) hand the builder's handle over - no download and re-upload of W; its host copy is made
+ * when somebody reads G.W.  coords may be NULL (order_mode 0 or 4).  report / *out as gspx_graph_setup. */
+int gspx_graph_setup_from_knn(gspx_knn* h, int lap_type, int compute_dtype, const double* coords, int d,
+                              int order_mode, const int32_t* perm_in, int64_t report[12], gspx_graph** out);
 /* The ingredients of Graph._get_upper_bound (graph.py:933-960: the smallest of four classical upper bounds of
  * lambda_max of the combinatorial Laplacian), taken in one pass while W was on the device - float64 graphs built
  * from W: out[0] max W_ij, out[1] max dw, out[2] max (dw_i + dw_j) over the stored entries, out[3] max (dw_i +

@@ -98,6 +98,7 @@ SIGNATURES = {
     "gspx_curve_order": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_int, _P]),
     "gspx_graph_setup": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
                                     _c.c_int, _P, _P, _c.POINTER(_P)]),
+    "gspx_graph_setup_from_knn": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P, _c.POINTER(_P)]),
     "gspx_graph_download_perm": (_c.c_int, [_P, _P]),
     "gspx_graph_lmax_bounds": (_c.c_int, [_P, _P]),
     "gspx_sbm_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_uint64, _P]),

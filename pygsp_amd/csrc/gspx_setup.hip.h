@@ -225,6 +225,12 @@ extern "C" int gspx_curve_order(gspx_ctx* ctx, int64_t N, int d, const double* c
 
 #define GSPX_I64 2 /* data_dtype of gspx_graph_setup only: int64 adjacency (ER / SBM graphs of the reference) */
 
+// W already on the device (uploaded by graph_setup_t below, or left there by the neighbour / block-model builders)
+template <typename TIn, typename T>
+static int graph_setup_core(gspx_graph* g, int64_t nnz, const int* wptr_d, const int* wcol_d, const TIn* wraw_d,
+                            const double* coords, int d, int order_mode, const int32_t* perm_in, int64_t* report,
+                            std::chrono::steady_clock::time_point t0);
+
 template <typename TIn, typename T>
 static int graph_setup_t(gspx_graph* g, int64_t nnz, const int32_t* indptr, const int32_t* indices, const void* data,
                          const double* coords, int d, int order_mode, const int32_t* perm_in, int64_t* report) {
@@ -232,21 +238,33 @@ static int graph_setup_t(gspx_graph* g, int64_t nnz, const int32_t* indptr, cons
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const auto t0 = std::chrono::steady_clock::now();
-  DevMem wptr, wcol, wraw, wval, rep;
+  DevMem wptr, wcol, wraw;
   CHK(wptr.alloc((size_t)(N + 1) * sizeof(int)));
   CHK(wcol.alloc((size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
   CHK(wraw.alloc((size_t)std::max<int64_t>(nnz, 1) * sizeof(TIn)));
-  CHK(rep.alloc(sizeof(gspx::WReport) + 16));
-  HIPCHK(hipMemsetAsync(rep.p, 0, sizeof(gspx::WReport) + 16, st));
   HIPCHK(hipMemcpyAsync(wptr.p, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, st));
   if (nnz > 0) {
     HIPCHK(hipMemcpyAsync(wcol.p, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(wraw.p, data, (size_t)nnz * sizeof(TIn), hipMemcpyHostToDevice, st));
   }
+  return graph_setup_core<TIn, T>(g, nnz, wptr.as<int>(), wcol.as<int>(), (const TIn*)wraw.p, coords, d, order_mode,
+                                  perm_in, report, t0);
+}
+
+template <typename TIn, typename T>
+static int graph_setup_core(gspx_graph* g, int64_t nnz, const int* wptr_d, const int* wcol_d, const TIn* wraw_d,
+                            const double* coords, int d, int order_mode, const int32_t* perm_in, int64_t* report,
+                            std::chrono::steady_clock::time_point t0) {
+  gspx_ctx* ctx = g->ctx;
+  hipStream_t st = ctx->stream;
+  const int N = (int)g->N;
+  DevMem wval, rep;
+  CHK(rep.alloc(sizeof(gspx::WReport) + 16));
+  HIPCHK(hipMemsetAsync(rep.p, 0, sizeof(gspx::WReport) + 16, st));
   const int nb = std::max(1, (N + 255) / 256);
   if (N > 0)
-    hipLaunchKernelGGL((gspx::k_w_inspect<TIn>), dim3(nb), dim3(256), 0, st, wptr.as<int>(), wcol.as<int>(),
-                       (const TIn*)wraw.p, N, (long long)nnz, (gspx::WReport*)rep.p);
+    hipLaunchKernelGGL((gspx::k_w_inspect<TIn>), dim3(nb), dim3(256), 0, st, wptr_d, wcol_d, wraw_d, N, (long long)nnz,
+                       (gspx::WReport*)rep.p);
   gspx::WReport r;
   HIPCHK(hipMemcpyAsync(&r, rep.p, sizeof(r), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -282,8 +300,7 @@ static int graph_setup_t(gspx_graph* g, int64_t nnz, const int32_t* indptr, cons
     if (order_mode == 1) {  // "auto": kept only if it beats the graph's own order (engine.auto_order)
       const int reach = (int)std::min<int64_t>(8192, std::max<int64_t>(64, N / 64));
       unsigned long long* sc = (unsigned long long*)((char*)rep.p + sizeof(gspx::WReport));
-      hipLaunchKernelGGL(gspx::k_locality, dim3(nb), dim3(256), 0, st, wptr.as<int>(), wcol.as<int>(), N,
-                         g->iperm.as<int>(), reach, sc);
+      hipLaunchKernelGGL(gspx::k_locality, dim3(nb), dim3(256), 0, st, wptr_d, wcol_d, N, g->iperm.as<int>(), reach, sc);
       unsigned long long h[2] = {0, 0};
       HIPCHK(hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -303,15 +320,14 @@ static int graph_setup_t(gspx_graph* g, int64_t nnz, const int32_t* indptr, cons
   // ---- values in the compute dtype, then the ordinary device build ----------------------------------------
   const T* vals = nullptr;
   if (std::is_same<TIn, T>::value) {
-    vals = (const T*)wraw.p;
+    vals = (const T*)wraw_d;
   } else {
     CHK(wval.alloc((size_t)std::max<int64_t>(nnz, 1) * sizeof(T)));
     if (nnz > 0)
-      hipLaunchKernelGGL((gspx::k_setup_convert<TIn, T>), dim3(2048), dim3(256), 0, st, (const TIn*)wraw.p, (size_t)nnz,
-                         wval.as<T>());
+      hipLaunchKernelGGL((gspx::k_setup_convert<TIn, T>), dim3(2048), dim3(256), 0, st, wraw_d, (size_t)nnz, wval.as<T>());
     vals = wval.as<T>();
   }
-  CHK(create_from_w_dev<T>(g, nnz, wptr.as<int>(), wcol.as<int>(), vals));
+  CHK(create_from_w_dev<T>(g, nnz, wptr_d, wcol_d, vals));
   report[10] = 0;
   report[11] = (int64_t)(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
   g->build_ms = (double)report[11] / 1e3;
@@ -353,6 +369,48 @@ extern "C" int gspx_graph_setup(gspx_ctx* ctx, int64_t N, int64_t nnz, const int
   else if (data_dtype == GSPX_F64) rc = GSPX_SETUP(double);
   else rc = GSPX_SETUP(long long);
 #undef GSPX_SETUP
+  if (rc != GSPX_OK || report[10] != 0) {
+    delete g;
+    return rc;
+  }
+  *out = g;
+  return GSPX_OK;
+}
+
+// The same set-up for a W that a device builder left on the device (gspx_knn_build / gspx_radius_build /
+// gspx_sbm_build): no download, no upload - the generator classes hand the builder's handle over and the host copy of
+// W is made only when somebody reads G.W.
+extern "C" int gspx_graph_setup_from_knn(gspx_knn* h, int lap_type, int compute_dtype, const double* coords, int d,
+                                         int order_mode, const int32_t* perm_in, int64_t report[12], gspx_graph** out) {
+  if (!h || !out || !report) return set_err(GSPX_ERR_INVALID, "null handle, report or output");
+  *out = nullptr;
+  for (int i = 0; i < 12; ++i) report[i] = 0;
+  if (compute_dtype != GSPX_F32 && compute_dtype != GSPX_F64)
+    return set_err(GSPX_ERR_INVALID, "compute_dtype must be GSPX_F32 or GSPX_F64");
+  if (lap_type != GSPX_LAP_COMBINATORIAL && lap_type != GSPX_LAP_NORMALIZED)
+    return set_err(GSPX_ERR_INVALID, "Unknown Laplacian type %d", lap_type);
+  if (order_mode < 0 || order_mode > 4 || (order_mode == 4 && !perm_in))
+    return set_err(GSPX_ERR_INVALID, "order_mode: 0 none, 1 auto, 2 morton, 3 hilbert, 4 given permutation");
+  if (coords && d != 0 && (d < 1 || d > 64)) return set_err(GSPX_ERR_INVALID, "coords: 1 to 64 dimensions");
+  const int64_t N = h->N, nnz = h->nnz;
+  if (N >= ((int64_t)1 << 30) || nnz >= ((int64_t)1 << 31) - 8 * N - 64)
+    return set_err(GSPX_ERR_INVALID, "graph too large for int32 indexing");
+  if (!h->rowptr.p || (nnz > 0 && (!h->col.p || !h->val.p))) return set_err(GSPX_ERR_INVALID, "the handle holds no W");
+  gspx_ctx* ctx = h->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  replay_reset(ctx);
+  gspx_graph* g = new gspx_graph();
+  g->ctx = ctx;
+  g->N = N;
+  g->dtype = compute_dtype;
+  g->from_w = true;
+  g->lap_type = lap_type;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = compute_dtype == GSPX_F32
+                     ? graph_setup_core<double, float>(g, nnz, h->rowptr.as<int>(), h->col.as<int>(), h->val.as<double>(),
+                                                       coords, d, order_mode, perm_in, report, t0)
+                     : graph_setup_core<double, double>(g, nnz, h->rowptr.as<int>(), h->col.as<int>(), h->val.as<double>(),
+                                                        coords, d, order_mode, perm_in, report, t0);
   if (rc != GSPX_OK || report[10] != 0) {
     delete g;
     return rc;

@@ -489,29 +489,53 @@ class DeviceGraph:
         else:
             data, code = data.astype(np.float64), _capi.F64
         c = np.ascontiguousarray
-        perm_in, xy, d = None, None, 0
-        if isinstance(order, np.ndarray) or isinstance(order, (list, tuple)):
-            perm_in, mode = c(order, dtype=np.int32), 4
-        else:
-            mode = cls.ORDER_MODES[order]
-        if mode in (1, 2, 3):
-            ok = coords is not None and np.ndim(coords) == 2 and np.shape(coords)[0] == N and np.shape(coords)[1] >= 2
-            if ok and N >= 4096:
-                xy = c(coords, dtype=np.float64)
-                d = xy.shape[1]
-            else:
-                mode = 0
+        mode, xy, d, perm_in = cls._order_args(N, coords, order)
         report = np.zeros(12, dtype=np.int64)
         h = ctypes.c_void_p()
         _capi.check(_capi.load().gspx_graph_setup(
             ctx._h, N, W.nnz, _capi.ptr(c(indptr)), _capi.ptr(c(indices)), _capi.ptr(c(data)), code,
             _capi.LAP_COMBINATORIAL if lap_type == "combinatorial" else _capi.LAP_NORMALIZED, _capi.dtype_code(dtype),
             _capi.ptr(xy), d, mode, _capi.ptr(perm_in), _capi.ptr(report), ctypes.byref(h)))
-        rep = {"nan": int(report[0]), "inf": int(report[1]), "negative": int(report[2]), "zeros": int(report[3]),
-               "self_loops": int(report[4]), "asymmetric": int(report[5]), "reordered": bool(report[7]),
-               "locality_own": report[8] / 1e9, "locality_curve": report[9] / 1e9, "built": report[10] == 0,
-               "setup_ms": report[11] / 1e3}
-        return (cls(h, ctx, N, dtype) if h.value else None), rep
+        return (cls(h, ctx, N, dtype) if h.value else None), cls._setup_report(report)
+
+    @classmethod
+    def _order_args(cls, N, coords, order):
+        """(order_mode, coordinates or None, their dimension, permutation or None) of the set-up calls."""
+        perm_in, xy, d = None, None, 0
+        if isinstance(order, np.ndarray) or isinstance(order, (list, tuple)):
+            perm_in, mode = np.ascontiguousarray(order, dtype=np.int32), 4
+        else:
+            mode = cls.ORDER_MODES[order]
+        if mode in (1, 2, 3):
+            ok = coords is not None and np.ndim(coords) == 2 and np.shape(coords)[0] == N and np.shape(coords)[1] >= 2
+            if ok and N >= 4096:
+                xy = np.ascontiguousarray(coords, dtype=np.float64)
+                d = xy.shape[1]
+            else:
+                mode = 0
+        return mode, xy, d, perm_in
+
+    @staticmethod
+    def _setup_report(report):
+        return {"nan": int(report[0]), "inf": int(report[1]), "negative": int(report[2]), "zeros": int(report[3]),
+                "self_loops": int(report[4]), "asymmetric": int(report[5]), "reordered": bool(report[7]),
+                "locality_own": report[8] / 1e9, "locality_curve": report[9] / 1e9, "built": report[10] == 0,
+                "setup_ms": report[11] / 1e3}
+
+    @classmethod
+    def setup_from(cls, adjacency, lap_type="combinatorial", dtype=np.float64, coords=None, order="auto"):
+        """The same set-up for a DeviceAdjacency - the W a device builder (knn_graph / radius_graph / sbm_graph with
+        keep_on_device=True) left on the device: nothing is downloaded or uploaded (gspx_graph_setup_from_knn)."""
+        if lap_type not in ("combinatorial", "normalized"):
+            raise ValueError("Unknown Laplacian type {}".format(lap_type))
+        N = adjacency.shape[0]
+        mode, xy, d, perm_in = cls._order_args(N, coords, order)
+        report = np.zeros(12, dtype=np.int64)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.load().gspx_graph_setup_from_knn(
+            adjacency._h, _capi.LAP_COMBINATORIAL if lap_type == "combinatorial" else _capi.LAP_NORMALIZED,
+            _capi.dtype_code(dtype), _capi.ptr(xy), d, mode, _capi.ptr(perm_in), _capi.ptr(report), ctypes.byref(h)))
+        return (cls(h, adjacency.ctx, N, dtype) if h.value else None), cls._setup_report(report)
 
     def lmax_bounds(self):
         """(max W, max dw, max (dw_i + dw_j) over entries, max (dw_i + (W dw)_i / dw_i)) taken on the device while W
@@ -898,11 +922,50 @@ METRICS = {"euclidean": 0, "manhattan": 1, "max_dist": 2}
 SYMMETRIZE = {"average": 0, "maximum": 1, "fill": 1, "tril": 2, "triu": 3}
 
 
-def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False, metric="euclidean", symmetrize="average"):
+class DeviceAdjacency:
+    """The weight matrix a device builder produced, still on the device (a gspx_knn handle).  Graph() takes it in
+    place of a scipy matrix (DeviceGraph.setup_from): the host copy is made by download(), once, when somebody
+    reads G.W.  `weights`: dtype of the host copy (the block-model samplers hand out int64 ones like the
+    reference)."""
+
+    def __init__(self, handle, ctx, N, nnz, weights=np.float64):
+        self._h, self.ctx, self.shape, self.nnz, self.weights = handle, ctx, (int(N), int(N)), int(nnz), np.dtype(weights)
+        self._host = None
+
+    def download(self):
+        if self._host is None:
+            if not self._h:
+                raise RuntimeError("the device adjacency has been released")
+            N = self.shape[0]
+            indptr = np.empty(N + 1, dtype=np.int32)
+            indices = np.empty(self.nnz, dtype=np.int32)
+            data = np.empty(self.nnz, dtype=np.float64)
+            _capi.check(_capi.load().gspx_knn_download_w(self._h, _capi.ptr(indptr), _capi.ptr(indices), _capi.ptr(data)))
+            if self.weights != np.float64:
+                data = np.ones(self.nnz, dtype=self.weights) if self.weights.kind in "iu" else data.astype(self.weights)
+            self._host = sparse.csr_matrix((data, indices, indptr), shape=self.shape)
+            self.close()
+        return self._host
+
+    def close(self):
+        h, self._h = self._h, None
+        if h and _capi is not None:
+            _capi.load().gspx_knn_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False, metric="euclidean", symmetrize="average",
+              keep_on_device=False):
     """k-nearest-neighbour weights on the device (gspx_knn_build): the KD-tree query, Gaussian weights
     and symmetrisation of NNGraph (nngraph.py:213-226, 289-297) in 1 to 64 dimensions (a uniform grid in 1-3-D;
     beyond that a tiled brute force whose pair distances run on the matrix cores).  coords: (N, d), already centred / rescaled.  Returns (W csr float64, sigma, info)
-    where info = {"build_ms": ...} plus "NN", "D" (N x k, nearest first) when neighbors=True."""
+    where info = {"build_ms": ...} plus "NN", "D" (N x k, nearest first) when neighbors=True.  keep_on_device: W is
+    returned as a DeviceAdjacency (not downloaded)."""
     ctx = ctx or default_context()
     X = np.ascontiguousarray(coords, dtype=np.float64)
     if X.ndim != 2:
@@ -915,23 +978,21 @@ def knn_graph(coords, k, sigma=None, ctx=None, neighbors=False, metric="euclidea
     try:
         nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))
-        indptr = np.empty(N + 1, dtype=np.int32)
-        indices = np.empty(nnz.value, dtype=np.int32)
-        data = np.empty(nnz.value, dtype=np.float64)
-        _capi.check(lib.gspx_knn_download_w(h, _capi.ptr(indptr), _capi.ptr(indices), _capi.ptr(data)))
         info = {"build_ms": ms.value}
         if neighbors:
             NN = np.empty((N, int(k)), dtype=np.int32)
             D = np.empty((N, int(k)), dtype=np.float64)
             _capi.check(lib.gspx_knn_download_neighbors(h, _capi.ptr(NN), _capi.ptr(D)))
             info["NN"], info["D"] = NN, D
+        W = DeviceAdjacency(h, ctx, N, nnz.value)
+        h = None
     finally:
-        lib.gspx_knn_destroy(h)
-    W = sparse.csr_matrix((data, indices, indptr), shape=(N, N))
-    return W, sg.value, info
+        if h:
+            lib.gspx_knn_destroy(h)
+    return (W if keep_on_device else W.download()), sg.value, info
 
 
-def radius_graph(coords, epsilon, sigma=None, ctx=None, metric="euclidean"):
+def radius_graph(coords, epsilon, sigma=None, ctx=None, metric="euclidean", keep_on_device=False):
     """Radius-graph weights on the device (gspx_radius_build): NNtype='radius' of NNGraph
     (nngraph.py:228-287) in 1 to 64 dimensions (a grid of epsilon-sized cells up to 3-D; beyond that the candidates of
     an MFMA distance sweep, tested in the KD-tree's arithmetic).  Returns (W csr float64, sigma, info)."""
@@ -947,16 +1008,15 @@ def radius_graph(coords, epsilon, sigma=None, ctx=None, metric="euclidean"):
     try:
         nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))
-        indptr = np.empty(N + 1, dtype=np.int32)
-        indices = np.empty(nnz.value, dtype=np.int32)
-        data = np.empty(nnz.value, dtype=np.float64)
-        _capi.check(lib.gspx_knn_download_w(h, _capi.ptr(indptr), _capi.ptr(indices), _capi.ptr(data)))
+        W = DeviceAdjacency(h, ctx, N, nnz.value)
+        h = None
     finally:
-        lib.gspx_knn_destroy(h)
-    return sparse.csr_matrix((data, indices, indptr), shape=(N, N)), sg.value, {"build_ms": ms.value}
+        if h:
+            lib.gspx_knn_destroy(h)
+    return (W if keep_on_device else W.download()), sg.value, {"build_ms": ms.value}
 
 
-def sbm_graph(z, M, seed=None, ctx=None):
+def sbm_graph(z, M, seed=None, ctx=None, keep_on_device=False):
     """Stochastic-block-model adjacency sampled on the device (gspx_sbm_build): every unordered pair
     of distinct vertices (r, c) is an edge with probability M[z[r], z[c]], unit weights
     (stochasticblockmodel.py:125-144 with directed=False, self_loops=False; one block = Erdos-Renyi).
@@ -979,13 +1039,13 @@ def sbm_graph(z, M, seed=None, ctx=None):
     try:
         nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))
-        indptr = np.empty(N + 1, dtype=np.int32)
-        indices = np.empty(nnz.value, dtype=np.int32)
-        data = np.empty(nnz.value, dtype=np.float64)
-        _capi.check(lib.gspx_knn_download_w(h, _capi.ptr(indptr), _capi.ptr(indices), _capi.ptr(data)))
+        # (keep_on_device: unit int64 weights in the host copy, like the reference's W)
+        W = DeviceAdjacency(h, ctx, N, nnz.value, weights=np.int64 if keep_on_device else np.float64)
+        h = None
     finally:
-        lib.gspx_knn_destroy(h)
-    return sparse.csr_matrix((data, indices, indptr), shape=(N, N)), ms.value
+        if h:
+            lib.gspx_knn_destroy(h)
+    return (W if keep_on_device else W.download()), ms.value
 
 
 def plan_describe(coeffs, ctx=None):

@@ -68,6 +68,7 @@ class Graph:
         self.tile_stats = None
         self._perm, self._perm_done = None, False
         self._dev = {}     # compute dtype -> engine.DeviceGraph
+        self._adj_host = self._adj_dev = None  # W: the scipy matrix / a builder's result still on the device
         self._L = self._dw = None
         self._flags = {}   # lazily computed facts about W ("directed")
         self._forget_spectrum()
@@ -77,7 +78,9 @@ class Graph:
         if coords is not None:
             self.coords = np.asanyarray(coords)
         self.plotting, self.signals = dict(plotting), {}
-        if not self._setup_on_device(adjacency):
+        if isinstance(adjacency, engine.DeviceAdjacency) and not self._setup_from_device_adjacency(adjacency):
+            adjacency = adjacency.download()  # (a directed symmetrisation type: the host route below)
+        if self._adj_dev is None and not self._setup_on_device(adjacency):
             # the host route (dense input, a directed graph, explicit zeros, ...): the reference's steps one by one
             self._adjacency = _checked_adjacency(adjacency, self.logger)
             self.n_vertices = self.N = self._adjacency.shape[0]
@@ -131,6 +134,47 @@ class Graph:
             self.tile_stats = dev.enable_gather_tiles()
         self._dev[self.compute_dtype] = dev
         return True
+
+    def _setup_from_device_adjacency(self, adjacency):
+        """A generator class hands over the W its device builder produced (engine.DeviceAdjacency): checks, vertex
+        order and Laplacian run on it where it lies (gspx_graph_setup_from_knn); the host copy behind G.W is made
+        when somebody asks for it.  False when the host route has to take over (a directed W)."""
+        order = self.reorder
+        if isinstance(order, str) and order == "rcm":
+            return False
+        if order == "auto" and getattr(self, "coords", None) is None:
+            order = "none"  # a sampled block model: no coordinates, and no order helps a random graph
+        if order in ("morton", "hilbert") and adjacency.shape[0] < 4096:
+            return False
+        dev, rep = engine.DeviceGraph.setup_from(adjacency, self.lap_type, self.compute_dtype,
+                                                 getattr(self, "coords", None), order)
+        if dev is None:
+            return False
+        if rep["self_loops"]:
+            self.logger.warning("Adjacency: there are self-loops (non-zeros on the diagonal). "
+                                "The Laplacian will not see them.")
+        self._adj_dev = adjacency
+        self.n_vertices = self.N = adjacency.shape[0]
+        self._flags["directed"] = False
+        self.n_edges = self.Ne = (adjacency.nnz - rep["self_loops"]) // 2 + rep["self_loops"]
+        self._perm_done, self._perm_lazy = True, dev if rep["reordered"] else None
+        self.setup_report = rep
+        if self.tiles == "auto":
+            self.tile_stats = dev.auto_gather_tiles()
+        elif self.tiles:
+            self.tile_stats = dev.enable_gather_tiles()
+        self._dev[self.compute_dtype] = dev
+        return True
+
+    @property
+    def _adjacency(self):
+        if self._adj_host is None and self._adj_dev is not None:
+            self._adj_host, self._adj_dev = self._adj_dev.download(), None
+        return self._adj_host
+
+    @_adjacency.setter
+    def _adjacency(self, W):
+        self._adj_host, self._adj_dev = W, None
 
     def _forget_spectrum(self):
         """Everything derived from the Laplacian's spectrum (graph.py:602-609)."""
@@ -333,7 +377,8 @@ class Graph:
         """The smallest of four classical upper bounds of lambda_max (graph.py:933-960)."""
         if self.lap_type != "combinatorial":
             return 2  # normalized Laplacian
-        if not self.is_directed() and self.W.dtype in (np.float64, np.int64):
+        w_dtype = self._adj_dev.weights if self._adj_dev is not None else self.W.dtype
+        if not self.is_directed() and w_dtype in (np.float64, np.int64):
             # the same four candidates from one device pass over W (gspx_graph_lmax_bounds), same operation order
             on_device = self.device_graph().lmax_bounds() if self.compute_dtype == np.float64 else None
             if on_device is not None:
@@ -447,9 +492,10 @@ class NNGraph(Graph):
         ctx = kwargs.get("ctx") or engine.default_context(int(kwargs.get("device", 0)))
         if NNtype == "knn":
             W, self.sigma, info = engine.knn_graph(points, k, sigma, ctx=ctx, metric=metric,
-                                                   symmetrize=symmetrize_type)
+                                                   symmetrize=symmetrize_type, keep_on_device=True)
         else:  # nngraph.py:228-287; a symmetric relation: (W + W.T) / 2 = W
-            W, self.sigma, info = engine.radius_graph(points, epsilon, sigma, ctx=ctx, metric=metric)
+            W, self.sigma, info = engine.radius_graph(points, epsilon, sigma, ctx=ctx, metric=metric,
+                                                      keep_on_device=True)
         self.knn_build_ms = info["build_ms"]
         Graph.__init__(self, W, plotting=plotting, coords=points, **kwargs)
 
@@ -570,10 +616,8 @@ class StochasticBlockModel(Graph):
             raise ValueError("Probabilities should be in [0, 1].")
         device_seed = int(stream.integers(0, 2 ** 63))
         ctx = kwargs.get("ctx") or engine.default_context(int(kwargs.get("device", 0)))
-        pattern, self.sampler_ms = engine.sbm_graph(self.z, self.M, seed=device_seed, ctx=ctx)
-        # unit int64 weights, like the reference's W
-        W = sparse.csr_matrix((np.ones(pattern.nnz, dtype=np.int64), pattern.indices, pattern.indptr),
-                              shape=pattern.shape)
+        # (W stays on the device until somebody reads G.W: unit int64 weights then, like the reference's W)
+        W, self.sampler_ms = engine.sbm_graph(self.z, self.M, seed=device_seed, ctx=ctx, keep_on_device=True)
         Graph.__init__(self, W, **kwargs)
 
 

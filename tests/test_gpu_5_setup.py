@@ -215,3 +215,47 @@ def test_upper_bound_of_lmax_from_the_device_pass(ctx):
     G32 = graphs.Graph(W, coords=coords, compute_dtype=np.float32)
     G32.estimate_lmax("bounds")
     assert abs(G32.lmax - ref) >= 0 and G32.lmax > 0
+
+
+def test_generators_hand_their_device_adjacency_over(ctx):
+    """NNGraph / Sensor / StochasticBlockModel end in Graph.__init__(W) (nngraph.py:289-313,
+    stochasticblockmodel.py:144-181).  Here the W their device builders produced stays on the device
+    (engine.DeviceAdjacency -> gspx_graph_setup_from_knn): same Laplacian, edge count, vertex order and filter output as
+    the graph built from the downloaded matrix, and G.W - made on first access - is that matrix."""
+    G = graphs.Sensor(30000, k=6, seed=3)
+    assert G._adj_dev is not None and G._adj_host is None and not G.is_directed()
+    assert G.setup_report["built"] and G.setup_report["reordered"]
+    Wh, coords = graphs.sensor_weights(30000, k=6, seed=3)
+    assert G.n_edges == Wh.nnz // 2 and G.N == 30000
+    G.estimate_lmax("bounds")
+    assert G._adj_dev is not None  # (the bounds came from the device pass: nobody has asked for W yet)
+    H = graphs.Graph(Wh, coords=coords)
+    H.estimate_lmax("bounds")
+    assert G.lmax == pytest.approx(H.lmax, rel=1e-12)
+    s = np.random.default_rng(0).standard_normal((G.N, 3))
+    yg = filters.Heat(G, 10).filter(s, order=20)
+    yh = filters.Heat(H, 10).filter(s, order=20)
+    assert rel_err(yg, yh) < 1e-12
+    assert np.array_equal(G._internal_order(), H._internal_order())
+    assert G._adj_dev is not None
+    W = G.W  # now the download
+    assert G._adj_dev is None and sparse.isspmatrix_csr(W) and abs(W - Wh).max() < 1e-15
+    assert _same_csr(G.L, orc.laplacian(W))
+    # a second Laplacian type on the same graph object: rebuilt from the (now host) matrix
+    G.compute_laplacian("normalized")
+    assert abs(G.L - orc.laplacian(W, "normalized")).max() < 1e-14
+    # radius graphs, another symmetrisation type (utils.symmetrize 'tril': the lower triangle mirrored)
+    X = np.random.default_rng(5).uniform(0, 1, (5000, 2))
+    R = graphs.NNGraph(X, NNtype="radius", epsilon=0.03, rescale=False, center=False)
+    assert R._adj_dev is not None and _same_csr(R.L, orc.laplacian(R.W))
+    T = graphs.NNGraph(X, k=5, symmetrize_type="tril", rescale=False, center=False)
+    assert T._adj_dev is not None and not T.is_directed() and abs(T.W - T.W.T).nnz == 0 and _same_csr(T.L, orc.laplacian(T.W))
+    # block models: unit int64 weights in the host copy, like the reference's W
+    B = graphs.StochasticBlockModel(6000, k=3, p=0.01, q=0.001, seed=2)
+    assert B._adj_dev is not None
+    yb = filters.Heat(B, 5).filter(np.ones(B.N), order=10)
+    WB = B.W
+    assert WB.dtype == np.int64 and set(np.unique(WB.data)) == {1} and abs(WB - WB.T).nnz == 0
+    assert B.n_edges == WB.nnz // 2 and _same_csr(B.L, orc.laplacian(WB))
+    assert rel_err(yb, orc.cheby_op(orc.laplacian(WB), B.lmax, filters.compute_cheby_coeff(filters.Heat(B, 5), m=10),
+                                    np.ones(B.N))) < 1e-12
