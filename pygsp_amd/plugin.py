@@ -82,14 +82,34 @@ def device_graph_for(G, ctx=None):
         return dev
 
 
+def _estimate_lmax_on_device(self, method="lanczos"):
+    """``Graph.estimate_lmax`` of the reference (graph.py:858-931) with its 'lanczos' branch on the device: the
+    ARPACK call of graph.py:911-917 (3.3 s at N = 1M, random start vector) becomes gspx_lanczos_lmax on the
+    graph's device Laplacian (milliseconds, deterministic).  Same contract - a Ritz value from below, checked
+    against the upper bound, increased by 1 % (graph.py:919-920), ValueError when it does not converge - and the
+    same caching through ``_lmax_method``; every other method is the reference's own code."""
+    if method != "lanczos":
+        return _saved["estimate_lmax"](self, method)
+    if method == self._lmax_method:
+        return
+    ritz, _ = device_graph_for(self).lanczos_lmax(max_iter=80, tol=5e-4)
+    assert ritz <= self._get_upper_bound() * (1 + 1e-6) + 1e-12
+    self._lmax_method = method
+    self._lmax = ritz * 1.01
+
+
 def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, reorder="auto",
-            tiles="auto", devices=None):
+            tiles="auto", devices=None, lmax="reference"):
     """Patch the real pygsp in place.  `laplacian`: 'device' (L assembled by HIP kernels from
     G.W) or 'host' (upload the reference's G.L).  `devices` (a list of GPU ids, optional): every
     ``Filter.filter(method='chebyshev')`` splits its signal columns over these GPUs - the graph is replicated
-    once per GPU, the outputs are gathered by RCCL inside libgspx (pygsp_amd.multi.filter_columns)."""
+    once per GPU, the outputs are gathered by RCCL inside libgspx (pygsp_amd.multi.filter_columns).
+    `lmax`: 'device' also replaces ``Graph.estimate_lmax`` so that its default 'lanczos' method runs on the device
+    (the step right before the path); 'reference' (default) leaves ARPACK in place."""
     if laplacian not in ("device", "host"):
         raise ValueError("laplacian must be 'device' or 'host'")
+    if lmax not in ("device", "reference"):
+        raise ValueError("lmax must be 'device' or 'reference'")
     if pygsp_module is None:
         import pygsp as pygsp_module
     if devices is not None:
@@ -105,6 +125,13 @@ def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, r
         _saved["alias"] = getattr(pygsp_module.filters, "cheby_op", None)
     approx.cheby_op = _filters.cheby_op
     pygsp_module.filters.cheby_op = _filters.cheby_op
+    graph_cls = getattr(getattr(pygsp_module, "graphs", None), "Graph", None)
+    if lmax == "device" and graph_cls is not None:
+        if "estimate_lmax" not in _saved:
+            _saved["estimate_lmax"] = graph_cls.estimate_lmax
+        graph_cls.estimate_lmax = _estimate_lmax_on_device
+    elif "estimate_lmax" in _saved and graph_cls is not None:
+        graph_cls.estimate_lmax = _saved.pop("estimate_lmax")
     return pygsp_module
 
 
@@ -117,6 +144,9 @@ def uninstall(pygsp_module=None):
     alias = _saved.pop("alias")
     if alias is not None:
         pygsp_module.filters.cheby_op = alias
+    graph_cls = getattr(getattr(pygsp_module, "graphs", None), "Graph", None)
+    if "estimate_lmax" in _saved and graph_cls is not None:
+        graph_cls.estimate_lmax = _saved.pop("estimate_lmax")
 
 
 def use_backend(name, pygsp_module=None, **install_options):

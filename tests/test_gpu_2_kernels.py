@@ -563,3 +563,61 @@ def test_host_pipeline_equals_one_shot_call(ctx, dtype):
     finally:
         for k, v in (("host_pipeline", 1), ("host_batch", 0), ("host_threads", 0)):
             ctx.set_option(k, v)
+
+
+def test_plugin_estimate_lmax_seam(ctx):
+    """plugin.install(lmax='device'): ``Graph.estimate_lmax`` of a pygsp-shaped module (graph.py:858-931) takes its
+    'lanczos' branch to the device - Ritz value x 1.01 within the reference's tolerance of the true lambda_max,
+    cached through ``_lmax_method``, 'bounds' untouched, and the original method back after uninstall()."""
+    import types
+
+    from scipy.sparse import linalg as splinalg
+
+    from pygsp_amd import plugin
+
+    W, _ = graphs.sensor_weights(6000, k=6, seed=8)
+    calls = []
+
+    class RefGraph:
+        def __init__(self):
+            self.W, self.N, self.lap_type = W, W.shape[0], "combinatorial"
+            self.L = orc.laplacian(W)
+            self._lmax = self._lmax_method = None
+
+        def is_directed(self):
+            return False
+
+        def _get_upper_bound(self):
+            return upper_lmax(W)
+
+        def estimate_lmax(self, method="lanczos"):  # stands for the reference's ARPACK / bounds code
+            calls.append(method)
+            self._lmax_method = method
+            self._lmax = self._get_upper_bound()
+
+    fake = types.ModuleType("pygsp")
+    fake.filters = types.ModuleType("pygsp.filters")
+    fake.filters.approximations = types.ModuleType("pygsp.filters.approximations")
+    fake.filters.approximations.cheby_op = fake.filters.cheby_op = lambda G, c, s, **kw: None
+    fake.graphs = types.ModuleType("pygsp.graphs")
+    fake.graphs.Graph = RefGraph
+    original = RefGraph.estimate_lmax
+    true = float(splinalg.eigsh(orc.laplacian(W).astype(np.float64), k=1, return_eigenvectors=False)[0])
+    try:
+        plugin.install(fake, lmax="device")
+        G = RefGraph()
+        G.estimate_lmax()
+        assert calls == [] and G._lmax_method == "lanczos"
+        assert true * (1 - 5e-3) * 1.01 <= G._lmax <= true * 1.01 * (1 + 1e-9)
+        first = G._lmax
+        G.estimate_lmax("lanczos")  # cached
+        assert G._lmax == first and calls == []
+        G.estimate_lmax("bounds")   # the reference's own code
+        assert calls == ["bounds"] and G._lmax == upper_lmax(W)
+        plugin.install(fake)        # default: the reference's estimate_lmax again
+        assert RefGraph.estimate_lmax is original
+        plugin.install(fake, lmax="device")
+        assert RefGraph.estimate_lmax is not original
+    finally:
+        plugin.uninstall(fake)
+    assert RefGraph.estimate_lmax is original

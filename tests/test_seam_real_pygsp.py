@@ -66,3 +66,30 @@ def test_reference_doctest_value_through_the_seam(tmp_path):
     res, calls = _run_reference_tests(tmp_path, str(script))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert calls.get("cheby_op", 0) >= 3, calls
+
+
+def test_estimate_lmax_seam_on_the_real_graph_class():
+    """plugin.install(pygsp, lmax='device') replaces the REAL ``pygsp.graphs.Graph.estimate_lmax`` (graph.py:858) and
+    uninstall() / a default install() put the reference's method back; with the seam in place the 'bounds' method is
+    still the reference's own code (no device here, so the 'lanczos' branch itself runs in `-m gpu`,
+    test_plugin_estimate_lmax_seam)."""
+    code = (
+        "import pygsp\n"
+        "from pygsp_amd import plugin\n"
+        "orig = pygsp.graphs.Graph.estimate_lmax\n"
+        "plugin.install(pygsp, lmax='device')\n"
+        "assert pygsp.graphs.Graph.estimate_lmax is not orig\n"
+        "G = pygsp.graphs.Logo()\n"
+        "G.estimate_lmax('bounds')\n"
+        "assert abs(G.lmax - 18.583333333333332) < 1e-12 and G._lmax_method == 'bounds'\n"
+        "plugin.install(pygsp)\n"
+        "assert pygsp.graphs.Graph.estimate_lmax is orig\n"
+        "plugin.install(pygsp, lmax='device'); plugin.uninstall(pygsp)\n"
+        "assert pygsp.graphs.Graph.estimate_lmax is orig\n"
+        "print('seam ok')\n")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([REF, ROOT])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    env["MPLBACKEND"] = "Agg"
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "seam ok" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
