@@ -192,6 +192,10 @@ int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, doubl
  * kernels (sum of device times), out[4] device-to-host DMA, out[5] unpacking (busiest host thread), out[6]
  * batches (0: the call was not pipelined), out[7] signals per batch, out[8] host threads per direction. */
 int gspx_last_host_timing(gspx_ctx* ctx, double out[9]);
+/* Host clock of the last pipelined gspx_cheby_filter, per batch, in ms since the call began: [6 b + 0] packed,
+ * [+1] H2D issued, [+2] kernels begun, [+3] kernels done, [+4] D2H done, [+5] unpacked.  *batches: how many there
+ * were; out (capacity doubles) may be NULL. */
+int gspx_last_host_timeline(gspx_ctx* ctx, double* out, int capacity, int* batches);
 
 /* Calibration: read+write GB/s of the engine's 16-byte-per-lane streaming copy kernel over two
  * `bytes`-sized buffers (the measured HBM ceiling reported beside roofline fractions). */

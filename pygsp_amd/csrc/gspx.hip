@@ -265,6 +265,9 @@ struct HostPipe {
   // timings of the last pipelined call (ms): wall, pack (busiest worker), H2D (sum of DMA times), kernels
   // (sum of device times), D2H, unpack (busiest worker), batches, batch width, host threads per direction
   double timing[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // host clock (ms since the call began) per batch of the last pipelined call: packed, H2D issued, kernels begun,
+  // kernels done, D2H done, unpacked
+  std::vector<double> timeline;
   bool ready = false;
   int init() {
     if (ready) return GSPX_OK;
@@ -2605,6 +2608,16 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
 extern "C" int gspx_last_host_timing(gspx_ctx* ctx, double out[9]) {
   if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null argument");
   for (int i = 0; i < 9; ++i) out[i] = ctx->pipe ? ctx->pipe->timing[i] : 0.0;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_last_host_timeline(gspx_ctx* ctx, double* out, int capacity, int* batches) {
+  if (!ctx || !batches) return set_err(GSPX_ERR_INVALID, "null argument");
+  const std::vector<double> empty;
+  const std::vector<double>& t = ctx->pipe ? ctx->pipe->timeline : empty;
+  *batches = (int)(t.size() / 6);
+  if (out)
+    for (int i = 0; i < capacity && i < (int)t.size(); ++i) out[i] = t[(size_t)i];
   return GSPX_OK;
 }
 

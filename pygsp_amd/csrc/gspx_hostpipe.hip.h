@@ -121,6 +121,10 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
     return true;
   };
   std::vector<double> pack_ms((size_t)P, 0.0), unpack_ms((size_t)Q, 0.0);
+  std::vector<double> line((size_t)nb * 6, 0.0);  // (each entry is written by the one thread that completes the stage)
+  auto stamp = [&](int b, int what) {
+    line[(size_t)b * 6 + what] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  };
   double h2d_ms = 0, d2h_ms = 0;
   auto width_of = [&](int b) { return widths[(size_t)b]; };
 
@@ -142,6 +146,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
         last = ++pack_arrived[(size_t)b] == P;
       }
       if (last) {  // the panel is complete: one contiguous DMA
+        stamp(b, 0);
         if (hipfail(hipSetDevice(ctx->device), "hipSetDevice")) return;
         if (b >= NIN) {  // the slot's previous DMA (batch b - NIN) is complete: its kernels have run
           float t = 0;
@@ -152,6 +157,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
                                    hipMemcpyHostToDevice, hp.stream_in), "hipMemcpyAsync (H2D)")) return;
         if (hipfail(hipEventRecord(hp.t_in[s][1], hp.stream_in), "hipEventRecord")) return;
         if (hipfail(hipEventRecord(hp.h2d_ev[s], hp.stream_in), "hipEventRecord")) return;
+        stamp(b, 1);
         std::lock_guard<std::mutex> lock(mu);
         issued = b + 1;
         cv.notify_all();
@@ -171,6 +177,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
       if (hipfail(hipStreamSynchronize(hp.stream_out), "hipStreamSynchronize")) return;
       float t = 0;
       if (hipEventElapsedTime(&t, hp.t_out[0], hp.t_out[1]) == hipSuccess) d2h_ms += t;
+      stamp(b, 4);
       std::lock_guard<std::mutex> lock(mu);
       shipped = b + 1;
       cv.notify_all();
@@ -200,6 +207,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
       unpack_ms[(size_t)q] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       std::lock_guard<std::mutex> lock(mu);
       if (++unpack_arrived[(size_t)b] == Q) {
+        stamp(b, 5);
         unpacked = b + 1;
         cv.notify_all();
       }
@@ -222,11 +230,13 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
     const int s = b % NIN, so = b & 1;
     if (!wait_for([&] { return issued >= b + 1 && shipped >= b - 1; })) break;
     if (hipfail(hipStreamWaitEvent(ctx->stream, hp.h2d_ev[s], 0), "hipStreamWaitEvent")) break;
+    stamp(b, 2);
     const int rc = filter_dev_t<T>(g, lmax, Nf, M, coeffs, width_of(b), (const T*)hp.dx[s].p, (T*)hp.dy[so].p, mode);
     if (rc != GSPX_OK) {
       fail(rc);
       break;
     }
+    stamp(b, 3);
     k_ms += ctx->timing[0];
     for (int i = 0; i < 5; ++i) tm[i] += ctx->timing[i];
     std::lock_guard<std::mutex> lock(mu);
@@ -257,6 +267,7 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
   hp.timing[6] = nb;
   hp.timing[7] = (double)w;
   hp.timing[8] = P;
+  hp.timeline = line;
   if (kernel_ms) *kernel_ms = k_ms;
   return GSPX_OK;
 }

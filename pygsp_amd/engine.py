@@ -60,6 +60,16 @@ class Context:
                 "unpack_ms": out[5], "batches": int(out[6]), "signals_per_batch": int(out[7]),
                 "host_threads_per_direction": int(out[8])}
 
+    def last_host_timeline(self):
+        """(batches, 6) array: host clock (ms since the call began) at which every batch of the last pipelined
+        host-array call was packed, had its H2D issued, began / finished its kernels, finished its D2H, was unpacked."""
+        n = ctypes.c_int(0)
+        _capi.check(_capi.load().gspx_last_host_timeline(self._h, None, 0, ctypes.byref(n)))
+        out = np.zeros((max(n.value, 0), 6))
+        if n.value > 0:
+            _capi.check(_capi.load().gspx_last_host_timeline(self._h, _capi.ptr(out), out.size, ctypes.byref(n)))
+        return out
+
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
