@@ -1729,24 +1729,27 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   if (lg < 8)
     lds = std::min(lds, (size_t)GSPX_TILE_MAXN1 * 16 * lg + (((size_t)g->gt_entmax * sizeof(T) + 15) & ~(size_t)15) +
                             (((size_t)g->gt_entmax + 15) & ~(size_t)15) + 64);
+  if (lg < 8) lds = (lds + 2047) & ~(size_t)2047;  // (graphs differ in their largest block: few distinct sizes)
   int per_cu = 2;
   {  // once per kernel build, device and LDS size (a driver call per launch would cost microseconds each)
-    static std::map<std::pair<const void*, int>, std::pair<size_t, int>> lds_set;
+    struct Known { size_t attr = 0; std::map<size_t, int> fit; };
+    static std::map<std::pair<const void*, int>, Known> known;
     static std::mutex lds_mu;
     std::lock_guard<std::mutex> lock(lds_mu);
-    const auto key = std::make_pair((const void*)kern, g->ctx->device);
-    auto it = lds_set.find(key);
-    if (it == lds_set.end() || it->second.first != lds) {
+    Known& k = known[std::make_pair((const void*)kern, g->ctx->device)];
+    if (k.attr < lds) {  // the limit only ever grows
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      int fit = 2;
-      if (lg < 8) {  // resident workgroups of the small builds: what registers and LDS allow
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (const void*)kern, (int)threads, lds));
-        fit = std::max(2, std::min(fit, 16));
-      }
-      lds_set[key] = std::make_pair(lds, fit);
-      it = lds_set.find(key);
+      k.attr = lds;
     }
-    per_cu = it->second.second;
+    if (lg < 8) {  // resident workgroups of the small builds: what registers and LDS allow
+      auto it = k.fit.find(lds);
+      if (it == k.fit.end()) {
+        int fit = 2;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (const void*)kern, (int)threads, lds));
+        it = k.fit.emplace(lds, std::max(2, std::min(fit, 16))).first;
+      }
+      per_cu = it->second;
+    }
   }
   t.rowptr = g->rptr.as<int>();
   t.col = g->rcol.as<int>();
@@ -1766,6 +1769,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   unsigned nwg = (unsigned)std::max<int64_t>(8, ((int64_t)per_cu * g->ctx->cu_count) / 8 * 8);
   if (opt.tile_workgroups > 0)
     nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.tile_workgroups, 1 << 20) / 8 * 8);
+  nwg = std::min(nwg, 8u * (unsigned)std::max(t.per_xcd, 1));  // (workgroups beyond an XCD's blocks would exit at once)
   t.nt = opt.tile_nt >= 0 ? (int)opt.tile_nt : ((size_t)g->N * ld * sizeof(T) >= ((size_t)192 << 20) ? 5 : 0);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), lds, st, t);
   return GSPX_OK;

@@ -959,10 +959,12 @@ class DeviceAdjacency:
 
     def close(self):
         h, self._h = self._h, None
-        if h and _capi is not None:
+        if h:
             _capi.load().gspx_knn_destroy(h)
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may already be gone; the OS reclaims the memory
+            return
         try:
             self.close()
         except Exception:
