@@ -283,8 +283,8 @@ def run_config(key, workload, G, bank, nsig, K, dtype, ctx, oracle_cols=2, reps=
         # row through the L2 -> Infinity Cache / HBM path
         "gather": {"bytes_per_step": gather_bytes, "rate_GBps": gather_bytes / (step_ms * 1e-3) / 1e9},
         "roofline_gather": roof_gather,
-        "kernel": ("k_step_narrow (sub-wave rows: rows under 16 bytes of a matrix that stays in the L2s)"
-                   if tiled and nsig * elt < 16 and dev.nnz_internal * (elt + 4) < (20 << 20) else
+        "kernel": ("k_step_narrow (sub-wave rows: a single signal on a matrix that stays in the L2s)"
+                   if tiled and nsig == 1 and dev.nnz_internal * (elt + 4) < (20 << 20) else
                    "k_step_tile (LDS-staged gathers)" if tiled else "plain gather kernels (no vertex locality: no tiles)"),
         "internal_order": "curve / RCM" if G._internal_order() is not None else "none (graph's own order)",
         "parity_vs_oracle": {"max_rel_err": err, "columns": len(cols), "tolerance": 1e-5 if elt == 8 else 1e-3},

@@ -85,7 +85,7 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *                   T_{k-2} rows, bit 3 T_k stores; -1 (default): 5 for panels of 192 MiB and more
  *   "tile_workgroups" / "pair_workgroups"   persistent workgroups of k_step_tile / k_newton_pair (0: 2 per CU)
  *   "tile_pad"      1 (default) panels whose rows are not made of 16-byte pieces take k_step_tile with padded
- *                   rows (rows under 16 bytes only on graphs beyond the L2s); 2 always; 0 never.  "tile_min_row"
+ *                   rows (a single signal only on graphs beyond the L2s); 2 always; 0 never.  "tile_min_row"
  *                   (16) narrowest rows in bytes k_step_tile takes; "tile_lg" 2 / 4 / 8: no build narrower than that
  *   "vec", "rows_per_wave", "narrow_g_log2", "waves_per_block"   launch shapes of the plain gather
  *                   kernels (0 / -1 = auto)

@@ -323,7 +323,7 @@ struct Options {
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU; what fits for the small builds)
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
-                                // (rows under 16 bytes only on graphs beyond the L2s); 2: always; 0: never
+                                // (a single signal only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
@@ -1804,10 +1804,11 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   constexpr unsigned TVEC = 16 / (unsigned)sizeof(T);
   const unsigned ldp = (ld + TVEC - 1) / TVEC * TVEC;
   const bool tile_direct = (deferred || nf == 1) && tile_usable<T>(g, opt, ld, y, ldy);
-  // (rows under 16 bytes - one fp64 signal, up to three fp32 ones - on a graph whose matrix stays in the L2s: the
-  // sub-wave kernel is the faster one there, 0.125 against 0.150 ms for 30 orders at N = 50k; from ~20 MB of matrix
-  // on the padded tile path wins, 0.89 against 1.19 ms at N = 1M.  Wider odd rows: the tile path at every size.)
-  const bool pad_pays = opt.tile_pad == 2 || (size_t)ld * sizeof(T) >= 16 ||
+  // (a single signal on a graph whose matrix stays in the L2s: the sub-wave kernel is the faster one there, 0.125
+  // against 0.150 ms for 30 orders at N = 50k; from ~20 MB of matrix on the padded tile path wins, 0.86 against
+  // 1.19 ms at N = 1M.  Two signals and more: the tile path at every size - 0.15 against 0.18 ms for two fp32
+  // signals at N = 100k.)
+  const bool pad_pays = opt.tile_pad == 2 || ld >= 2 ||
                         (size_t)g->nnz_int * (sizeof(T) + 4) >= ((size_t)20 << 20);
   const bool padded = !tile_direct && (deferred || nf == 1) && opt.tile_pad && pad_pays && tile_geometry<T>(g, opt, ldp);
   const unsigned ldw = padded ? ldp : ld;
@@ -2150,7 +2151,7 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
   constexpr unsigned TVEC = 16 / (unsigned)sizeof(T);
   const unsigned ldp = (ld + TVEC - 1) / TVEC * TVEC;
   const bool tile_direct = tile_usable<T>(g, opt, ld, y, ldy) && (size_t)nf * N * ld * sizeof(T) < ((size_t)1 << 31);
-  const bool pad_pays = opt.tile_pad == 2 || (size_t)ld * sizeof(T) >= 16 ||
+  const bool pad_pays = opt.tile_pad == 2 || ld >= 2 ||
                         (size_t)g->nnz_int * (sizeof(T) + 4) >= ((size_t)20 << 20);
   const bool padded = !tile_direct && opt.tile_pad && pad_pays && tile_geometry<T>(g, opt, ldp) &&
                       (size_t)nf * N * ldp * sizeof(T) < ((size_t)1 << 31);
