@@ -98,7 +98,9 @@ int gspx_div_dev(gspx_graph* g, int64_t Nsig, const void* y_dev, void* z_dev, do
  * sigma == 0 selects the mean neighbour distance.  metric: 0 euclidean, 1 manhattan, 2 max_dist (the
  * reference's dist_type; 'minkowski' with order 1, 2 or inf maps onto them).  symmetrize: 0 'average',
  * 1 'maximum' (= 'fill' for a k-NN matrix), 2 'tril', 3 'triu' (utils.symmetrize, utils.py:247-275).  Neighbours and distances
- * equal scipy's KD-tree bit for bit (ties ordered by vertex index); a point is never its own neighbour. */
+ * equal scipy's KD-tree bit for bit (ties ordered by vertex index); a point is never its own neighbour.  Context option "knn_f32": the candidate sweep beyond three
+ * dimensions on the fp32 matrix cores - 1 (default) when its rounding margin is small against the bounds, 0 never,
+ * 2 always; the selection is exact either way. */
 typedef struct gspx_knn gspx_knn;
 int gspx_knn_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, int k, double sigma,
                    int metric, int symmetrize, gspx_knn** out);

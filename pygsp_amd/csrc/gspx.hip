@@ -322,6 +322,8 @@ struct Options {
   int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU; what fits for the small builds)
+  int64_t knn_f32 = 1;          // neighbour sweep beyond three dimensions on the fp32 matrix cores: 1 when its rounding
+                                // margin is small against the bounds, 0 never, 2 always (the selection stays exact)
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
                                 // (a single signal only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
@@ -546,6 +548,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
   if (!strcmp(key, "tile_min_row")) return &o.tile_min_row;
   if (!strcmp(key, "tile_pad")) return &o.tile_pad;
+  if (!strcmp(key, "knn_f32")) return &o.knn_f32;
   if (!strcmp(key, "tile_nt")) return &o.tile_nt;
   if (!strcmp(key, "fuse_input")) return &o.fuse_input;
   if (!strcmp(key, "edge_vertex_walk")) return &o.edge_vertex_walk;

@@ -81,7 +81,7 @@ template <int DT> __device__ __forceinline__ void bf_load_query(double (&q)[4 * 
 // X (N x d, row major) -> Xop[tile][t][lane] = X[16 tile + (lane & 15)][4 t + (lane >> 4)] (zero beyond N / d),
 // norm[i] = sum_j x_ij^2 (padded to whole tiles with 1e300)
 __global__ void k_bf_prepare(const double* __restrict__ x, int N, int d, int DT, double* __restrict__ xop,
-                             double* __restrict__ norm) {
+                             double* __restrict__ norm, float* __restrict__ xop32) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)((N + 15) / 16) * DT * 64;
   if (gid < total) {
@@ -91,7 +91,9 @@ __global__ void k_bf_prepare(const double* __restrict__ x, int N, int d, int DT,
     const long long tile = tt / DT;
     const long long p = tile * 16 + (lane & 15);
     const int j = 4 * t + (lane >> 4);
-    xop[gid] = (p < N && j < d) ? x[p * d + j] : 0.0;
+    const double v = (p < N && j < d) ? x[p * d + j] : 0.0;
+    xop[gid] = v;
+    if (xop32) xop32[gid] = (float)v;  // operands of the fp32 sweep (the bound's margin covers their rounding)
   }
   if (gid < N) {
     double s = 0;
@@ -148,8 +150,13 @@ __device__ __forceinline__ void bf_append(const int* __restrict__ off, int cap, 
 
 // One wave = 64 queries (four 16-query tiles, their operands in registers), sweeping all point tiles: 4 x DT
 // MFMAs per point tile, then 16 (query, point) pairs per lane are tested against the query's bound.
-template <int DT>
-__global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ xop, const double* __restrict__ norm,
+// F = double: v_mfma_f64_16x16x4f64.  F = float: v_mfma_f32_16x16x4f32 at twice the rate - the sweep only has to
+// admit a SUPERSET of the true neighbours (k_bf_select decides in the KD-tree's arithmetic), so single precision
+// does when its rounding margin, (4 DT + 8) 2^-24 (|x|^2 + |y|^2), is small against the bounds (the caller checks);
+// the bound is rounded up and the point's norm down, towards admitting.
+typedef float bf_f4 __attribute__((ext_vector_type(4)));
+template <int DT, typename F>
+__global__ __launch_bounds__(256) void k_bf_collect(const F* __restrict__ xop, const double* __restrict__ norm,
                                                     const double* __restrict__ tau, int N, int phase, int step,
                                                     int count, double margin_scale, double norm_max, int cap,
                                                     const int* __restrict__ off, int* __restrict__ cnt,
@@ -158,27 +165,33 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q0 = wave * 64;
   if (q0 >= N) return;
+  constexpr bool F32 = sizeof(F) == 4;
+  typedef typename std::conditional<F32, bf_f4, bf_d4>::type acc_t;
   const int ntiles = (N + 15) / 16;
-  double a[4][DT];
+  F a[4][DT];
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt) {
     const long long tile = (long long)(q0 / 16 + qt);
 #pragma unroll
-    for (int t = 0; t < DT; ++t) a[qt][t] = tile < ntiles ? xop[(tile * DT + t) * 64 + lane] : 0.0;
+    for (int t = 0; t < DT; ++t) a[qt][t] = tile < ntiles ? xop[(tile * DT + t) * 64 + lane] : F(0);
   }
-  // this lane's 16 queries: q0 + 16 qt + kq + 4 e; bound minus the query's own norm (what is compared is
-  // |y|^2 - 2 x.y), with the rounding margin of the product form
-  double lim[4][4];
+  // this lane's 16 queries - rows kq + 4 e of a query tile in the fp64 product's result layout, rows 4 kq + e in
+  // the fp32 one's -; bound minus the query's own norm (what is compared is |y|^2 - 2 x.y), with the rounding
+  // margin of the product form
+  auto query_of = [&](int qt, int e) { return q0 + 16 * qt + (F32 ? 4 * kq + e : kq + 4 * e); };
+  F lim[4][4];
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int q = q0 + 16 * qt + kq + 4 * e;
+      const int q = query_of(qt, e);
       if (q < N) {
         const double nq = norm[q];
-        lim[qt][e] = tau[q] - nq + margin_scale * (nq + norm_max);
+        const double l = tau[q] - nq + margin_scale * (nq + norm_max);
+        if constexpr (F32) lim[qt][e] = __double2float_ru(l);
+        else lim[qt][e] = l;
       } else {
-        lim[qt][e] = -1e300;
+        lim[qt][e] = F32 ? F(-3e38) : F(-1e300);
       }
     }
   // Software pipeline: a tile's operands AND its norms are loaded one tile ahead, so no load issued in an
@@ -191,41 +204,49 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
   volatile unsigned long long* queue = queue_all[threadIdx.x >> 6];
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   int queued = 0;  // wave-uniform
-  double b[DT], b_next[DT], n_next;
+  F b[DT], b_next[DT], n_next;
+  auto norm_of = [&](int i) {  // (the padding points' 1e300 stays "infinitely far" in single precision)
+    const double v = norm[i];
+    if constexpr (F32) return v > 3e38 ? 3e38f : __double2float_rd(v);
+    else return v;
+  };
   // the j-th point tile of this sweep: phase 0 takes every step-th tile (a strided subset of the cloud: a fair
   // sample whatever order the points come in), phase 1 the tiles in between
   auto tile_of = [&](int j) { return phase == 0 ? j * step : (j / (step - 1)) * step + 1 + j % (step - 1); };
   int ct_next = tile_of(0);
   {
-    n_next = norm[ct_next * 16 + cq];
+    n_next = norm_of(ct_next * 16 + cq);
 #pragma unroll
     for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)ct_next * DT + t) * 64 + lane];
   }
   for (int j = 0; j < count; ++j) {
     const int ct = ct_next;
-    const double nc = n_next;
+    const F nc = n_next;
 #pragma unroll
     for (int t = 0; t < DT; ++t) b[t] = b_next[t];
     if (j + 1 < count) {
       ct_next = tile_of(j + 1);
-      n_next = norm[ct_next * 16 + cq];  // (padded: no bounds test between the load and its use a tile later)
+      n_next = norm_of(ct_next * 16 + cq);  // (padded: no bounds test between the load and its use a tile later)
 #pragma unroll
       for (int t = 0; t < DT; ++t) b_next[t] = xop[((long long)ct_next * DT + t) * 64 + lane];
     }
-    bf_d4 acc[4];
+    acc_t acc[4];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) acc[qt] = bf_d4{0, 0, 0, 0};
+    for (int qt = 0; qt < 4; ++qt) acc[qt] = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) acc[qt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][t], b[t], acc[qt], 0, 0, 0);
-    // D layout: lane (kq, cq) holds query rows kq + 4 e, point column cq
+      for (int qt = 0; qt < 4; ++qt) {
+        if constexpr (F32) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qt][t], b[t], acc[qt], 0, 0, 0);
+        else acc[qt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qt][t], b[t], acc[qt], 0, 0, 0);
+      }
+    // D layout: lane (kq, cq) holds query rows kq + 4 e (fp64) / 4 kq + e (fp32), point column cq
     // (the tests are folded with a scalar OR of the compare masks: two vector instructions per pair)
     bool any = false;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) any |= nc - 2.0 * acc[qt][e] <= lim[qt][e];
+      for (int e = 0; e < 4; ++e) any |= nc - F(2) * acc[qt][e] <= lim[qt][e];
     if (__builtin_amdgcn_ballot_w64(any) != 0) {
       // Hits are parked in the wave's LDS queue and appended 64 at a time: an append is an atomic (whose return the
       // wave must wait for) plus a scattered store, and about 60 % of the tiles hit something - appending on the
@@ -235,12 +256,12 @@ __global__ __launch_bounds__(256) void k_bf_collect(const double* __restrict__ x
       for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool hit = nc - 2.0 * acc[qt][e] <= lim[qt][e];
+          const bool hit = nc - F(2) * acc[qt][e] <= lim[qt][e];
           const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
           if (m != 0) {
             if (hit) {
               const int pos = queued + __popcll(m & lt_mask);
-              queue[pos] = ((unsigned long long)(unsigned)(q0 + 16 * qt + kq + 4 * e) << 32) | (unsigned)c;
+              queue[pos] = ((unsigned long long)(unsigned)query_of(qt, e) << 32) | (unsigned)c;
             }
             queued += __popcll(m);
             if (queued >= 64) {  // at most 127 parked: room for one more round of 64
@@ -417,8 +438,10 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   const double expect = (double)k * (n1 / std::max(M - 1, 1) + (step > 1 ? (double)N / n1 : 0.0));
   // room for four times the expectation (clustered clouds), at least 8 k (+ 1: the point itself passes its own bound)
   const int cap = (int)std::min<int64_t>(std::max<int64_t>((int64_t)(4.0 * expect), 8 * k) + 1, N);
-  DevMem xop, norm, tau, cnt, buf, pmax;
+  DevMem xop, xop32, norm, tau, cnt, buf, pmax;
   CHK(xop.alloc((size_t)ntiles * DT * 64 * sizeof(double)));
+  const bool try32 = ctx->opt.knn_f32 != 0;
+  if (try32) CHK(xop32.alloc((size_t)ntiles * DT * 64 * sizeof(float)));
   CHK(norm.alloc((size_t)ntiles * 16 * sizeof(double)));
   CHK(tau.alloc((size_t)N * sizeof(double)));
   CHK(cnt.alloc((size_t)N * sizeof(int)));
@@ -426,20 +449,41 @@ static int knn_bruteforce(gspx_ctx* ctx, const double* x, int N, int d, int k, i
   HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)N * sizeof(int), st));
   const long long total = (long long)ntiles * DT * 64;
   hipLaunchKernelGGL(gspx::k_bf_prepare, dim3((unsigned)((std::max<long long>(total, N) + 255) / 256)), dim3(256), 0, st, x,
-                     N, d, DT, xop.as<double>(), norm.as<double>());
+                     N, d, DT, xop.as<double>(), norm.as<double>(), try32 ? xop32.as<float>() : (float*)nullptr);
   launch_bf(ctx, x, N, d, k, metric, stride, tau.as<double>(), 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
-  std::vector<double> hn((size_t)N);
+  std::vector<double> hn((size_t)N), ht((size_t)N);
   HIPCHK(hipMemcpyAsync(hn.data(), norm.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (try32) HIPCHK(hipMemcpyAsync(ht.data(), tau.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   double nmax = 0;
   for (double v : hn) nmax = std::max(nmax, v);
   // |fl(|y|^2 - 2 x.y) + |x|^2 - |x - y|^2| <= (4 DT + 8) u (|x|^2 + |y|^2) with u = 2^-53; ten times that
-  const double margin = 10.0 * (4.0 * DT + 8.0) * 1.1102230246251565e-16;
+  const double margin64 = 10.0 * (4.0 * DT + 8.0) * 1.1102230246251565e-16;
+  // The same bound with u = 2^-24 for the single-precision sweep: used when it widens a typical bound (the
+  // median over a sample of the queries) by at most half a percent - clouds far from the origin (|x|^2 >> the
+  // neighbour distances) keep the fp64 sweep.
+  const double margin32 = 10.0 * (4.0 * DT + 8.0) * 5.9604644775390625e-08;
+  bool use32 = false;
+  if (try32 && nmax < 1e30) {
+    std::vector<double> sample;
+    for (size_t i = 0; i < (size_t)N; i += std::max<size_t>(1, (size_t)N / 2048)) sample.push_back(ht[i]);
+    std::nth_element(sample.begin(), sample.begin() + sample.size() / 2, sample.end());
+    const double tmed = sample[sample.size() / 2];
+    use32 = ctx->opt.knn_f32 == 2 || margin32 * 2.0 * nmax <= 0.005 * tmed;
+  }
+  const double margin = use32 ? margin32 : margin64;
   const dim3 grid((unsigned)((N + 255) / 256));
 #define GSPX_BF(D_, PH_, CNT_)                                                                                           \
-  hipLaunchKernelGGL((gspx::k_bf_collect<D_>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),              \
-                     tau.as<double>(), N, PH_, step, CNT_, margin, nmax, cap, (const int*)nullptr, cnt.as<int>(),  \
-                     buf.as<int>())
+  do {                                                                                                                   \
+    if (use32)                                                                                                           \
+      hipLaunchKernelGGL((gspx::k_bf_collect<D_, float>), grid, dim3(256), 0, st, xop32.as<float>(), norm.as<double>(),  \
+                         tau.as<double>(), N, PH_, step, CNT_, margin, nmax, cap, (const int*)nullptr, cnt.as<int>(),    \
+                         buf.as<int>());                                                                                 \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((gspx::k_bf_collect<D_, double>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),  \
+                         tau.as<double>(), N, PH_, step, CNT_, margin, nmax, cap, (const int*)nullptr, cnt.as<int>(),    \
+                         buf.as<int>());                                                                                 \
+  } while (0)
   auto sweep = [&](int phase, int count) {
     if (DT == 4) GSPX_BF(4, phase, count);
     else if (DT == 8) GSPX_BF(8, phase, count);
@@ -535,7 +579,7 @@ static int radius_candidates(gspx_ctx* ctx, const double* x, int N, int d, doubl
   HIPCHK(hipMemsetAsync(cnt.p, 0, ((size_t)N + 1) * sizeof(int), st));
   const long long total = (long long)ntiles * DT * 64;
   hipLaunchKernelGGL(gspx::k_bf_prepare, dim3((unsigned)((std::max<long long>(total, N) + 255) / 256)), dim3(256), 0, st, x,
-                     N, d, DT, xop.as<double>(), norm.as<double>());
+                     N, d, DT, xop.as<double>(), norm.as<double>(), (float*)nullptr);
   hipLaunchKernelGGL((k_fill<double>), dim3(1024), dim3(256), 0, st, tau.as<double>(), (size_t)N, eps2);
   std::vector<double> hn((size_t)N);
   HIPCHK(hipMemcpyAsync(hn.data(), norm.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -546,7 +590,7 @@ static int radius_candidates(gspx_ctx* ctx, const double* x, int N, int d, doubl
   const dim3 grid((unsigned)((N + 255) / 256));
   auto sweep = [&](const int* offp, int* bufp) {
 #define GSPX_BF(D_)                                                                                                  \
-  hipLaunchKernelGGL((gspx::k_bf_collect<D_>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),          \
+  hipLaunchKernelGGL((gspx::k_bf_collect<D_, double>), grid, dim3(256), 0, st, xop.as<double>(), norm.as<double>(),  \
                      tau.as<double>(), N, 0, 1, ntiles, margin, nmax, 0, offp, cnt.as<int>(), bufp)
     if (DT == 4) GSPX_BF(4);
     else if (DT == 8) GSPX_BF(8);

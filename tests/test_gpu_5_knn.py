@@ -337,10 +337,17 @@ def test_highdim_oracle(ctx, N, d, k):
     through the MFMA candidate sweep for the large clouds and the exact scan for the tiny one."""
     rng = np.random.default_rng(N + d)
     X = rng.standard_normal((N, d)) * rng.uniform(0.5, 2.0, d) + rng.uniform(-1, 1, d)
-    check_against_oracle(ctx, X, k)
-    st = _search_stats(ctx, X, k)
-    if N > 4 * k + 64:  # (a query in the thin tail of the cloud may outgrow its list and take the exact scan)
-        assert st["exact_scans"] <= N // 1000 and k <= st["mean_candidates"] <= st["capacity"], st
+    # the candidate sweep on the fp64 matrix cores, on the fp32 ones (forced; the default picks it when its rounding
+    # margin is small against the bounds - it is, on these clouds), and the default: the selection is exact either way
+    for f32 in (0, 2, 1):
+        ctx.set_option("knn_f32", f32)
+        try:
+            check_against_oracle(ctx, X, k)
+            st = _search_stats(ctx, X, k)
+        finally:
+            ctx.set_option("knn_f32", 1)
+        if N > 4 * k + 64:  # (a query in the thin tail of the cloud may outgrow its list and take the exact scan)
+            assert st["exact_scans"] <= N // 1000 and k <= st["mean_candidates"] <= st["capacity"], (f32, st)
 
 
 def test_highdim_clustered_ties_and_other_metrics(ctx):
@@ -351,6 +358,13 @@ def test_highdim_clustered_ties_and_other_metrics(ctx):
     centres = rng.standard_normal((5, 7)) * 50
     Xc = centres[rng.integers(0, 5, 9000)] + 1e-3 * rng.standard_normal((9000, 7))
     check_against_oracle(ctx, Xc, 8)
+    # (|x|^2 ~ 1e4 against neighbour distances of 1e-3: the default keeps the fp64 sweep here; forcing the fp32 one
+    # admits whole clusters, the lists overflow, the exact scan takes over - slower, never wrong)
+    ctx.set_option("knn_f32", 2)
+    try:
+        check_against_oracle(ctx, Xc, 8)
+    finally:
+        ctx.set_option("knn_f32", 1)
     for metric in ("manhattan", "max_dist"):
         X = rng.standard_normal((4000, 6))
         W, sg, info = engine.knn_graph(X, 7, ctx=ctx, neighbors=True, metric=metric)

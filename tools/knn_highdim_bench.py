@@ -22,6 +22,9 @@ def main():
     for N, d, k, host_rows in ((50000, 9, 8, 50000), (100000, 16, 10, 20000), (100000, 25, 10, 5000),
                                (200000, 8, 10, 50000), (50000, 64, 16, 2000)):
         X = np.random.default_rng(N + d).standard_normal((N, d))
+        ctx.set_option("knn_f32", 0)  # the candidate sweep on the fp64 matrix cores ...
+        _, _, info64 = engine.knn_graph(X, k, ctx=ctx, neighbors=True)
+        ctx.set_option("knn_f32", 1)  # ... and the default: on the fp32 ones where their rounding margin allows
         t0 = time.perf_counter()
         W, sigma, info = engine.knn_graph(X, k, ctx=ctx, neighbors=True)
         t_dev = time.perf_counter() - t0
@@ -32,6 +35,8 @@ def main():
         lib.gspx_knn_destroy(h)
         pairs = float(N) * N
         case = {"N": N, "d": d, "k": k, "device_build_ms": info["build_ms"], "device_total_s_incl_download": t_dev,
+                "device_build_ms_fp64_sweep": info64["build_ms"],
+                "same_result_either_sweep": bool(np.array_equal(info["NN"], info64["NN"]) and np.array_equal(info["D"], info64["D"])),
                 "pair_distances_per_s": pairs / (info["build_ms"] * 1e-3),
                 "mfma_flops_per_s": pairs * 2 * (4 * (4 if d <= 16 else 8 if d <= 32 else 16)) / (info["build_ms"] * 1e-3),
                 "sample": int(st[0]), "capacity": int(st[1]), "mean_candidates": st[2], "exact_scans": int(st[3])}
