@@ -244,6 +244,15 @@ def test_generators_hand_their_device_adjacency_over(ctx):
     # a second Laplacian type on the same graph object: rebuilt from the (now host) matrix
     G.compute_laplacian("normalized")
     assert abs(G.L - orc.laplacian(W, "normalized")).max() < 1e-14
+    # the fp32 engine on the device-resident float64 W (converted there)
+    F = graphs.Sensor(9000, k=6, seed=4, compute_dtype=np.float32)
+    assert F._adj_dev is not None
+    F.estimate_lmax("bounds")
+    sf = np.random.default_rng(1).standard_normal((F.N, 5))
+    yf = filters.Heat(F, 10).filter(sf, order=20)
+    ref = orc.cheby_op(orc.laplacian(F.W), F.lmax, filters.compute_cheby_coeff(filters.Heat(F, 10), m=20),
+                       sf.astype(np.float32).astype(np.float64))
+    assert rel_err(yf, ref) < 1e-4
     # radius graphs, another symmetrisation type (utils.symmetrize 'tril': the lower triangle mirrored)
     X = np.random.default_rng(5).uniform(0, 1, (5000, 2))
     R = graphs.NNGraph(X, NNtype="radius", epsilon=0.03, rescale=False, center=False)
