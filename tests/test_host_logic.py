@@ -272,3 +272,43 @@ def test_expander_like_tells_random_graphs_from_embedded_ones():
     grid = sparse.csr_matrix((np.ones(r.size), (r, c)), shape=(n * n, n * n))
     assert not engine.expander_like(sparse.csr_matrix(grid + grid.T))
     assert not engine.expander_like(sparse.csr_matrix((100, 100)))  # empty / tiny graphs: no opinion
+
+
+def test_graph_keeps_a_device_adjacency_until_w_is_read(monkeypatch):
+    """Host logic of the generator hand-over (graphs.Graph with an engine.DeviceAdjacency; the device calls replaced by
+    stand-ins): the set-up runs on the handle, facts that do not need the matrix (N, edge count, directedness) come
+    from its report, G.W downloads exactly once and releases the handle; a W the device route declines (directed)
+    is downloaded first and takes the ordinary constructor."""
+    W = sparse.csr_matrix(np.array([[0, 1, 2.0], [1, 0, 0], [2, 0, 0]]))
+    downloads = []
+
+    class FakeAdjacency(engine.DeviceAdjacency):
+        def __init__(self, host):
+            self._h, self.ctx, self.shape, self.nnz, self.weights, self._host = None, None, host.shape, host.nnz, np.dtype(np.float64), None
+            self._src = host
+
+        def download(self):
+            downloads.append(1)
+            return self._src
+
+    class FakeDev:
+        ctx = None
+
+        def auto_gather_tiles(self):
+            return {"enabled": False}
+
+    report = {"self_loops": 0, "negative": 0, "reordered": False, "built": True}
+    monkeypatch.setattr(engine.DeviceGraph, "setup_from",
+                        classmethod(lambda cls, adj, lap, dt, coords, order: (FakeDev(), dict(report))))
+    G = graphs.Graph(FakeAdjacency(W))
+    assert G._adj_dev is not None and downloads == [] and G.N == 3 and G.n_edges == 2 and not G.is_directed()
+    assert abs(G.W - W).nnz == 0 and downloads == [1] and G._adj_dev is None
+    assert G.W is G.W and downloads == [1]
+    # declined by the device route: the matrix is fetched and the host route builds the graph
+    monkeypatch.setattr(engine.DeviceGraph, "setup_from", classmethod(lambda cls, *a: (None, dict(report))))
+    built = []
+    monkeypatch.setattr(graphs.Graph, "_setup_on_device", lambda self, adj: False)
+    monkeypatch.setattr(graphs.Graph, "compute_laplacian", lambda self, lap_type="combinatorial": built.append(lap_type))
+    downloads.clear()
+    H = graphs.Graph(FakeAdjacency(W))
+    assert downloads == [1] and H._adj_dev is None and H.n_edges == 2 and built == ["combinatorial"]
