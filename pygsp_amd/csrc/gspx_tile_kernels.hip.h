@@ -92,6 +92,8 @@ template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
 
 // INS: the step adds extra input panels to the row (synthesis by Clenshaw, a.nin > 0) - its own build, so
 // that the analysis path does not carry their registers across the row products
+// (A bound of five waves per SIMD for the 4-lane build - five resident workgroups instead of four - costs 20-50
+// bytes of scratch and 20 % of the fp64 build's speed: measured, dropped.)
 template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false, int NT = 512>
 __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   static_assert(NT == 512 || (NT == 64 * LG && NCOL == 1), "narrow builds: one row per group, one chunk per row");
