@@ -11,6 +11,8 @@ Mirrors (names, argument meaning, shapes, exceptions):
 Only ``method='chebyshev'`` is implemented: it is the accelerated path.  The exact (Fourier)
 method is a different algorithm (dense eigendecomposition) and stays with the reference.
 """
+import functools
+
 import numpy as np
 
 from . import _capi
@@ -46,10 +48,22 @@ def compute_cheby_coeff(f, m=30, N=None, *args, **kwargs):
     which = kwargs.pop("i", 0)
     points = int(N) if N else m + 1
     half = f.G.lmax / 2
+    nodes, table = _quadrature_tables(int(m), points)
+    samples = f._kernels[which](half * nodes + half)
+    return np.array([2.0 / points * np.dot(samples, table[order]) for order in range(m + 1)])
+
+
+@functools.lru_cache(maxsize=64)
+def _quadrature_tables(m, points):
+    """cos(theta_j) and the rows cos(o theta_j), o = 0..m, of the quadrature above: functions of (m, N) alone,
+    so they are kept between calls (two thirds of a call's host time on small graphs went into recomputing
+    them) - the same expressions as before, hence the same bits."""
     grid = np.arange(points)
-    samples = f._kernels[which](half * np.cos(np.pi * (grid + 0.5) / points) + half)
-    return np.array([2.0 / points * np.dot(samples, np.cos(np.pi * order * (grid + 0.5) / points))
-                     for order in range(m + 1)])
+    nodes = np.cos(np.pi * (grid + 0.5) / points)
+    table = np.array([np.cos(np.pi * order * (grid + 0.5) / points) for order in range(m + 1)])
+    nodes.setflags(write=False)
+    table.setflags(write=False)
+    return nodes, table
 
 
 # How a SINGLE filter's polynomial is evaluated on the device (filterbanks and synthesis always
