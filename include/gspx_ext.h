@@ -188,6 +188,13 @@ int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int
  *    then for each filter f: w_new, w_cur, w_old]
  * `plan` must hold (M-1)*(4+3*Nf) doubles.  a1 = a2 = lmax/2 as approximations.py:93-96. */
 int gspx_plan_describe(gspx_ctx* ctx, int Nf, int M, const double* coeffs, double* plan);
+/* Host-only: the signal-column batches (widths[0 .. *n_batches), they add up to Nsig; 0 batches = the one-shot
+ * form) and the host threads per direction the pipelined gspx_cheby_filter would use for a call of N x Nsig
+ * elements of `dtype` with `planes_total` = Nf + 1 panels, under the options "host_pipeline" (mode),
+ * "host_batch", "host_edge", "host_threads". */
+int gspx_host_pipeline_describe(int mode, int64_t host_batch, int64_t host_edge, int64_t host_threads, int dtype,
+                                int64_t N, int64_t Nsig, int planes_total, int64_t* widths, int capacity,
+                                int* n_batches, int* threads);
 
 /* Stage times of the LAST gspx_cheby_filter call on this context (milliseconds): out[0] wall time of the
  * pipelined call, out[1] packing (busiest host thread), out[2] host-to-device DMA (sum over batches), out[3]

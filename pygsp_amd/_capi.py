@@ -109,6 +109,8 @@ SIGNATURES = {
     "gspx_last_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "gspx_last_host_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "gspx_last_host_timeline": (_c.c_int, [_P, _P, _c.c_int, _P]),
+    "gspx_host_pipeline_describe": (_c.c_int, [_c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int64,
+                                               _c.c_int64, _c.c_int, _P, _c.c_int, _P, _P]),
     "gspx_plan_describe": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P]),
     "gspx_lanczos_lmax": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.POINTER(_c.c_double),
                                      _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),

@@ -2613,6 +2613,28 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
   return GSPX_OK;
 }
 
+// host-only: the column batches and thread count the pipelined host-pointer call would use (for schedule tests)
+extern "C" int gspx_host_pipeline_describe(int mode, int64_t host_batch, int64_t host_edge, int64_t host_threads,
+                                           int dtype, int64_t N, int64_t Nsig, int planes_total, int64_t* widths,
+                                           int capacity, int* n_batches, int* threads) {
+  if (!n_batches || N < 0 || Nsig < 0 || planes_total < 1 || (dtype != GSPX_F32 && dtype != GSPX_F64))
+    return set_err(GSPX_ERR_INVALID, "bad argument");
+  Options opt;
+  opt.host_pipeline = mode;
+  opt.host_batch = host_batch;
+  opt.host_edge = host_edge;
+  opt.host_threads = host_threads;
+  std::vector<int64_t> w;
+  int t = 1;
+  host_pipeline_shape(opt, elt_size(dtype), N, Nsig, planes_total, &w, &t);
+  if (w.size() < 2) w.clear();  // (a single batch is the one-shot form)
+  *n_batches = (int)w.size();
+  if (threads) *threads = t;
+  if (widths)
+    for (int i = 0; i < capacity && i < (int)w.size(); ++i) widths[i] = w[(size_t)i];
+  return GSPX_OK;
+}
+
 extern "C" int gspx_last_host_timing(gspx_ctx* ctx, double out[9]) {
   if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null argument");
   for (int i = 0; i < 9; ++i) out[i] = ctx->pipe ? ctx->pipe->timing[i] : 0.0;

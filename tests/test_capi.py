@@ -125,3 +125,38 @@ def test_filterbank_schedule_is_deferred(golden_sensor123):
     plan = engine.plan_describe(c)
     assert plan.shape == (20, 4 + 12)
     assert np.all(plan[:, 2] == 0)  # no in-step flush: all T_k kept, one combine pass at the end
+
+
+def test_host_pipeline_schedules():
+    """The batch schedule of the pipelined host-pointer call (gspx_host_pipeline_describe, host-only): batches add
+    up to the panel, 128-byte rows with half-width first and last batches for large calls, the one-shot form for
+    small ones, no ragged tail under 32-byte rows in the automatic schedule, explicit widths honoured."""
+    import ctypes
+
+    import numpy as np
+    lib = _capi.load()
+
+    def shape(mode, batch, edge, threads, dtype, N, nsig, planes=2):
+        w = np.zeros(256, dtype=np.int64)
+        n, t = ctypes.c_int(0), ctypes.c_int(0)
+        _capi.check(lib.gspx_host_pipeline_describe(mode, batch, edge, threads, dtype, N, nsig, planes, _capi.ptr(w),
+                                                    w.size, ctypes.byref(n), ctypes.byref(t)))
+        return [int(v) for v in w[:n.value]], t.value
+
+    assert shape(1, 0, 0, 0, _capi.F64, 1000000, 64)[0] == [8, 16, 16, 16, 8]      # the headline call
+    assert shape(1, 0, 0, 0, _capi.F32, 1000000, 64)[0] == [16, 16, 16, 16]
+    assert shape(1, 0, 0, 0, _capi.F32, 1000000, 256)[0] == [16] + [32] * 7 + [16]
+    assert shape(1, 0, 0, 0, _capi.F64, 1000000, 4)[0] == []                       # too few columns: one shot
+    assert shape(1, 0, 0, 0, _capi.F64, 20000, 64)[0] == []                        # under 48 MB of panels: one shot
+    assert shape(0, 0, 0, 0, _capi.F64, 1000000, 64)[0] == []                      # switched off
+    assert shape(2, 0, 0, 0, _capi.F64, 1000, 8)[0] == [4, 4]                      # "always": two halves at least
+    assert shape(2, 0, 0, 0, _capi.F64, 1000, 2)[0] == []                          # (halves under 32-byte rows: merged)
+    assert shape(2, 24, 0, 3, _capi.F64, 1000, 56) == ([24, 24, 8], 3)             # explicit width and threads
+    assert shape(2, 16, 4, 0, _capi.F64, 1000, 40)[0] == [4, 16, 16, 4]
+    for dtype, elt in ((_capi.F64, 8), (_capi.F32, 4)):
+        for nsig in range(2, 200):
+            for mode in (1, 2):
+                w, t = shape(mode, 0, 0, 0, dtype, 3000000, nsig, planes=7)
+                assert (not w) or (sum(w) == nsig and len(w) >= 2 and min(w) >= 1 and 1 <= t <= 64), (dtype, nsig, mode, w)
+                if w and nsig * elt >= 64:
+                    assert w[-1] * elt >= 32, (dtype, nsig, mode, w)
