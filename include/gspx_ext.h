@@ -181,6 +181,15 @@ int gspx_graph_download_perm(gspx_graph* g, int32_t* perm);
  * np.identity(N)) produced where it is consumed. */
 int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int64_t w, void* out_dev);
 
+/* A signal cube between its two layouts, on the device (queued on the context's stream): the row-major
+ * (N, S, F) tensor Filter.filter takes and returns (filter.py:146-328: vertices x signals x features) and the F
+ * feature planes [f][n][s] the engine works on (the (Nf N, Nsig) stacking of approximations.py:88,
+ * filter.py:315-316).  to_planes != 0: src is the cube, dst the planes; 0: the other way.  Needed only when a
+ * device-resident array arrives in the other layout than the call reads it in (an (N, Nf) panel of Nf signals
+ * taken as ONE signal with Nf features, filter.py:270-278). */
+int gspx_planes_pack_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t S, int64_t F, const void* src_dev,
+                         void* dst_dev, int to_planes);
+
 /* Host-only: the step schedule the engine would run for (Nf, M) under the ctx's current
  * options, for CPU-side verification of the schedule logic (no device work).  Each of the
  * K = M-1 rows of `plan` is 4 + 3*Nf doubles:

@@ -2850,6 +2850,45 @@ extern "C" int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int6
   return GSPX_OK;
 }
 
+// (vertex, signal, feature) tensor <-> feature planes [feature][vertex][signal]: the two layouts a signal cube
+// has on either side of Filter.filter (filter.py:310-311, 315-316) - for device-resident arrays that arrive in
+// the "wrong" one (an (N, Nf) panel of Nf signals read as one signal with Nf features, filter.py:270-278).
+// One thread per element of the planes side, whose accesses are the coalesced ones; the cube side of a vertex
+// is S * F contiguous elements, so its lines are shared by neighbouring lanes.
+template <typename T>
+__global__ void k_planes_pack(const T* __restrict__ src, T* __restrict__ dst, int64_t N, int S, int F, int to_planes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index in [f][n][s]
+  if (i >= N * S * F) return;
+  const int s = (int)(i % S);
+  const int64_t n = (i / S) % N;
+  const int f = (int)(i / ((int64_t)S * N));
+  const int64_t cube = (n * S + s) * F + f;
+  if (to_planes) dst[i] = src[cube];
+  else dst[cube] = src[i];
+}
+
+extern "C" int gspx_planes_pack_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t S, int64_t F, const void* src_dev,
+                                    void* dst_dev, int to_planes) {
+  if (!ctx || N < 0 || S < 0 || F < 0 || (dtype != GSPX_F32 && dtype != GSPX_F64))
+    return set_err(GSPX_ERR_INVALID, "gspx_planes_pack_dev: bad argument");
+  if (N * S * F == 0) return GSPX_OK;
+  if (!src_dev || !dst_dev || src_dev == dst_dev)
+    return set_err(GSPX_ERR_INVALID, "gspx_planes_pack_dev: null or aliased buffers");
+  if (S >= ((int64_t)1 << 31) || F >= ((int64_t)1 << 31) || N * S * F >= ((int64_t)1 << 40))
+    return set_err(GSPX_ERR_INVALID, "gspx_planes_pack_dev: tensor too large");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t total = N * S * F;
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (dtype == GSPX_F32)
+    hipLaunchKernelGGL((k_planes_pack<float>), dim3(nb), dim3(256), 0, ctx->stream, (const float*)src_dev,
+                       (float*)dst_dev, N, (int)S, (int)F, to_planes);
+  else
+    hipLaunchKernelGGL((k_planes_pack<double>), dim3(nb), dim3(256), 0, ctx->stream, (const double*)src_dev,
+                       (double*)dst_dev, N, (int)S, (int)F, to_planes);
+  HIPCHK(hipGetLastError());
+  return GSPX_OK;
+}
+
 extern "C" int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps) {
   if (!ctx || !gbps || bytes < 4096 || iters < 1)
     return set_err(GSPX_ERR_INVALID, "gspx_bench_copy: bad argument");

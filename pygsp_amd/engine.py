@@ -159,6 +159,117 @@ class DeviceBuffer:
         return out
 
 
+class DeviceArray:
+    """A signal tensor that lives on the device between calls: what ``Filter.filter`` / ``analyze`` /
+    ``synthesize`` return when they are given one, so that a chain of filters (the doctest of filter.py:232-256:
+    heat -> analysis -> synthesis) costs one upload and one download instead of a PCIe round trip per call.
+
+    `shape` is the shape the reference's call would have returned (the squeezed (vertices, signals, features)
+    cube of filter.py:328); the memory is the engine's layout - `n_features` planes [feature][vertex][signal] in
+    the compute dtype, exactly what gspx_cheby_filter_dev reads and writes, so chaining moves nothing.
+    ``np.asarray(a)`` / ``a.numpy()`` download it as the float64 array the reference would have returned."""
+
+    __array_priority__ = 100
+
+    def __init__(self, buf, cube, dtype):
+        self._buf, self.ctx = buf, buf.ctx
+        self.cube = tuple(int(d) for d in cube)  # (vertices, signals, features)
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(d for d in self.cube if d != 1)
+
+    @classmethod
+    def from_host(cls, ctx, array, dtype=np.float64):
+        """Upload a host signal: (N,), (N, Nsig) or (N, Nsig, Nfeat) of any real dtype / memory order."""
+        a = np.asanyarray(array)
+        if np.iscomplexobj(a):
+            raise TypeError("complex signals are not supported by the Chebyshev path")
+        if a.ndim < 1 or a.ndim > 3:
+            raise ValueError("At most 3 dimensions: #nodes x #signals x #features.")
+        cube = a.reshape(a.shape + (1,) * (3 - a.ndim))
+        planes = np.ascontiguousarray(np.moveaxis(cube, 2, 0), dtype=dtype)
+        buf = ctx.alloc(max(planes.nbytes, 16))
+        if planes.nbytes:
+            buf.upload(planes)
+        out = cls(buf, cube.shape, dtype)
+        out.shape = tuple(a.shape)  # as given (not squeezed): the caller's own shape rules apply to it
+        return out
+
+    @classmethod
+    def empty(cls, ctx, cube, dtype):
+        n = int(np.prod(cube)) * np.dtype(dtype).itemsize
+        return cls(ctx.alloc(max(n, 16)), cube, dtype)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.cube))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ptr(self):
+        if self._buf is None:
+            raise ValueError("the device array has been freed")
+        return self._buf.ptr
+
+    def planes(self, signals, features):
+        """Device pointer (+ the object keeping it alive) of this tensor as `features` planes of (N, signals):
+        itself when that is how it is stored, else a repacked copy (gspx_planes_pack_dev) - the per-vertex
+        elements are re-read in row-major order, as ``reshape`` of the host array would."""
+        N, S0, F0 = self.cube
+        if S0 * F0 != signals * features:
+            raise ValueError("cannot view {} signals x {} features as {} x {}".format(S0, F0, signals, features))
+        if (S0, F0) == (signals, features) or self.size == 0:
+            return self.ptr, self
+        lib, code, cur = _capi.load(), _capi.dtype_code(self.dtype), self
+        if F0 != 1:  # planes -> the row-major cube (N, S0 * F0)
+            flat = DeviceArray.empty(self.ctx, (N, S0 * F0, 1), self.dtype)
+            _capi.check(lib.gspx_planes_pack_dev(self.ctx._h, code, N, S0, F0, ctypes.c_void_p(self.ptr),
+                                                 ctypes.c_void_p(flat.ptr), 0))
+            cur = flat
+        if features != 1:  # the cube (N, signals, features) -> planes
+            out = DeviceArray.empty(self.ctx, (N, signals, features), self.dtype)
+            _capi.check(lib.gspx_planes_pack_dev(self.ctx._h, code, N, signals, features, ctypes.c_void_p(cur.ptr),
+                                                 ctypes.c_void_p(out.ptr), 1))
+            cur = out
+        return cur.ptr, cur
+
+    def numpy(self):
+        """The float64 host array the reference would have returned (shape `self.shape`)."""
+        N, S, F = self.cube
+        if self.size == 0:
+            return np.zeros(self.shape)
+        planes = self._buf_download((F, N, S))
+        return np.asarray(np.moveaxis(planes, 0, 2), dtype=np.float64).reshape(self.shape)
+
+    def _buf_download(self, shape):
+        if self._buf is None:
+            raise ValueError("the device array has been freed")
+        return self._buf.download(shape, self.dtype)
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.numpy()
+        return out if dtype is None else out.astype(dtype, copy=False)
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError("len() of unsized object")
+        return self.shape[0]
+
+    def __repr__(self):
+        return "DeviceArray(shape={}, dtype={}, device={})".format(self.shape, self.dtype, self.ctx.device)
+
+    def free(self):
+        if self._buf is not None:
+            self._buf.free()
+            self._buf = None
+
+
 def gather(parts, root_out):
     """Concatenate device buffers living on (possibly) different contexts / GPUs into `root_out`:
     the single-process form of the path's one collective (gspx_gather; peer copies over xGMI)."""

@@ -262,6 +262,106 @@ def _record_timing(G, ms):
         pass
 
 
+def _shape_of(s):
+    """Shape of a signal argument without touching its data (a DeviceArray would be downloaded by np.shape)."""
+    shape = getattr(s, "shape", None)
+    return tuple(shape) if isinstance(shape, tuple) else np.shape(s)
+
+
+def _cube_shape(G, Nf, shape):
+    """The shape rules of Filter.filter (filter.py:267-290) applied to a signal's SHAPE alone: returns
+    (vertices, signals, input features).  A trailing axis of length 1 or Nf is the feature axis; Nf (> 1) input
+    features mean synthesis.  Same checks, same messages, same order as the reference."""
+    shape = tuple(shape)
+    if len(shape) == 0 or shape[0] != G.N:  # graph.py:632-640
+        raise ValueError("First dimension must be the number of vertices "
+                         "G.N = {}, got {}.".format(G.N, shape))
+    if len(shape) == 1 or shape[-1] not in (1, Nf):
+        if len(shape) == 3:
+            raise ValueError("Third dimension (#features) should be either 1 or the number "
+                             "of filters Nf = {}, got {}.".format(Nf, shape))
+        shape = shape + (1,)
+    if len(shape) < 3:
+        shape = (shape[0], 1, shape[-1])
+    if len(shape) > 3:
+        raise ValueError("At most 3 dimensions: #nodes x #signals x #features.")
+    return shape
+
+
+def filter_signals(bank, s, method="chebyshev", order=30, devices=None, coefficients=None):
+    """``Filter.filter`` (filter.py:146-328) for any object with the reference's Filter attributes (``G``, ``Nf``,
+    what `coefficients` reads): the mirror class below and - through plugin.install(wrap_filter=True) - the real
+    pygsp.filters.Filter.  `coefficients(bank, m=order)`: compute_cheby_coeff of whichever package `bank`
+    comes from.
+
+    analysis:  one device call, output planes [filter][vertex][signal] viewed as (vertex, signal, filter);
+    synthesis: ONE device call (vector-coefficient Clenshaw: K products) where the reference loops over the
+               filters (filter.py:318-321: Nf x cheby_op = K Nf products and Nf host round trips);
+    a DeviceArray in gives a DeviceArray out (nothing crosses PCIe)."""
+    from . import engine
+    coefficients = coefficients or compute_cheby_coeff
+    on_device = isinstance(s, engine.DeviceArray)
+    if on_device:
+        cube_shape = _cube_shape(bank.G, bank.Nf, s.shape)
+    else:
+        s = bank.G._check_signal(s)
+        cube_shape = _cube_shape(bank.G, bank.Nf, s.shape)
+    synthesis = cube_shape[2] != 1
+    if method == "exact":
+        raise NotImplementedError(
+            "method='exact' (dense Fourier filtering, filter.py:292-301) is outside the "
+            "accelerated path; use the reference implementation for it.")
+    if method != "chebyshev":
+        raise ValueError("Unknown method {}.".format(method))
+    coeffs = coefficients(bank, m=order)
+    if on_device:
+        return _filter_device_array(bank, s, cube_shape, _as_coeff_matrix(coeffs), devices)
+    cube = s.reshape(cube_shape)
+    if not synthesis:
+        # device buffer [filter][vertex][signal] -> (vertex, signal, filter), as filter.py:310-311
+        flat = cheby_op(bank.G, coeffs, cube[:, :, 0], devices=devices)
+        out = np.moveaxis(flat.reshape(bank.Nf, bank.G.N, cube.shape[1]), 0, 2)
+    else:
+        # out = sum_f p_f(L) s[:, :, f]  (filter.py:313-322), one device call
+        if np.iscomplexobj(cube):
+            raise TypeError("complex signals are not supported by the Chebyshev path")
+        planes = np.ascontiguousarray(np.moveaxis(cube, 2, 0))
+        split = _device_list(bank.G, devices)
+        if split is not None and planes.shape[2] > 0:
+            from . import multi
+            y, ms = multi.filter_columns(bank.G, _as_coeff_matrix(coeffs), planes, split, _capi.SYNTHESIS)
+        else:
+            y, ms = _device_graph_of(bank.G).cheby_filter(_as_coeff_matrix(coeffs), planes, bank.G.lmax,
+                                                          _capi.SYNTHESIS)
+        _record_timing(bank.G, ms)
+        out = np.asarray(y, dtype=np.float64)
+    return np.squeeze(out)
+
+
+def _filter_device_array(bank, s, cube_shape, coeffs, devices):
+    """The device-resident form of filter_signals: `s` (engine.DeviceArray) is read as `cube_shape`, filtered
+    where it lies and returned as a new DeviceArray whose `shape` is what the reference would have returned."""
+    from . import engine
+    if _device_list(bank.G, devices) is not None:
+        raise ValueError("a DeviceArray lives on one GPU: it cannot be combined with a device list")
+    dev = _device_graph_of(bank.G)
+    if not hasattr(dev, "cheby_filter_dev") or s.ctx is not dev.ctx:
+        raise ValueError("the DeviceArray does not live on the context of this graph's device Laplacian")
+    if s.dtype != dev.dtype:
+        raise ValueError("the DeviceArray holds {} but the graph computes in {}".format(s.dtype, dev.dtype))
+    N, nsig, nfeat = cube_shape
+    synthesis = nfeat != 1
+    x_ptr, keep = s.planes(nsig, nfeat)
+    out = engine.DeviceArray.empty(dev.ctx, (N, nsig, 1 if synthesis else bank.Nf), dev.dtype)
+    ms = 0.0
+    if N * nsig:
+        ms = dev.cheby_filter_dev(coeffs, x_ptr, out.ptr, nsig, bank.G.lmax,
+                                  _capi.SYNTHESIS if synthesis else _capi.ANALYSIS)
+    del keep
+    _record_timing(bank.G, ms)
+    return out
+
+
 class Filter:
     """A bank of kernels g_i(lambda) on a graph, applied by Chebyshev filtering on the device.
 
@@ -310,67 +410,27 @@ class Filter:
         at = np.asanyarray(x)
         return np.stack([np.broadcast_to(g(at), at.shape) for g in self._kernels]).astype(np.float64)
 
-    # ---- shape algebra of Filter.filter (filter.py:267-290) -------------------------------------------
-    def _as_three_axes(self, s):
-        """`s` as (vertices, signals, input features) plus whether the call is a synthesis.  A trailing
-        axis of length 1 or Nf is the feature axis; Nf (> 1) input features mean synthesis."""
-        s = self.G._check_signal(s)
-        feature_axis = s.ndim > 1 and s.shape[-1] in (1, self.Nf)
-        if not feature_axis:
-            if s.ndim == 3:
-                raise ValueError("Third dimension (#features) should be either 1 or the number "
-                                 "of filters Nf = {}, got {}.".format(self.Nf, s.shape))
-            s = s[..., np.newaxis]
-        if s.ndim == 2:
-            s = s[:, np.newaxis, :]
-        if s.ndim != 3:
-            raise ValueError("At most 3 dimensions: #nodes x #signals x #features.")
-        return s, s.shape[2] != 1
-
     def filter(self, s, method="chebyshev", order=30, devices=None):
         """Filter signals (analysis or synthesis), filter.py:146-328.
 
         Shapes follow the reference exactly: `s` is (N,), (N, Nsig) or (N, Nsig, Nfeat) with
         Nfeat in {1, Nf}; a trailing dimension equal to Nf means synthesis.  The result is
-        squeezed.  `devices` (this engine's addition): a list of GPU ids to split the signal columns over.
+        squeezed.  This engine's additions: `devices`, a list of GPU ids to split the signal columns over;
+        `s` may be an engine.DeviceArray (G.to_device(x)), and then so is the result (see filter_signals).
         """
-        cube, synthesis = self._as_three_axes(s)
-        if method == "exact":
-            raise NotImplementedError(
-                "method='exact' (dense Fourier filtering, filter.py:292-301) is outside the "
-                "accelerated path; use the reference implementation for it.")
-        if method != "chebyshev":
-            raise ValueError("Unknown method {}.".format(method))
-        coeffs = compute_cheby_coeff(self, m=order)
-        if not synthesis:
-            # device buffer [filter][vertex][signal] -> (vertex, signal, filter), as filter.py:310-311
-            flat = cheby_op(self.G, coeffs, cube[:, :, 0], devices=devices)
-            out = np.moveaxis(flat.reshape(self.Nf, self.G.N, cube.shape[1]), 0, 2)
-        else:
-            # out = sum_f p_f(L) s[:, :, f]  (filter.py:313-322), one device call
-            if np.iscomplexobj(cube):
-                raise TypeError("complex signals are not supported by the Chebyshev path")
-            planes = np.ascontiguousarray(np.moveaxis(cube, 2, 0))
-            split = _device_list(self.G, devices)
-            if split is not None and planes.shape[2] > 0:
-                from . import multi
-                y, ms = multi.filter_columns(self.G, _as_coeff_matrix(coeffs), planes, split, _capi.SYNTHESIS)
-            else:
-                y, ms = _device_graph_of(self.G).cheby_filter(_as_coeff_matrix(coeffs), planes, self.G.lmax,
-                                                              _capi.SYNTHESIS)
-            _record_timing(self.G, ms)
-            out = np.asarray(y, dtype=np.float64)
-        return np.squeeze(out)
+        return filter_signals(self, s, method, order, devices)
 
     def analyze(self, s, method="chebyshev", order=30, devices=None):
-        if np.ndim(s) == 3 and np.shape(s)[-1] != 1:
-            raise ValueError("Last dimension (#features) should be 1, got {}.".format(np.shape(s)))
+        shape = _shape_of(s)
+        if len(shape) == 3 and shape[-1] != 1:
+            raise ValueError("Last dimension (#features) should be 1, got {}.".format(shape))
         return self.filter(s, method, order, devices=devices)
 
     def synthesize(self, s, method="chebyshev", order=30, devices=None):
-        if np.shape(s)[-1] != self.Nf:
+        shape = _shape_of(s)
+        if shape[-1] != self.Nf:
             raise ValueError("Last dimension (#features) should be the number of filters "
-                             "Nf = {}, got {}.".format(self.Nf, np.shape(s)))
+                             "Nf = {}, got {}.".format(self.Nf, shape))
         return self.filter(s, method, order, devices=devices)
 
     def localize(self, i, **kwargs):
@@ -382,24 +442,26 @@ class Filter:
     def compute_frame(self, **kwargs):
         """The (Nf*N, N) matrix whose rows are the localised kernels (filter.py:506-600): the bank applied
         to every delta, i.e. to the identity - N signals, produced on the device panel by panel
-        (no N x N identity is ever held or shipped; see _frame_panels)."""
+        (no N x N identity is ever held or shipped; see frame_panels)."""
         method, order = kwargs.pop("method", "chebyshev"), kwargs.pop("order", 30)
         if kwargs:
             raise TypeError("unexpected arguments {}".format(sorted(kwargs)))
         if method != "chebyshev":
             return self.filter(np.identity(self.G.N), method=method, order=order).T.reshape(-1, self.G.N)
-        return _frame_panels(self, order)
+        return frame_panels(self, order)
 
 
-def _frame_panels(bank, order, panel=1024):
-    """compute_frame without the dense identity: column j of block f of the frame is p_f(L) delta_j.
-    Columns [j0, j0 + w) of the identity are written on the device (gspx_identity_panel_dev), filtered
-    there in one call per panel, and only the result crosses PCIe - no N x N identity is built or
-    shipped.  `panel` signals per call keep the workspace bounded (w = N would need K+1 panels of N x N)."""
+def frame_panels(bank, order=30, panel=1024, coefficients=None):
+    """compute_frame without the dense identity.  The reference filters np.identity(N) and returns
+    ``filter(I).T.reshape(-1, N)`` (filter.py:599-600): row f N + j of the frame is p_f(L) delta_j.  Here columns
+    [j0, j0 + w) of the identity are written on the device (gspx_identity_panel_dev), filtered there in one call
+    per panel, and only the result crosses PCIe - no N x N identity is built or shipped.  `panel` signals per
+    call keep the workspace bounded (w = N would need K+1 panels of N x N).  `bank`: the mirror Filter or the
+    real pygsp one (plugin.install(wrap_filter=True)), `coefficients` its compute_cheby_coeff."""
     G, Nf = bank.G, bank.Nf
-    coeffs = _as_coeff_matrix(compute_cheby_coeff(bank, m=order))
+    coeffs = _as_coeff_matrix((coefficients or compute_cheby_coeff)(bank, m=order))
     dev = _device_graph_of(G)
-    frame = np.empty((Nf, G.N, G.N))
+    frame = np.empty((Nf, G.N, G.N))  # [filter][delta j][vertex]
     total_ms = 0.0
     on_device = hasattr(dev, "ctx") and hasattr(dev, "cheby_filter_dev")
     if on_device:
@@ -418,7 +480,7 @@ def _frame_panels(bank, order, panel=1024):
                 deltas[j0 + np.arange(w), np.arange(w)] = 1
                 y, ms = dev.cheby_filter(coeffs, deltas, G.lmax, _capi.ANALYSIS)
                 total_ms += ms
-            frame[:, :, j0:j0 + w] = y
+            frame[:, j0:j0 + w, :] = np.swapaxes(y, 1, 2)
     finally:
         if on_device:
             bx.free()

@@ -285,6 +285,13 @@ class Graph:
                              "G.N = {}, got {}.".format(self.N, arr.shape))
         return arr
 
+    def to_device(self, s, dtype=None):
+        """Upload a signal ((N,), (N, Nsig) or (N, Nsig, Nfeat)) once and keep it on this graph's device: an
+        engine.DeviceArray that Filter.filter / analyze / synthesize take and return, so that a chain of filters
+        costs one upload and one download (np.asarray(result))."""
+        arr = self._check_signal(s)
+        return engine.DeviceArray.from_host(self.context, arr, np.dtype(dtype or self.compute_dtype))
+
     # ---- operators on the device CSR (SURVEY 8(f) row 3) ----------------------------------------
     def dirichlet_energy(self, x):
         """x^T L x (graph.py:642-702), computed on the device: one sparse product and one reduction."""

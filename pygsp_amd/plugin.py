@@ -33,7 +33,7 @@ def _finite_coords(G):
     return coords
 
 
-def device_graph_for(G, ctx=None):
+def device_graph_for(G, ctx=None, dtype=None):
     """libgspx graph attached to a reference ``pygsp.graphs.Graph``: cached on the object next to the
     very ``G.L`` (and ``G.W``) it was built from, and rebuilt when ``G.compute_laplacian`` replaced
     them, mirroring graph.py:602-609.  The cache entry holds the matrices themselves and compares with
@@ -42,12 +42,13 @@ def device_graph_for(G, ctx=None):
     A stale entry is dropped, not destroyed: whoever still holds the old DeviceGraph (another thread in the
     middle of a filter call, a caller that kept the return value) keeps a live handle, and the device memory
     goes when the last reference does (DeviceGraph.__del__)."""
-    conf = (G.lap_type, np.dtype(_config["dtype"]).str, _config["laplacian"], _config["reorder"],
-            bool(_config.get("tiles", "auto")))
+    dtype = np.dtype(dtype or _config["dtype"])
+    conf = (G.lap_type, dtype.str, _config["laplacian"], _config["reorder"], bool(_config.get("tiles", "auto")))
     ctx = ctx or engine.default_context(_config["device"])
+    key = (id(ctx), dtype.str)
     with _cache_lock:
         cache = G.__dict__.setdefault("_gspx_dev", {})
-        cached = cache.get(id(ctx))
+        cached = cache.get(key)
         if (cached is not None and cached[0] is G.L and cached[1] is G.W and cached[2] == conf
                 and cached[4] is ctx and getattr(cached[3], "_h", None)):
             return cached[3]
@@ -62,7 +63,7 @@ def device_graph_for(G, ctx=None):
             # checks, directedness, vertex order and Laplacian in one device call on the uploaded G.W
             # (gspx_graph_setup); a directed graph / explicit zeros come back as None and take the route below
             try:
-                dev, _ = engine.DeviceGraph.setup(G.W, G.lap_type, _config["dtype"], coords, order, ctx=ctx)
+                dev, _ = engine.DeviceGraph.setup(G.W, G.lap_type, dtype, coords, order, ctx=ctx)
             except ValueError:
                 dev = None
         if dev is None:
@@ -73,12 +74,12 @@ def device_graph_for(G, ctx=None):
                 perm = engine.locality_order(G.W, None)
             if _config["laplacian"] == "device":
                 W = G.W if not G.is_directed() else sparse.csr_matrix((G.W + G.W.T) / 2)
-                dev = engine.DeviceGraph.from_w(W, G.lap_type, dtype=_config["dtype"], perm=perm, ctx=ctx)
+                dev = engine.DeviceGraph.from_w(W, G.lap_type, dtype=dtype, perm=perm, ctx=ctx)
             else:  # bit-parity mode: upload the Laplacian the reference built
-                dev = engine.DeviceGraph.from_l(G.L, dtype=_config["dtype"], perm=perm, ctx=ctx)
+                dev = engine.DeviceGraph.from_l(G.L, dtype=dtype, perm=perm, ctx=ctx)
         if _config.get("tiles", "auto"):
             dev.auto_gather_tiles()
-        cache[id(ctx)] = (G.L, G.W, conf, dev, ctx)
+        cache[key] = (G.L, G.W, conf, dev, ctx)
         return dev
 
 
@@ -92,20 +93,76 @@ def _estimate_lmax_on_device(self, method="lanczos"):
         return _saved["estimate_lmax"](self, method)
     if method == self._lmax_method:
         return
-    ritz, _ = device_graph_for(self).lanczos_lmax(max_iter=80, tol=5e-4)
-    assert ritz <= self._get_upper_bound() * (1 + 1e-6) + 1e-12
+    ritz = _lanczos_ritz(device_graph_for(self, dtype=np.float64))
+    if not ritz <= self._get_upper_bound() * (1 + 1e-6) + 1e-12:  # graph.py:919 (an assert there)
+        raise ValueError("The Lanczos estimate {} exceeds the upper bound of lambda_max.".format(ritz))
     self._lmax_method = method
     self._lmax = ritz * 1.01
 
 
+def _lanczos_ritz(dev):
+    """Largest Ritz value of the float64 device Laplacian; a second, longer run before giving up (the
+    reference's ARPACK call stops at tol 5e-3, graph.py:911-917: where it succeeds this must not fail)."""
+    try:
+        return dev.lanczos_lmax(max_iter=80, tol=5e-4)[0]
+    except ValueError:
+        return dev.lanczos_lmax(max_iter=400, tol=5e-3)[0]
+
+
+def to_device(G, s):
+    """Upload a signal of a reference ``pygsp.graphs.Graph`` once and keep it on the device (engine.DeviceArray):
+    with install(wrap_filter=True) the real ``Filter.filter`` / ``analyze`` / ``synthesize`` take it and return
+    one, so a chain of filters costs one upload and one download (``np.asarray(result)``)."""
+    arr = G._check_signal(s)
+    dev = device_graph_for(G)
+    return engine.DeviceArray.from_host(dev.ctx, arr, dev.dtype)
+
+
+def _reference_coefficients(bank, m):
+    # the coefficients of the patched package itself (approximations.py:9-55): its own code, its own kernels
+    return _saved["module"].filters.approximations.compute_cheby_coeff(bank, m=m)
+
+
+def _filter_on_device(self, s, method="chebyshev", order=30):
+    """``pygsp.filters.Filter.filter`` (filter.py:146-328) with its Chebyshev branch in one device call: the shape
+    rules are the reference's (filters._cube_shape restates filter.py:267-290), analysis is the call the
+    reference makes, synthesis is ONE vector-coefficient recurrence on the device instead of the loop of
+    filter.py:318-321 (Nf cheby_op calls, each with its own host round trip), and a DeviceArray stays on the
+    device.  Everything else (method='exact', unknown methods) is the reference's own code."""
+    if method != "chebyshev":
+        return _saved["filter"](self, s, method=method, order=order)
+    return _filters.filter_signals(self, s, method, order, None, _reference_coefficients)
+
+
+def _compute_frame_on_device(self, **kwargs):
+    """``Filter.compute_frame`` (filter.py:506-600) without its N x N host identity: the deltas are written on
+    the device panel by panel (filters.frame_panels); same (Nf N, N) result.  Other methods, and graphs whose
+    size collides with the shape rules (N in {1, Nf}: the identity then reads as a synthesis input,
+    filter.py:270), run the reference's own code."""
+    extra = set(kwargs) - {"method", "order"}
+    if kwargs.get("method", "chebyshev") != "chebyshev" or extra or self.G.N in (1, self.Nf):
+        return _saved["compute_frame"](self, **kwargs)
+    if self.G.N > 2000:  # filter.py:593-596
+        _filters_logger(self).warning("Creating a big matrix. You should prefer the filter method.")
+    return _filters.frame_panels(self, kwargs.get("order", 30), coefficients=_reference_coefficients)
+
+
+def _filters_logger(bank):
+    import logging
+    return logging.getLogger(type(bank).__module__)
+
+
 def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, reorder="auto",
-            tiles="auto", devices=None, lmax="reference"):
+            tiles="auto", devices=None, lmax="reference", wrap_filter=True):
     """Patch the real pygsp in place.  `laplacian`: 'device' (L assembled by HIP kernels from
     G.W) or 'host' (upload the reference's G.L).  `devices` (a list of GPU ids, optional): every
     ``Filter.filter(method='chebyshev')`` splits its signal columns over these GPUs - the graph is replicated
     once per GPU, the outputs are gathered by RCCL inside libgspx (pygsp_amd.multi.filter_columns).
     `lmax`: 'device' also replaces ``Graph.estimate_lmax`` so that its default 'lanczos' method runs on the device
-    (the step right before the path); 'reference' (default) leaves ARPACK in place."""
+    (the step right before the path); 'reference' (default) leaves ARPACK in place.
+    `wrap_filter` (default True; the secondary seam of SURVEY 8(b)): also replace ``Filter.filter`` and
+    ``Filter.compute_frame`` (filter.py:146, 506) - fused synthesis, device-built identity panels,
+    device-resident arrays; False patches ``cheby_op`` alone, and the reference's own loops call it."""
     if laplacian not in ("device", "host"):
         raise ValueError("laplacian must be 'device' or 'host'")
     if lmax not in ("device", "reference"):
@@ -123,8 +180,17 @@ def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, r
     if "cheby_op" not in _saved:
         _saved["cheby_op"] = approx.cheby_op
         _saved["alias"] = getattr(pygsp_module.filters, "cheby_op", None)
+    _saved["module"] = pygsp_module
     approx.cheby_op = _filters.cheby_op
     pygsp_module.filters.cheby_op = _filters.cheby_op
+    filter_cls = getattr(pygsp_module.filters, "Filter", None)
+    can_wrap = filter_cls is not None and hasattr(approx, "compute_cheby_coeff")
+    if wrap_filter and can_wrap:
+        if "filter" not in _saved:
+            _saved["filter"], _saved["compute_frame"] = filter_cls.filter, filter_cls.compute_frame
+        filter_cls.filter, filter_cls.compute_frame = _filter_on_device, _compute_frame_on_device
+    elif "filter" in _saved and filter_cls is not None:
+        filter_cls.filter, filter_cls.compute_frame = _saved.pop("filter"), _saved.pop("compute_frame")
     graph_cls = getattr(getattr(pygsp_module, "graphs", None), "Graph", None)
     if lmax == "device" and graph_cls is not None:
         if "estimate_lmax" not in _saved:
@@ -144,6 +210,10 @@ def uninstall(pygsp_module=None):
     alias = _saved.pop("alias")
     if alias is not None:
         pygsp_module.filters.cheby_op = alias
+    _saved.pop("module", None)
+    filter_cls = getattr(pygsp_module.filters, "Filter", None)
+    if "filter" in _saved and filter_cls is not None:
+        filter_cls.filter, filter_cls.compute_frame = _saved.pop("filter"), _saved.pop("compute_frame")
     graph_cls = getattr(getattr(pygsp_module, "graphs", None), "Graph", None)
     if "estimate_lmax" in _saved and graph_cls is not None:
         graph_cls.estimate_lmax = _saved.pop("estimate_lmax")

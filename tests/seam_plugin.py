@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-CALLS = {"cheby_op": 0, "graphs": 0}
+CALLS = {"cheby_op": 0, "graphs": 0, "synthesis_device_calls": 0, "synthesis_filters": 0, "frames": 0}
 
 
 class OracleDevice:
@@ -35,6 +35,7 @@ class OracleDevice:
         c = np.atleast_2d(np.asarray(coeffs, dtype=np.float64))
         x = np.ascontiguousarray(x, dtype=np.float64)
         CALLS["cheby_op"] += 1
+        CALLS["synthesis_device_calls"] += int(mode == 1)
         if mode == 0:
             return orc.cheby_op(self.L, lmax, c, x).reshape(c.shape[0], self.N, -1), 0.0
         return sum(orc.cheby_op(self.L, lmax, c[f], x[f]) for f in range(c.shape[0])), 0.0
@@ -42,9 +43,9 @@ class OracleDevice:
 
 def pytest_configure(config):
     import pygsp
-    from pygsp_amd import plugin
+    from pygsp_amd import filters as product_filters, plugin
 
-    def device_graph_for(G):
+    def device_graph_for(G, ctx=None, dtype=None):
         cached = getattr(G, "_gspx_dev", None)
         if cached is not None and cached[0] is G.L:
             return cached[1]
@@ -53,9 +54,29 @@ def pytest_configure(config):
         return dev
 
     plugin.device_graph_for = device_graph_for
-    plugin.install(pygsp)
+    wrap = os.environ.get("GSPX_SEAM_WRAP_FILTER", "1") != "0"
+    plugin.install(pygsp, wrap_filter=wrap)
     assert pygsp.filters.approximations.cheby_op is pygsp.filters.cheby_op
     assert pygsp.filters.cheby_op.__module__ == "pygsp_amd.filters"
+    assert (pygsp.filters.Filter.filter.__module__ == "pygsp_amd.plugin") == wrap
+    assert (pygsp.filters.Filter.compute_frame.__module__ == "pygsp_amd.plugin") == wrap
+
+    # count the Chebyshev synthesis calls and frames that go through Filter.filter / compute_frame
+    patched_filter, patched_frame = pygsp.filters.Filter.filter, pygsp.filters.Filter.compute_frame
+
+    def counting_filter(self, s, method="chebyshev", order=30):
+        if method == "chebyshev":
+            try:
+                CALLS["synthesis_filters"] += int(product_filters._cube_shape(self.G, self.Nf, np.shape(s))[2] != 1)
+            except ValueError:
+                pass
+        return patched_filter(self, s, method=method, order=order)
+
+    def counting_frame(self, **kwargs):
+        CALLS["frames"] += int(kwargs.get("method", "chebyshev") == "chebyshev")
+        return patched_frame(self, **kwargs)
+
+    pygsp.filters.Filter.filter, pygsp.filters.Filter.compute_frame = counting_filter, counting_frame
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -19,9 +19,10 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pygsp", "te
                                 reason="needs the reference checkout at /root/reference")
 
 
-def _run_reference_tests(tmp_path, test_file):
+def _run_reference_tests(tmp_path, test_file, wrap_filter=True):
     report = tmp_path / "seam.json"
     env = dict(os.environ)
+    env["GSPX_SEAM_WRAP_FILTER"] = "1" if wrap_filter else "0"
     env["PYTHONPATH"] = os.pathsep.join([REF, ROOT, os.path.join(ROOT, "tests")])
     env["PYTHONDONTWRITEBYTECODE"] = "1"  # nothing is written under /root/reference
     env["GSPX_SEAM_REPORT"] = str(report)
@@ -43,6 +44,18 @@ def test_reference_test_filters_passes_through_the_patched_seam(tmp_path):
     assert n_passed >= 25, tail
     # ... and the Chebyshev calls really went through the product's cheby_op
     assert calls.get("cheby_op", 0) >= 50 and calls.get("graphs", 0) >= 1, calls
+    # the secondary seam (filter.py:313-322): every Chebyshev synthesis was ONE device call, not Nf cheby_op calls
+    assert calls["synthesis_filters"] >= 5 and calls["synthesis_device_calls"] == calls["synthesis_filters"], calls
+    assert calls["frames"] >= 1, calls
+
+
+def test_reference_test_filters_passes_with_the_primary_seam_alone(tmp_path):
+    """install(wrap_filter=False): cheby_op is the only patched name; the reference's own synthesis loop
+    (filter.py:318-321) then calls it once per filter and no fused synthesis call is made."""
+    res, calls = _run_reference_tests(tmp_path, "test_filters.py", wrap_filter=False)
+    tail = res.stdout[-3000:] + res.stderr[-2000:]
+    assert res.returncode == 0 and " passed" in res.stdout and "failed" not in res.stdout, tail
+    assert calls.get("cheby_op", 0) >= 50 and calls["synthesis_device_calls"] == 0 and calls["synthesis_filters"] >= 5, calls
 
 
 def test_reference_doctest_value_through_the_seam(tmp_path):
