@@ -810,6 +810,7 @@ def main_threads(a):
             "evaluation": "recurrence", "engine_options": a.opt, "gather_tiles": r0.G.tile_stats},
         "launcher": "one process, one driver thread + one libgspx context per GPU (no torch)",
         "devices": devices,
+        "driver_thread_cores": [len(p) if p else None for p in group.pinned],  # NUMA pinning (multi.pin_thread_near)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_step_tile" if tiled else "k_step_panel / k_step_lds",
@@ -866,7 +867,7 @@ def main():
             cpu_all = {"error": repr(e)}
 
     from pygsp_amd import engine, graphs
-    from pygsp_amd import dist as gdist
+    from tools import torchrun_plumbing as gdist  # launcher plumbing (torch only when WORLD_SIZE > 1)
 
     if a.no_headline:  # profiling passes of single configs
         ctx0 = engine.default_context(local)

@@ -181,6 +181,11 @@ int gspx_graph_download_perm(gspx_graph* g, int32_t* perm);
  * np.identity(N)) produced where it is consumed. */
 int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int64_t w, void* out_dev);
 
+/* PCI address ("0000:c1:00.0", NUL-terminated) of HIP device `device`: what a host driver needs to find the NUMA
+ * node the GPU hangs off (/sys/bus/pci/devices/<address>/numa_node) and pin the thread - and the packing threads
+ * libgspx starts from it - that feeds this GPU to the cores next to it (pygsp_amd.multi). */
+int gspx_device_pci_bus_id(int device, char* out, int capacity);
+
 /* A signal cube between its two layouts, on the device (queued on the context's stream): the row-major
  * (N, S, F) tensor Filter.filter takes and returns (filter.py:146-328: vertices x signals x features) and the F
  * feature planes [f][n][s] the engine works on (the (Nf N, Nsig) stacking of approximations.py:88,

@@ -456,6 +456,19 @@ extern "C" int gspx_device_count(int* n) {
   return GSPX_OK;
 }
 
+extern "C" int gspx_device_pci_bus_id(int device, char* out, int capacity) {
+  if (!out || capacity < 16) return set_err(GSPX_ERR_INVALID, "gspx_device_pci_bus_id: need a buffer of >= 16 chars");
+  out[0] = 0;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(GSPX_ERR_NODEVICE, "no HIP device visible (libgspx has no CPU fallback)");
+  }
+  if (device < 0 || device >= c) return set_err(GSPX_ERR_INVALID, "device %d of %d", device, c);
+  HIPCHK(hipDeviceGetPCIBusId(out, capacity, device));
+  return GSPX_OK;
+}
+
 extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
   if (!out) return set_err(GSPX_ERR_INVALID, "gspx_ctx_create: null output");
   *out = nullptr;
@@ -2600,7 +2613,10 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
       if (rc != GSPX_HOSTPIPE_UNAVAILABLE) return rc;
       // an in-place call, or no pinned / device staging memory to be had: the one-shot form below
     }
-    if (ctx->pipe) ctx->pipe->timing[6] = 0;  // the last host call was not pipelined
+    if (ctx->pipe) {  // the last host call was not pipelined: no stage times, no timeline of an earlier call
+      ctx->pipe->timing[6] = 0;
+      ctx->pipe->timeline.clear();
+    }
   }
   CHK(ctx->io_x.ensure(n_in * e));
   CHK(ctx->io_y.ensure(n_out * e));

@@ -1620,9 +1620,9 @@ template <typename T> __global__ void k_fill(T* p, size_t n, T v) {
 // exclusive scan of int32 (three small kernels; tile = 1024 elements)
 // ---------------------------------------------------------------------------------------------
 #define GSPX_SCAN_TILE 1024
-__global__ __launch_bounds__(256) void k_scan_tiles(const int* __restrict__ in, int n,
-                                                    int* __restrict__ out,
-                                                    int* __restrict__ tile_sums) {
+// (in and out may be the same array - radix_argsort scans its histogram in place: every thread reads its four
+// inputs before it writes its four outputs, and no thread touches another's - so neither is __restrict__)
+__global__ __launch_bounds__(256) void k_scan_tiles(const int* in, int n, int* out, int* __restrict__ tile_sums) {
   __shared__ int wsum[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int base = blockIdx.x * GSPX_SCAN_TILE + t * 4;

@@ -598,6 +598,16 @@ static int radius_candidates(gspx_ctx* ctx, const double* x, int N, int d, doubl
 #undef GSPX_BF
   };
   sweep(nullptr, nullptr);  // count only
+  {  // the total in 64 bits BEFORE the 32-bit scan: a sum beyond 2^32 would wrap back to a plausible positive value
+    std::vector<int> hc((size_t)N);
+    HIPCHK(hipMemcpyAsync(hc.data(), cnt.p, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int64_t total64 = 0;
+    for (int v : hc) total64 += v;
+    if (total64 >= ((int64_t)1 << 31))
+      return set_err(GSPX_ERR_INVALID, "gspx_radius_build: %lld candidate pairs, more than 2^31 (epsilon too large)",
+                     (long long)total64);
+  }
   CHK(scan_exclusive(ctx, cnt.as<int>(), off.as<int>(), N + 1));
   int total_c = 0;
   HIPCHK(hipMemcpyAsync(&total_c, off.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -177,6 +177,11 @@ def cheby_op(G, c, signal, **kwargs):
     if evaluation not in ("recurrence", "newton"):
         raise ValueError("evaluation must be 'recurrence' or 'newton'")
     devices = _device_list(G, kwargs.get("devices"))
+    if devices is not None and evaluation == "newton":
+        # (the column split runs the three-term recurrence on every GPU: the same call must not return
+        # different bits with and without a device list)
+        raise ValueError("evaluation='newton' is a single-device evaluation; it cannot be combined with a device "
+                         "list (devices=[...] / plugin.install(devices=[...]))")
     if devices is not None and x.shape[1] > 0:
         # signal-parallel: the graph replicated per GPU, the columns split, one RCCL gather
         from . import multi

@@ -100,7 +100,8 @@ class Graph:
         order = self.reorder
         if isinstance(order, str) and order == "rcm":
             return False
-        if order == "auto" and getattr(self, "coords", None) is None and adjacency.shape[0] >= 4096:
+        coords = self._curve_coords(adjacency.shape[0])
+        if order == "auto" and coords is None and adjacency.shape[0] >= 4096:
             # no coordinates: the candidate order is reverse Cuthill-McKee, a host (scipy) algorithm - unless the graph
             # is random-like (ER / SBM: balls grow by the mean degree per hop), where no order helps
             if not engine.expander_like(adjacency):
@@ -109,8 +110,8 @@ class Graph:
         if order in ("morton", "hilbert") and adjacency.shape[0] < 4096:
             return False  # an explicitly requested curve on a small graph: the numpy curves of engine.locality_order
         try:
-            dev, rep = engine.DeviceGraph.setup(adjacency, self.lap_type, self.compute_dtype,
-                                                getattr(self, "coords", None), order, ctx=self.context)
+            dev, rep = engine.DeviceGraph.setup(adjacency, self.lap_type, self.compute_dtype, coords, order,
+                                                ctx=self.context)
         except ValueError as e:
             if "canonical" in str(e):
                 return False  # duplicates / unsorted indices: the host route sums and sorts them
@@ -142,12 +143,14 @@ class Graph:
         order = self.reorder
         if isinstance(order, str) and order == "rcm":
             return False
-        if order == "auto" and getattr(self, "coords", None) is None:
+        coords = self._curve_coords(adjacency.shape[0])
+        if order == "auto" and coords is None:
+            if getattr(self, "coords", None) is not None and adjacency.shape[0] >= 4096:
+                return False  # coordinates no curve can use (a 1-D point cloud): the host route tries RCM
             order = "none"  # a sampled block model: no coordinates, and no order helps a random graph
         if order in ("morton", "hilbert") and adjacency.shape[0] < 4096:
             return False
-        dev, rep = engine.DeviceGraph.setup_from(adjacency, self.lap_type, self.compute_dtype,
-                                                 getattr(self, "coords", None), order)
+        dev, rep = engine.DeviceGraph.setup_from(adjacency, self.lap_type, self.compute_dtype, coords, order)
         if dev is None:
             return False
         if rep["self_loops"]:
@@ -165,6 +168,15 @@ class Graph:
             self.tile_stats = dev.enable_gather_tiles()
         self._dev[self.compute_dtype] = dev
         return True
+
+    def _curve_coords(self, n_vertices):
+        """The coordinates a space-filling curve can order (the test of engine.DeviceGraph._order_args: one row per
+        vertex, at least two columns), else None - a 1-D point cloud or a layout of another size then takes the
+        same route as a graph without coordinates (random-like: no order; otherwise reverse Cuthill-McKee on the
+        host) instead of silently keeping the graph's own order."""
+        coords = getattr(self, "coords", None)
+        ok = coords is not None and np.ndim(coords) == 2 and np.shape(coords)[0] == n_vertices and np.shape(coords)[1] >= 2
+        return coords if ok else None
 
     @property
     def _adjacency(self):
@@ -356,7 +368,8 @@ class Graph:
         # with a random start vector: 3.3 s at N = 1M and not reproducible).  Same contract: an estimate
         # from below, increased by 1 % (graph.py:920); non-convergence is a ValueError (engine).
         ritz, _ = self.device_graph().lanczos_lmax(max_iter=80, tol=5e-4)
-        assert ritz <= self._get_upper_bound() * (1 + 1e-6) + 1e-12
+        if not ritz <= self._get_upper_bound() * (1 + 1e-6) + 1e-12:  # graph.py:919 (an assert there)
+            raise ValueError("The Lanczos estimate {} exceeds the upper bound of lambda_max.".format(ritz))
         return ritz * 1.01
 
     def _lmax_lanczos_host(self):

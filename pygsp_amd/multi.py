@@ -43,6 +43,61 @@ def context_for(device, occurrence=0):
         return ctx
 
 
+def numa_cpus_of(device, sysfs="/sys", address=None):
+    """The host cores next to HIP device `device`: the cpulist of the NUMA node its PCI function hangs off
+    (gspx_device_pci_bus_id -> <sysfs>/bus/pci/devices/<address>/numa_node -> <sysfs>/devices/system/node/node<k>/
+    cpulist).  None when the platform does not say (numa_node -1, no sysfs, one node)."""
+    import ctypes
+    import os
+    buf = ctypes.create_string_buffer(64)
+    try:
+        if address is None:
+            _capi.check(_capi.load().gspx_device_pci_bus_id(int(device), buf, 64))
+            address = buf.value.decode()
+        address = address.strip().lower()
+        with open(os.path.join(sysfs, "bus/pci/devices", address, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, "devices/system/node/node{}".format(node), "cpulist")) as f:
+            return parse_cpulist(f.read())
+    except (OSError, ValueError, _capi.GspxError):
+        return None
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> {0, 1, 2, 3, 8, 10, 11} (the kernel's cpulist format)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_thread_near(device):
+    """Restrict the CALLING thread (and the threads libgspx starts from it: the packers of the host pipeline) to
+    the cores of the GPU's NUMA node; pageable-memory staging then reads the local memory controller.  A no-op
+    when the node is unknown, when it would leave no allowed core, or with GSPX_NUMA_PIN=0.  Returns the cores
+    or None."""
+    import os
+    if os.environ.get("GSPX_NUMA_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = numa_cpus_of(device)
+    if not cpus:
+        return None
+    allowed = cpus & os.sched_getaffinity(0)
+    if not allowed:
+        return None
+    try:
+        os.sched_setaffinity(0, allowed)  # pid 0: the calling thread
+    except OSError:
+        return None
+    return allowed
+
+
 class DeviceGroup:
     """Contexts of a device list, one driver thread per context."""
 
@@ -61,6 +116,7 @@ class DeviceGroup:
             self.ctxs.append(context_for(d, seen.get(d, 0)))
             seen[d] = seen.get(d, 0) + 1
         self.n_distinct = len(seen)
+        self.pinned = [None] * len(devices)  # cores each driver thread was restricted to (None: not pinned)
 
     def __len__(self):
         return len(self.ctxs)
@@ -73,6 +129,8 @@ class DeviceGroup:
 
         def work(i):
             try:
+                if n > 1 and self.n_distinct > 1:  # a driver thread per GPU: next to its GPU's memory controller
+                    self.__dict__.setdefault("pinned", [None] * n)[i] = pin_thread_near(self.devices[i])
                 out[i] = fn(i, self.ctxs[i])
             except BaseException as e:  # surfaced on the caller's thread
                 errs.append((i, e))

@@ -28,8 +28,8 @@ def _finite_coords(G):
         coords = np.asarray(coords, dtype=np.float64)
     except (TypeError, ValueError):
         return None
-    if coords.ndim != 2 or coords.shape[0] != G.N or not np.isfinite(coords).all():
-        return None  # plotting layouts may hold NaN / inf: fall back to the pattern-based order
+    if coords.ndim != 2 or coords.shape[0] != G.N or coords.shape[1] < 2 or not np.isfinite(coords).all():
+        return None  # plotting layouts may hold NaN / inf, a 1-D cloud has no curve: the pattern-based order
     return coords
 
 

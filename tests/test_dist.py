@@ -37,7 +37,7 @@ def _worker(rank, world, port, tmp):
     import torch
     from scipy import sparse
     from oracle import cheby_oracle as orc
-    from pygsp_amd import dist as gd
+    from tools import torchrun_plumbing as gd
     r, w, _ = gd.init_process_group("gloo")
     assert (r, w) == (rank, world)
     # a batch of 3 independent graphs, sharded 2 + 1

@@ -220,6 +220,49 @@ def test_bench_threads_two_contexts_on_this_gpu():
     assert sp["parity_vs_oracle"]["max_rel_err"] < 1e-11
 
 
+def test_bench_threads_eight_contexts_on_this_gpu():
+    """The 8-way form the driver's 8-GPU node would run, dry on this box's one GPU (`--gpus 8 --devices 0,0,0,0,0,0,0,0`):
+    eight contexts and driver threads, the weak line, the 64 signals of one graph split 8 x 8 (signal_parallel), the
+    batch of BASELINE configs[4] one graph per context, gspx_gather of eight parts - parity on all eight."""
+    res = _run_bench(["--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--steps", "2", "--warmup", "1", "--vertices", "100000"],
+                     timeout=1200)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["devices"] == [0] * 8
+    assert len(out["per_device"]) == 8 and all(p["frac"] > 0 for p in out["per_device"])
+    assert out["driver_thread_cores"] == [None] * 8  # one physical GPU: nothing to pin apart
+    assert out["gather_ms"] > 0 and "gspx_gather" in out["gather_impl"] and out["rccl_ranks"] == 0
+    assert out["parity_vs_oracle"]["ranks"] == 8 and out["parity_vs_oracle"]["max_rel_err"] < 1e-11
+    sp = out["signal_parallel"]
+    assert sp["n_gpus"] == 8 and "8/8/8/8/8/8/8/8" in sp["workload"] and sp["value"] > 0
+    assert sp["parity_vs_oracle"]["max_rel_err"] < 1e-11
+    b5 = out["batch_config4"]
+    assert b5["n_gpus"] == 8 and b5["n_graphs"] == 8 and "1/1/1/1/1/1/1/1" in b5["workload"] and b5["value"] > 0
+    assert b5["parity_vs_oracle"]["max_rel_err"] < 1e-11 and b5["parity_vs_oracle"]["graphs_checked"] == 8
+
+
+def test_device_pci_address_and_numa_lookup():
+    """gspx_device_pci_bus_id names this GPU's PCI function; the NUMA lookup built on it never raises (the cores of
+    the GPU's node, or None when the platform does not say)."""
+    import ctypes
+
+    from pygsp_amd import multi
+    buf = ctypes.create_string_buffer(64)
+    _capi.check(_capi.load().gspx_device_pci_bus_id(0, buf, 64))
+    address = buf.value.decode()
+    assert len(address.split(":")) == 3 and "." in address, address
+    with pytest.raises(ValueError):
+        _capi.check(_capi.load().gspx_device_pci_bus_id(_capi.device_count(), buf, 64))
+    cpus = multi.numa_cpus_of(0)
+    assert cpus is None or (isinstance(cpus, set) and cpus)
+    before = os.sched_getaffinity(0)
+    try:
+        pinned = multi.pin_thread_near(0)
+        assert pinned is None or pinned == os.sched_getaffinity(0)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_bench_all_visible_gpus_through_rccl():
     """On a box with >= 2 GPUs: bench.py --gpus <all> drives them from one process and gathers through the
     library's RCCL communicators (ncclCommInitAll) with real peers."""

@@ -133,3 +133,23 @@ def test_a_failing_device_surfaces_its_error(monkeypatch, golden_sensor123):
     with pytest.raises(RuntimeError, match="device 1"):
         multi.filter_columns(G, c, np.ones((G.N, 6)), group)
     assert not _Buf.live  # the other devices' buffers do not leak
+
+
+def test_numa_node_of_a_gpu_from_sysfs(tmp_path):
+    """multi.numa_cpus_of / parse_cpulist: PCI address -> numa_node -> cpulist, on a fabricated sysfs tree (the
+    address itself comes from gspx_device_pci_bus_id on a GPU box); unknown nodes and missing files give None."""
+    from pygsp_amd import multi
+    assert multi.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert multi.parse_cpulist("") == set()
+    dev = tmp_path / "bus/pci/devices/0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices/system/node/node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127,192-255\n")
+    cpus = multi.numa_cpus_of(0, sysfs=str(tmp_path), address="0000:C1:00.0")
+    assert cpus == set(range(64, 128)) | set(range(192, 256))
+    (dev / "numa_node").write_text("-1\n")
+    assert multi.numa_cpus_of(0, sysfs=str(tmp_path), address="0000:c1:00.0") is None
+    assert multi.numa_cpus_of(0, sysfs=str(tmp_path), address="0000:ff:00.0") is None
+    assert multi.numa_cpus_of(0) is None or isinstance(multi.numa_cpus_of(0), set)  # no GPU here: None, never raises
