@@ -82,6 +82,17 @@ int gspx_tikhonov_cg_dev(gspx_graph* g, double tau, const void* mask_dev, int64_
 int gspx_graph_n_edges(gspx_graph* g, int64_t* n_edges);
 int gspx_graph_download_edges(gspx_graph* g, int32_t* sources, int32_t* targets, void* weights,
                               void* d_source, void* d_target);
+/* The differential operator of a DIRECTED graph, or of a graph with self-loops, from the caller's edge list
+ * (Graph.get_edge_list, graph.py:1019-1029: every stored entry of W for a directed graph, the upper triangle
+ * including the diagonal otherwise; sources non-decreasing).  The device graph was built from the symmetrised W
+ * (graph.py:613-616), whose degrees are the reference's dw of the directed graph, so the D values of
+ * difference.py:151-161 are formed on the device: -sqrt(w) / +sqrt(w), or -sqrt(w / dw[source]) /
+ * +sqrt(w / dw[target]), divided by sqrt(2) when `directed`.  Replaces the edge list gspx_graph_n_edges /
+ * gspx_graph_download_edges / gspx_grad_dev / gspx_div_dev work on (by default the upper triangle of the graph's
+ * own Laplacian). */
+int gspx_graph_set_edge_list(gspx_graph* g, int64_t n_edges, const int32_t* sources, const int32_t* targets,
+                             const double* weights, int directed);
+
 /* grad: y (n_edges x Nsig) = D^T x   (difference.py:168-244)
  * div:  z (N x Nsig)       = D y     (difference.py:246-331) */
 int gspx_grad_dev(gspx_graph* g, int64_t Nsig, const void* x_dev, void* y_dev, double* kernel_ms);
@@ -134,6 +145,12 @@ int gspx_radius_build(gspx_ctx* ctx, int64_t N, int d, const double* coords, dou
  * gspx_knn_info / gspx_knn_download_w and freed with gspx_knn_destroy. */
 int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const int64_t* bounds,
                    const double* M, uint64_t seed, gspx_knn** out);
+/* The same sampler with the reference's other two switches (stochasticblockmodel.py:69-70, 128-130): flags bit 0
+ * = directed (every ORDERED pair (r, c) is an entry W[r, c] = 1 with probability M[z_r][z_c]; M need not be
+ * symmetric), bit 1 = self_loops (the pairs r == c take part; an undirected self-loop is one stored entry).
+ * flags = 0 is gspx_sbm_build.  `connected=True` is a loop of the host layer over seeds (n_try). */
+int gspx_sbm_build_ex(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const int64_t* bounds,
+                      const double* M, uint64_t seed, int flags, gspx_knn** out);
 
 /* Space-filling-curve keys of N points (coords: N x d doubles on the HOST, d >= 2; the first two /
  * three axes are used): curve 0 = Morton, 1 = Hilbert (2-D).  The engine's internal vertex order

@@ -84,6 +84,7 @@ SIGNATURES = {
                                          _c.c_double, _c.c_int64, _P, _P]),
     "gspx_graph_n_edges": (_c.c_int, [_P, _P]),
     "gspx_graph_download_edges": (_c.c_int, [_P, _P, _P, _P, _P, _P]),
+    "gspx_graph_set_edge_list": (_c.c_int, [_P, _c.c_int64, _P, _P, _P, _c.c_int]),
     "gspx_grad_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
     "gspx_div_dev": (_c.c_int, [_P, _c.c_int64, _P, _P, _P]),
     "gspx_knn_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_int, _c.c_double, _c.c_int, _c.c_int, _P]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "gspx_graph_download_perm": (_c.c_int, [_P, _P]),
     "gspx_graph_lmax_bounds": (_c.c_int, [_P, _P]),
     "gspx_sbm_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_uint64, _P]),
+    "gspx_sbm_build_ex": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_uint64, _c.c_int, _P]),
     "gspx_radius_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_double, _c.c_double, _c.c_int, _P]),
     "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),
     "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,

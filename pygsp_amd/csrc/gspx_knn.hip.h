@@ -676,8 +676,11 @@ struct SbmSeg {       // one block pair
   long long chunk;    // candidates per chunk
   long long first;    // global index of its first chunk
   double log1mp;      // log(1 - p)  (-inf for p == 1)
-  int lo_a, n_a, lo_b, n_b;  // member ranges in `order`; lo_a == lo_b: within-block triangle
+  int lo_a, n_a, lo_b, n_b;  // member ranges in `order`
+  int kind;           // candidate index -> (r, c): 0 rectangle n_a x n_b, 1 triangle r > c, 2 triangle r >= c
+                      // (self-loops allowed), 3 square n_a x n_a without its diagonal (directed, no self-loops)
 };
+constexpr int GSPX_SBM_DIRECTED = 1, GSPX_SBM_SELF_LOOPS = 2;
 
 __device__ __forceinline__ unsigned long long sbm_hash(unsigned long long x) {  // splitmix64 finaliser
   x += 0x9E3779B97F4A7C15ull;
@@ -696,7 +699,7 @@ template <int PASS>
 __global__ void k_sbm_chunks(const SbmSeg* __restrict__ seg, int nseg, long long nchunks,
                              unsigned long long seed, const int* __restrict__ order,
                              int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ er,
-                             int* __restrict__ ec, int* __restrict__ deg) {
+                             int* __restrict__ ec, int* __restrict__ deg, int directed) {
   const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= nchunks) return;
   int lo = 0, hi = nseg - 1;  // last segment whose first chunk is <= ch
@@ -718,11 +721,20 @@ __global__ void k_sbm_chunks(const SbmSeg* __restrict__ seg, int nseg, long long
     if (PASS) {
       const long long idx = base + pos;
       long long r, c;
-      if (s.lo_a == s.lo_b) {  // idx = r (r - 1) / 2 + c, r > c
+      if (s.kind == 1) {  // idx = r (r - 1) / 2 + c, r > c
         r = (long long)floor((1.0 + sqrt(1.0 + 8.0 * (double)idx)) * 0.5);
         if (r * (r - 1) / 2 > idx) --r;
         if ((r + 1) * r / 2 <= idx) ++r;
         c = idx - r * (r - 1) / 2;
+      } else if (s.kind == 2) {  // idx = r (r + 1) / 2 + c, r >= c
+        r = (long long)floor((sqrt(1.0 + 8.0 * (double)idx) - 1.0) * 0.5);
+        if (r * (r + 1) / 2 > idx) --r;
+        if ((r + 1) * (r + 2) / 2 <= idx) ++r;
+        c = idx - r * (r + 1) / 2;
+      } else if (s.kind == 3) {  // row r holds its n_a - 1 off-diagonal columns
+        r = idx / (s.n_a - 1);
+        c = idx - r * (s.n_a - 1);
+        if (c >= r) ++c;
       } else {
         r = idx / s.n_b;
         c = idx - r * s.n_b;
@@ -731,7 +743,7 @@ __global__ void k_sbm_chunks(const SbmSeg* __restrict__ seg, int nseg, long long
       er[o + n] = vr;
       ec[o + n] = vc;
       atomicAdd(&deg[vr], 1);
-      atomicAdd(&deg[vc], 1);
+      if (!directed && vr != vc) atomicAdd(&deg[vc], 1);  // (an undirected self-loop is one stored entry)
     }
     ++n;
     ++pos;
@@ -741,13 +753,14 @@ __global__ void k_sbm_chunks(const SbmSeg* __restrict__ seg, int nseg, long long
 }
 __global__ void k_sbm_fill(const int* __restrict__ er, const int* __restrict__ ec, long long m,
                            const int* __restrict__ rowptr, int* __restrict__ cursor, int* __restrict__ col,
-                           double* __restrict__ val) {
+                           double* __restrict__ val, int directed) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m) return;
   const int r = er[e], c = ec[e];
   const int a = rowptr[r] + atomicAdd(&cursor[r], 1);
   col[a] = c;
   val[a] = 1.0;
+  if (directed || r == c) return;  // W[r, c] alone / the one entry of a self-loop
   const int b = rowptr[c] + atomicAdd(&cursor[c], 1);
   col[b] = r;
   val[b] = 1.0;
@@ -755,31 +768,52 @@ __global__ void k_sbm_fill(const int* __restrict__ er, const int* __restrict__ e
 
 }  // namespace gspx
 
+extern "C" int gspx_sbm_build_ex(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const int64_t* bounds,
+                                 const double* M, uint64_t seed, int flags, gspx_knn** out);
 extern "C" int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const int64_t* bounds,
                               const double* M, uint64_t seed, gspx_knn** out) {
+  return gspx_sbm_build_ex(ctx, N, k, order, bounds, M, seed, 0, out);
+}
+
+extern "C" int gspx_sbm_build_ex(gspx_ctx* ctx, int64_t N, int k, const int32_t* order, const int64_t* bounds,
+                                 const double* M, uint64_t seed, int flags, gspx_knn** out) {
   if (!ctx || !out) return set_err(GSPX_ERR_INVALID, "null ctx or output");
   *out = nullptr;
-  if (N < 1 || N >= ((int64_t)1 << 31) - 1 || k < 1 || k > 4096 || !order || !bounds || !M)
+  if (N < 1 || N >= ((int64_t)1 << 31) - 1 || k < 1 || k > 4096 || !order || !bounds || !M ||
+      (flags & ~(GSPX_SBM_DIRECTED | GSPX_SBM_SELF_LOOPS)))
     return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: bad argument");
+  const bool directed = (flags & GSPX_SBM_DIRECTED) != 0, loops = (flags & GSPX_SBM_SELF_LOOPS) != 0;
   if (bounds[0] != 0 || bounds[k] != N) return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: bounds must span [0, N]");
   for (int a = 0; a < k; ++a) {
     if (bounds[a + 1] < bounds[a]) return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: bounds must not decrease");
     for (int b = 0; b < k; ++b) {
       const double p = M[(size_t)a * k + b];
       if (!(p >= 0.0 && p <= 1.0)) return set_err(GSPX_ERR_INVALID, "Probabilities should be in [0, 1].");
-      if (p != M[(size_t)b * k + a]) return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: M must be symmetric (undirected graphs)");
+      if (!directed && p != M[(size_t)b * k + a])
+        return set_err(GSPX_ERR_INVALID, "gspx_sbm_build: M must be symmetric (undirected graphs)");
     }
   }
   std::vector<SbmSeg> segs;
   long long nchunks = 0;
+  // undirected: the block pairs (a, b <= a), the reference's r >= c half (stochasticblockmodel.py:129, mirrored
+  // by utils.symmetrize 'tril'); directed: all k^2 ordered block pairs, entry W[r, c] alone
   for (int a = 0; a < k; ++a)
-    for (int b = 0; b <= a; ++b) {
+    for (int b = 0; b <= (directed ? k - 1 : a); ++b) {
       const double p = M[(size_t)a * k + b];
       const long long na = bounds[a + 1] - bounds[a], nbk = bounds[b + 1] - bounds[b];
-      const long long total = a == b ? na * (na - 1) / 2 : na * nbk;
+      int kind = 0;
+      long long total = na * nbk;
+      if (a == b && !directed) {
+        kind = loops ? 2 : 1;
+        total = loops ? na * (na + 1) / 2 : na * (na - 1) / 2;
+      } else if (a == b && !loops) {
+        kind = 3;
+        total = na * (na - 1);
+      }
       if (p <= 0.0 || total <= 0) continue;
       SbmSeg s{};
       s.total = total;
+      s.kind = kind;
       long long c = 64;  // about 16 kept pairs per chunk
       while (c < ((long long)1 << 22) && (double)c * p < 16.0) c <<= 1;
       s.chunk = c;
@@ -830,7 +864,7 @@ extern "C" int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* or
     const unsigned nbc = (unsigned)((nchunks + 255) / 256);
     hipLaunchKernelGGL((k_sbm_chunks<0>), dim3(nbc), dim3(256), 0, st, dseg.as<SbmSeg>(), (int)segs.size(), nchunks,
                        (unsigned long long)seed, dorder.as<int>(), cnt.as<int>(), (const int*)nullptr,
-                       (int*)nullptr, (int*)nullptr, (int*)nullptr);
+                       (int*)nullptr, (int*)nullptr, (int*)nullptr, directed ? 1 : 0);
     KCHK(scan_exclusive(ctx, cnt.as<int>(), off.as<int>(), (int)nchunks + 1));
     int mi = 0;
     KHIP(hipMemcpyAsync(&mi, off.as<int>() + nchunks, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -842,17 +876,20 @@ extern "C" int gspx_sbm_build(gspx_ctx* ctx, int64_t N, int k, const int32_t* or
     KCHK(ec.alloc((size_t)std::max<long long>(m, 1) * sizeof(int)));
     hipLaunchKernelGGL((k_sbm_chunks<1>), dim3(nbc), dim3(256), 0, st, dseg.as<SbmSeg>(), (int)segs.size(), nchunks,
                        (unsigned long long)seed, dorder.as<int>(), (int*)nullptr, off.as<int>(), er.as<int>(),
-                       ec.as<int>(), deg.as<int>());
+                       ec.as<int>(), deg.as<int>(), directed ? 1 : 0);
   }
   KCHK(scan_exclusive(ctx, deg.as<int>(), h->rowptr.as<int>(), n + 1));
-  h->nnz = 2 * m;
-  KCHK(h->col.alloc((size_t)std::max<long long>(2 * m, 1) * sizeof(int)));
-  KCHK(h->val.alloc((size_t)std::max<long long>(2 * m, 1) * sizeof(double)));
+  int stored = 0;  // 2 m for an undirected graph without self-loops; fewer with them, m when directed
+  KHIP(hipMemcpyAsync(&stored, h->rowptr.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+  KHIP(hipStreamSynchronize(st));
+  h->nnz = stored;
+  KCHK(h->col.alloc((size_t)std::max<long long>(stored, 1) * sizeof(int)));
+  KCHK(h->val.alloc((size_t)std::max<long long>(stored, 1) * sizeof(double)));
   if (m > 0) {
     KCHK(cursor.alloc(((size_t)N + 1) * sizeof(int)));
     KHIP(hipMemsetAsync(cursor.p, 0, ((size_t)N + 1) * sizeof(int), st));
     hipLaunchKernelGGL(k_sbm_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, er.as<int>(), ec.as<int>(),
-                       m, h->rowptr.as<int>(), cursor.as<int>(), h->col.as<int>(), h->val.as<double>());
+                       m, h->rowptr.as<int>(), cursor.as<int>(), h->col.as<int>(), h->val.as<double>(), directed ? 1 : 0);
     hipLaunchKernelGGL(k_knn_row_sort, dim3((n + 255) / 256), dim3(256), 0, st, h->rowptr.as<int>(), n,
                        h->col.as<int>(), h->val.as<double>());
   }

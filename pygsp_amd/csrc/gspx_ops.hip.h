@@ -357,6 +357,77 @@ template <typename T> static int ensure_edges(gspx_graph* g) {
   return GSPX_OK;
 }
 
+// ---- differential operator from a caller's edge list (directed graphs, self-loops) --------------------
+// Graph.get_edge_list of a directed graph is every stored entry of W (graph.py:1019-1029) and its D carries a
+// factor 1 / sqrt(2) (difference.py:160-161); with self-loops the diagonal entries are edges too, whose two D
+// values cancel (difference.py:166 drops the stored zeros).  The device graph holds the Laplacian of the
+// SYMMETRISED W, so these edges cannot be read back from it: the host layer hands over (source, target, weight)
+// in get_edge_list order - sources non-decreasing - and the D values are formed here from the graph's degrees.
+template <typename T>
+static int set_edge_list_t(gspx_graph* g, int64_t E, const int32_t* src, const int32_t* dst, const double* w,
+                           int directed) {
+  gspx_ctx* ctx = g->ctx;
+  hipStream_t st = ctx->stream;
+  const int N = (int)g->N;
+  std::vector<int> eoff((size_t)N + 1, 0), toff((size_t)N + 1, 0), tedge((size_t)std::max<int64_t>(E, 1));
+  for (int64_t k = 0; k < E; ++k) {
+    if (src[k] < 0 || src[k] >= N || dst[k] < 0 || dst[k] >= N)
+      return set_err(GSPX_ERR_INVALID, "gspx_graph_set_edge_list: edge %lld has a vertex outside [0, N)", (long long)k);
+    if (k > 0 && src[k] < src[k - 1])
+      return set_err(GSPX_ERR_INVALID, "gspx_graph_set_edge_list: sources must not decrease (get_edge_list order)");
+    if (!(w[k] >= 0.0)) return set_err(GSPX_ERR_INVALID, "gspx_graph_set_edge_list: weights must be >= 0");
+    ++eoff[(size_t)src[k] + 1];
+    ++toff[(size_t)dst[k] + 1];
+  }
+  for (int i = 0; i < N; ++i) {
+    eoff[(size_t)i + 1] += eoff[i];
+    toff[(size_t)i + 1] += toff[i];
+  }
+  {
+    std::vector<int> cur(toff.begin(), toff.end() - 1);
+    for (int64_t k = 0; k < E; ++k) tedge[(size_t)cur[dst[k]]++] = (int)k;  // edges ending in a vertex, in edge order
+  }
+  std::vector<T> wt((size_t)std::max<int64_t>(E, 1));
+  for (int64_t k = 0; k < E; ++k) wt[(size_t)k] = (T)w[k];
+  const size_t e = (size_t)std::max<int64_t>(E, 1);
+  CHK(g->e_off.alloc(((size_t)N + 1) * sizeof(int)));
+  CHK(g->e_toff.alloc(((size_t)N + 1) * sizeof(int)));
+  CHK(g->e_src.alloc(e * sizeof(int)));
+  CHK(g->e_dst.alloc(e * sizeof(int)));
+  CHK(g->e_tedge.alloc(e * sizeof(int)));
+  CHK(g->e_cs.alloc(e * sizeof(T)));
+  CHK(g->e_ct.alloc(e * sizeof(T)));
+  CHK(g->e_w.alloc(e * sizeof(T)));
+  HIPCHK(hipMemcpyAsync(g->e_off.p, eoff.data(), ((size_t)N + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(g->e_toff.p, toff.data(), ((size_t)N + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  if (E > 0) {
+    HIPCHK(hipMemcpyAsync(g->e_src.p, src, (size_t)E * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g->e_dst.p, dst, (size_t)E * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g->e_tedge.p, tedge.data(), (size_t)E * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g->e_w.p, wt.data(), (size_t)E * sizeof(T), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_edge_values<T>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, g->e_src.as<int>(),
+                       g->e_dst.as<int>(), g->e_w.as<T>(), g->dw.as<T>(), (int)E, g->lap_type, directed,
+                       g->e_cs.as<T>(), g->e_ct.as<T>());
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(st));  // the host vectors above are read by the copies until here
+  g->n_edges = E;
+  g->edges_built = true;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_set_edge_list(gspx_graph* g, int64_t n_edges, const int32_t* sources, const int32_t* targets,
+                                        const double* weights, int directed) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (n_edges < 0 || n_edges >= ((int64_t)1 << 31) || (n_edges > 0 && (!sources || !targets || !weights)))
+    return set_err(GSPX_ERR_INVALID, "gspx_graph_set_edge_list: bad argument");
+  if (!g->from_w)
+    return set_err(GSPX_ERR_INVALID, "differential operator needs a graph created from W (degrees)");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  return g->dtype == GSPX_F32 ? set_edge_list_t<float>(g, n_edges, sources, targets, weights, directed)
+                              : set_edge_list_t<double>(g, n_edges, sources, targets, weights, directed);
+}
+
 static int edges_for(gspx_graph* g) {
   if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
   HIPCHK(hipSetDevice(g->ctx->device));

@@ -266,6 +266,31 @@ __global__ void k_edge_fill(const int* __restrict__ lptr, const int* __restrict_
     }
   }
 }
+// D values of a caller's edge list (difference.py:151-161): -sqrt(w) / +sqrt(w), or -sqrt(w / d_source) /
+// +sqrt(w / d_target) for the normalized Laplacian, both divided by sqrt(2) on a directed graph
+template <typename T>
+__global__ void k_edge_values(const int* __restrict__ esrc, const int* __restrict__ edst, const T* __restrict__ ew,
+                              const T* __restrict__ dw, int E, int lap_type, int directed, T* __restrict__ cs,
+                              T* __restrict__ ct) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  const T w = ew[k];
+  T a, b;
+  if (lap_type == 0) {
+    a = -sqrt(w);
+    b = -a;
+  } else {
+    a = -sqrt(w / dw[esrc[k]]);
+    b = sqrt(w / dw[edst[k]]);
+  }
+  if (directed) {
+    const T root2 = sqrt((T)2);
+    a /= root2;
+    b /= root2;
+  }
+  cs[k] = a;
+  ct[k] = b;
+}
 // grad: y[k][:] = cs[k] * x[src[k]][:] + ct[k] * x[dst[k]][:]      (D.T.dot(x), difference.py:244)
 // 2-D thread blocks (cw columns x 256/cw edges): consecutive lanes walk the signals of one edge, no
 // index division anywhere

@@ -996,7 +996,20 @@ def _ops_methods():
         E = src.size
         rows = np.concatenate([src, dst])
         cols = np.concatenate([np.arange(E), np.arange(E)])
-        return sparse.csc_matrix((np.concatenate([ds, dt]), (rows, cols)), shape=(self.N, E))
+        D = sparse.csc_matrix((np.concatenate([ds, dt]), (rows, cols)), shape=(self.N, E))
+        D.eliminate_zeros()  # the two values of a self-loop cancel (difference.py:166)
+        return D
+
+    def set_edge_list(self, sources, targets, weights, directed):
+        """Replace the edge list of grad / div / D by the caller's (gspx_graph_set_edge_list): the edges of a
+        directed graph or of a graph with self-loops, in Graph.get_edge_list order (sources non-decreasing)."""
+        src = np.ascontiguousarray(sources, dtype=np.int32)
+        dst = np.ascontiguousarray(targets, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if not (src.shape == dst.shape == w.shape and src.ndim == 1):
+            raise ValueError("sources, targets and weights must be vectors of one length")
+        _capi.check(_capi.load().gspx_graph_set_edge_list(self._h, src.size, _capi.ptr(src), _capi.ptr(dst),
+                                                          _capi.ptr(w), 1 if directed else 0))
 
     def grad_dev(self, x_ptr, y_ptr, nsig):
         ms = ctypes.c_double(0)
@@ -1031,7 +1044,7 @@ def _ops_methods():
         return _edge_op(self, y, n_edges(self), self.N, div_dev, "div")
 
     for f in (laplacian_apply_dev, laplacian_apply, dirichlet_energy_dev, dirichlet_energy,
-              tikhonov_cg_dev, tikhonov_cg, n_edges, edge_list, differential_operator, grad_dev,
+              tikhonov_cg_dev, tikhonov_cg, n_edges, edge_list, differential_operator, set_edge_list, grad_dev,
               div_dev, grad, div):
         setattr(DeviceGraph, f.__name__, f)
 
@@ -1139,11 +1152,12 @@ def radius_graph(coords, epsilon, sigma=None, ctx=None, metric="euclidean", keep
     return (W if keep_on_device else W.download()), sg.value, {"build_ms": ms.value}
 
 
-def sbm_graph(z, M, seed=None, ctx=None, keep_on_device=False):
-    """Stochastic-block-model adjacency sampled on the device (gspx_sbm_build): every unordered pair
+def sbm_graph(z, M, seed=None, ctx=None, keep_on_device=False, directed=False, self_loops=False):
+    """Stochastic-block-model adjacency sampled on the device (gspx_sbm_build_ex): every unordered pair
     of distinct vertices (r, c) is an edge with probability M[z[r], z[c]], unit weights
-    (stochasticblockmodel.py:125-144 with directed=False, self_loops=False; one block = Erdos-Renyi).
-    z: (N,) block labels in 0..k-1, M: (k, k) symmetric.  Returns (W csr float64, build_ms)."""
+    (stochasticblockmodel.py:125-144; one block = Erdos-Renyi).  directed: every ORDERED pair is an entry
+    W[r, c] on its own (M need not be symmetric); self_loops: the pairs r == c take part.
+    z: (N,) block labels in 0..k-1, M: (k, k).  Returns (W csr float64, build_ms)."""
     ctx = ctx or default_context()
     z = np.asarray(z)
     M = np.ascontiguousarray(M, dtype=np.float64)
@@ -1157,8 +1171,9 @@ def sbm_graph(z, M, seed=None, ctx=None, keep_on_device=False):
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
     lib = _capi.load()
     h = ctypes.c_void_p()
-    _capi.check(lib.gspx_sbm_build(ctx._h, N, k, _capi.ptr(order), _capi.ptr(bounds), _capi.ptr(M),
-                                   ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.byref(h)))
+    flags = (1 if directed else 0) | (2 if self_loops else 0)
+    _capi.check(lib.gspx_sbm_build_ex(ctx._h, N, k, _capi.ptr(order), _capi.ptr(bounds), _capi.ptr(M),
+                                      ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), flags, ctypes.byref(h)))
     try:
         nnz, sg, ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         _capi.check(lib.gspx_knn_info(h, ctypes.byref(nnz), ctypes.byref(sg), ctypes.byref(ms)))

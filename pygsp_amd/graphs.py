@@ -208,6 +208,20 @@ class Graph:
     def _directed(self):
         return self._flags.get("directed")
 
+    def is_connected(self):
+        """graph.py:303-355: every vertex reachable from every other one - for a directed graph along the
+        edges AND against them (strongly connected).  Connected components of W on the host (scipy's csgraph),
+        computed once."""
+        if "connected" not in self._flags:
+            from scipy.sparse import csgraph
+            if self.n_vertices == 0:
+                self._flags["connected"] = True
+            else:
+                n, _ = csgraph.connected_components(self.W, directed=self.is_directed(), connection="strong",
+                                                    return_labels=True)
+                self._flags["connected"] = bool(n == 1)
+        return self._flags["connected"]
+
     def _symmetric_w(self):
         """W itself if undirected, else (W + W.T)/2 (utils.symmetrize 'average', graph.py:613-616)."""
         return sparse.csr_matrix((self.W + self.W.T) / 2) if self.is_directed() else self.W
@@ -317,12 +331,16 @@ class Graph:
         return C.row, C.col, C.data
 
     def _device_differential(self):
-        if self.is_directed():
-            raise NotImplementedError("the device differential operator covers undirected graphs; "
-                                      "this graph is directed")
-        if self.W.diagonal().any():
-            raise NotImplementedError("the device differential operator does not cover self-loops")
-        return self.device_graph()
+        """The device graph with the edge list grad / div / D work on.  An undirected graph without self-loops
+        reads its edges off its own device Laplacian; a directed graph (all stored entries, D / sqrt(2),
+        difference.py:160-161) or one with self-loops (diagonal entries are edges whose two D values cancel,
+        difference.py:166) hands over Graph.get_edge_list, and the D values are formed on the device."""
+        dev = self.device_graph()
+        if (self.is_directed() or self.W.diagonal().any()) and getattr(self, "_edges_given_to", None) is not dev:
+            sources, targets, weights = self.get_edge_list()
+            dev.set_edge_list(sources, targets, weights, directed=self.is_directed())
+            self._edges_given_to = dev
+        return dev
 
     def compute_differential_operator(self):
         """difference.py:26-166.  D is assembled on the device (edge enumeration, sqrt of the
@@ -611,17 +629,14 @@ def sbm_weights(N, k=5, z=None, p=0.7, q=None, seed=None):
 
 
 class StochasticBlockModel(Graph):
-    """stochasticblockmodel.py:12-181 for undirected graphs without self-loops: labels z (sorted random
-    labels from the same numpy stream as the reference when not given), probabilities M (or p on the
-    diagonal and q elsewhere), edges sampled on the device in O(edges) (engine.sbm_graph) - equal in
-    distribution to the reference's N^2 loop, not bit-equal.  ``sbm_weights`` is the numpy sampler of
-    the same distribution."""
+    """stochasticblockmodel.py:12-181: labels z (sorted random labels from the same numpy stream as the
+    reference when not given), probabilities M (or p on the diagonal and q elsewhere), edges sampled on the
+    device in O(edges) (engine.sbm_graph) - equal in distribution to the reference's N^2 loop, not bit-equal.
+    directed / self_loops / connected (n_try fresh samples until one is connected) as the reference.
+    ``sbm_weights`` is the numpy sampler of the undirected, loop-free distribution."""
 
     def __init__(self, N=1024, k=5, z=None, M=None, p=0.7, q=None, directed=False, self_loops=False,
                  connected=False, n_try=10, seed=None, **kwargs):
-        if directed or self_loops or connected:
-            raise NotImplementedError("the device sampler covers directed=False, self_loops=False, "
-                                      "connected=False")
         self.k, self.directed, self.self_loops, self.connected = k, directed, self_loops, connected
         self.n_try, self.seed = n_try, seed
         stream = np.random.default_rng(seed)
@@ -634,10 +649,26 @@ class StochasticBlockModel(Graph):
         self.M = np.asarray(M, dtype=np.float64)
         if self.M.min() < 0 or self.M.max() > 1:
             raise ValueError("Probabilities should be in [0, 1].")
-        device_seed = int(stream.integers(0, 2 ** 63))
         ctx = kwargs.get("ctx") or engine.default_context(int(kwargs.get("device", 0)))
-        # (W stays on the device until somebody reads G.W: unit int64 weights then, like the reference's W)
-        W, self.sampler_ms = engine.sbm_graph(self.z, self.M, seed=device_seed, ctx=ctx, keep_on_device=True)
+        tries, self.sampler_ms = n_try, 0.0
+        while True:  # stochasticblockmodel.py:122-157: sample until connected, at most n_try times (None: for ever)
+            device_seed = int(stream.integers(0, 2 ** 63))
+            # (W stays on the device until somebody reads G.W: unit int64 weights then, like the reference's W)
+            W, ms = engine.sbm_graph(self.z, self.M, seed=device_seed, ctx=ctx, keep_on_device=True,
+                                     directed=directed, self_loops=self_loops)
+            self.sampler_ms += ms
+            if not connected:
+                break
+            trial = Graph(W, reorder="none", tiles=False, ctx=ctx)
+            if trial.is_connected():
+                W = trial.W  # (the host copy the connectivity test made: the device handle went with it)
+                break
+            if tries is not None:
+                tries -= 1
+                if tries <= 0:
+                    raise ValueError("The graph could not be connected after {} trials. Increase the connection "
+                                     "probability or the number of trials.".format(self.n_try))
+        self.info = {"node_com": self.z, "comm_sizes": np.bincount(self.z), "world_rad": np.sqrt(N)}
         Graph.__init__(self, W, **kwargs)
 
 

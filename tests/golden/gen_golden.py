@@ -179,6 +179,43 @@ def ops_sensor123():
     np.savez_compressed(os.path.join(OUT, "ops_sensor123.npz"), **out)
 
 
+def ops_directed():
+    """SURVEY 8(f) row 3, the branches of difference.py:160-166: the differential operator, grad and div of a
+    DIRECTED weighted graph (all stored entries are edges, values / sqrt(2)) and of an undirected graph with
+    self-loops (diagonal entries are edges whose stored zeros are eliminated); Laplacian and degrees beside them."""
+    from scipy import sparse
+    out = {}
+    rng = np.random.default_rng(11)
+    n = 60
+    A = sparse.random(n, n, 0.08, random_state=5, format="lil")
+    A.setdiag(0)
+    A[3, 3], A[17, 17] = 0.8, 1.7  # two self-loops in the directed graph too
+    Wd = sparse.csr_matrix(A)
+    Wd.eliminate_zeros()
+    B = sparse.random(n, n, 0.05, random_state=6, format="csr")
+    Wu = sparse.lil_matrix(B + B.T)
+    Wu[5, 5], Wu[20, 20], Wu[59, 59] = 1.5, 0.25, 2.0
+    Wu = sparse.csr_matrix(Wu)
+    x, X4 = rng.standard_normal(n), rng.standard_normal((n, 4))
+    out["x"], out["X4"] = x, X4
+    for name, W in (("dir", Wd), ("loops", Wu)):
+        out.update(csr_parts(W, "W" + name))
+        for lt in ("combinatorial", "normalized"):
+            G = graphs.Graph(W, lap_type=lt)
+            assert G.is_directed() == (name == "dir")
+            G.compute_differential_operator()
+            src, dst, w = G.get_edge_list()
+            key = "{}_{}".format(name, lt)
+            out["src_" + name], out["dst_" + name], out["w_" + name] = src, dst, w
+            out["ne_" + name] = np.int64(G.n_edges)
+            out["dw_" + name] = G.dw
+            out["D_" + key] = G.D.toarray()
+            out["L_" + key] = G.L.toarray()
+            out["grad_" + key], out["grad4_" + key] = G.grad(x), G.grad(X4)
+            out["div_" + key], out["div4_" + key] = G.div(G.grad(x)), G.div(G.grad(X4))
+    np.savez_compressed(os.path.join(OUT, "ops_directed.npz"), **out)
+
+
 def knn():
     """NNGraph (nngraph.py:113-297) on small point clouds, Sensor variants."""
     out = {}
@@ -277,6 +314,7 @@ if __name__ == "__main__":
     doctest_sensor30()
     laplacians4()
     ops_sensor123()
+    ops_directed()
     knn()
     knn_highdim()
     for f in sorted(os.listdir(OUT)):

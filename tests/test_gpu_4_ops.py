@@ -178,17 +178,77 @@ def test_ragged_graph_and_errors(ctx):
         with pytest.raises(ValueError):
             G.dirichlet_energy(X[:-1])
     Gd = graphs.Graph(sparse.csr_matrix(np.array([[0, 2, 0], [0, 0, 1], [0, 0, 0.0]])))
-    with pytest.raises(NotImplementedError):
-        Gd.compute_differential_operator()
-    with pytest.raises(NotImplementedError):
-        Gd.grad(np.ones(3))
     assert abs(Gd.dirichlet_energy([0.0, 1.0, 3.0]) - ops.dirichlet_energy(ops.laplacian(Gd.W), np.array([0, 1, 3.0]))) < 1e-14
-    Gl = graphs.Graph(np.array([[1, 2, 0], [2, 0, 1], [0, 1, 0.0]]))
-    with pytest.raises(NotImplementedError):
-        Gl.compute_differential_operator()
     # a graph uploaded as a Laplacian carries no degrees: no differential operator
     dev = engine.DeviceGraph.from_l(ops.laplacian(Wr), ctx=ctx)
     with pytest.raises(ValueError):
         dev.n_edges()
     assert np.max(np.abs(dev.laplacian_apply(np.ones(5000)))) < 1e-12  # L 1 = 0
     dev.destroy()
+
+
+def test_doctest_values_directed():
+    """difference.py:120-138: the directed 3-vertex example, both Laplacian types."""
+    G = graphs.Graph([[0, 2, 0], [2, 0, 1], [0, 0, 0]])
+    assert G.is_directed() and G.Ne == 3
+    G.compute_differential_operator()
+    np.testing.assert_allclose(G.D.toarray(), [[-1, 1, 0], [1, -1, -0.70710678], [0, 0, 0.70710678]], atol=1e-8)
+    G.compute_laplacian("normalized")
+    G.compute_differential_operator()
+    np.testing.assert_allclose(G.D.toarray(), [[-0.70710678, 0.70710678, 0], [0.63245553, -0.63245553, -0.4472136],
+                                               [0, 0, 1]], atol=1e-7)
+    # L = D D^T also for directed graphs (difference.py:31)
+    assert abs(G.D.dot(G.D.T) - G.L).max() < 1e-14
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_golden_directed_and_self_loops(dtype):
+    """difference.py:160-166 against the real reference (tests/golden/ops_directed.npz): D, grad, div of a directed
+    weighted graph (every stored entry an edge, values / sqrt(2)) and of an undirected graph with self-loops (their
+    stored zeros eliminated) - the edge list handed to the device, the D values formed there from its degrees."""
+    from conftest import load_golden
+    g = load_golden("ops_directed.npz")
+    tol = TOL[np.dtype(dtype)]
+    x, X4 = g["x"], g["X4"]
+    for name in ("dir", "loops"):
+        W = csr_from(g, "W" + name)
+        for lt in ("combinatorial", "normalized"):
+            key = "{}_{}".format(name, lt)
+            G = graphs.Graph(W, lap_type=lt, compute_dtype=dtype)
+            assert G.is_directed() == (name == "dir") and G.Ne == int(g["ne_" + name])
+            assert rel_err(G.dw, g["dw_" + name]) < tol and rel_err(G.L.toarray(), g["L_" + key]) < tol
+            G.compute_differential_operator()
+            assert G.D.shape == g["D_" + key].shape and rel_err(G.D.toarray(), g["D_" + key]) < tol
+            assert G.D.nnz == np.count_nonzero(g["D_" + key])  # the self-loops' zeros are not stored
+            assert rel_err(G.grad(x), g["grad_" + key]) < tol and rel_err(G.grad(X4), g["grad4_" + key]) < tol
+            assert rel_err(G.div(g["grad_" + key]), g["div_" + key]) < tol
+            assert rel_err(G.div(g["grad4_" + key]), g["div4_" + key]) < tol
+            src, dst, w = G.device_graph().edge_list()
+            np.testing.assert_array_equal(src, g["src_" + name])
+            np.testing.assert_array_equal(dst, g["dst_" + name])
+            with pytest.raises(ValueError):
+                G.div(np.ones(G.Ne + 1))
+        # switching the Laplacian type rebuilds the device graph: the edge list follows it
+        G.compute_laplacian("combinatorial")
+        assert rel_err(G.grad(x), g["grad_{}_combinatorial".format(name)]) < tol
+
+
+def test_directed_graph_at_size_against_the_oracle(ctx):
+    """A directed random graph of 30k vertices (ragged rows, a hub), 6 signals: grad / div against the oracle's D;
+    edge lists that are not in get_edge_list order are refused."""
+    rng = np.random.default_rng(9)
+    A = sparse.random(30000, 30000, 2e-4, random_state=4, format="csr")
+    A.setdiag(0)
+    A.eliminate_zeros()
+    G = graphs.Graph(A)
+    assert G.is_directed()
+    D = ops.differential_operator(A)
+    X = rng.standard_normal((G.N, 6))
+    assert rel_err(G.grad(X), ops.grad(D, X)) < 1e-12
+    Y = rng.standard_normal((G.Ne, 6))
+    assert rel_err(G.div(Y), ops.div(D, Y)) < 1e-12
+    src, dst, w = G.get_edge_list()
+    with pytest.raises(ValueError):
+        G.device_graph().set_edge_list(src[::-1], dst[::-1], w[::-1], True)
+    with pytest.raises(ValueError):
+        G.device_graph().set_edge_list(src, dst + G.N, w, True)

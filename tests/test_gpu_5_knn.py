@@ -191,8 +191,82 @@ def test_sbm_sampler_distribution(ctx):
     assert abs(c2[0, 1] - 0.1 * 150 * 150) < 5 * np.sqrt(0.09 * 150 * 150)
     with pytest.raises(ValueError):
         engine.sbm_graph(z, np.array([[2.0]]), ctx=ctx)
-    with pytest.raises(NotImplementedError):
-        graphs.StochasticBlockModel(100, directed=True)
+
+
+def test_sbm_sampler_directed_self_loops_connected(ctx):
+    """The other switches of stochasticblockmodel.py:69-72, 125-157, as distributions: directed (every ORDERED pair
+    an entry of its own, asymmetric M allowed), self_loops (pairs r == c take part; an undirected loop is one
+    entry), connected (fresh samples until one is connected, ValueError after n_try)."""
+    rng = np.random.default_rng(1)
+    N, k = 40000, 3
+    z = np.sort(rng.integers(0, k, N))
+    sizes = np.bincount(z, minlength=k).astype(np.float64)
+    M = np.array([[4e-4, 3e-5, 0], [6e-5, 5e-4, 2e-5], [1e-5, 0, 3e-4]])  # not symmetric
+    with pytest.raises(ValueError):
+        engine.sbm_graph(z, M, seed=1, ctx=ctx)  # undirected graphs need a symmetric M
+
+    def ordered_counts(W):
+        coo = W.tocoo()
+        off = coo.row != coo.col
+        m = np.zeros((k, k))
+        np.add.at(m, (z[coo.row[off]], z[coo.col[off]]), 1)
+        return m, int(np.count_nonzero(~off)), np.bincount(z[coo.row[~off]], minlength=k)
+
+    # directed, no self-loops: ordered pairs (r, c), r != c, each with probability M[z_r, z_c]
+    W, _ = engine.sbm_graph(z, M, seed=7, ctx=ctx, directed=True)
+    assert W.has_sorted_indices and W.data.min() == 1 and W.data.max() == 1 and W.diagonal().max() == 0
+    pairs = np.outer(sizes, sizes) - np.diag(sizes)
+    cnt, loops, _ = ordered_counts(W)
+    mean, sd = pairs * M, np.sqrt(pairs * M * (1 - M))
+    assert loops == 0 and (np.abs(cnt - mean) <= 5 * sd + 1e-9).all(), (cnt, mean)
+    assert (cnt[M == 0] == 0).all() and abs(W - W.T).nnz > 0
+    both = W.multiply(W.T).nnz  # reciprocated pairs: independent, so about sum p_ab p_ba over ordered pairs
+    assert abs(both - np.sum(pairs * M * M.T)) <= 5 * np.sqrt(np.sum(pairs * M * M.T)) + 3
+    W2, _ = engine.sbm_graph(z, M, seed=7, ctx=ctx, directed=True)
+    assert abs(W - W2).max() == 0
+    # directed with self-loops: the diagonal takes part with probability M[a, a]
+    W, _ = engine.sbm_graph(z, M, seed=8, ctx=ctx, directed=True, self_loops=True)
+    cnt, loops, per_block = ordered_counts(W)
+    assert (np.abs(cnt - mean) <= 5 * sd + 1e-9).all()
+    lm = sizes * np.diag(M)
+    assert (np.abs(per_block - lm) <= 5 * np.sqrt(lm) + 1e-9).all() and loops == per_block.sum()
+    # undirected with self-loops: symmetric, every loop stored once
+    Ms = (M + M.T) / 2
+    W, _ = engine.sbm_graph(z, Ms, seed=9, ctx=ctx, self_loops=True)
+    assert abs(W - W.T).max() == 0 and W.data.max() == 1
+    cnt, loops, per_block = ordered_counts(W)
+    up = np.outer(sizes, sizes)
+    up[np.diag_indices(k)] = sizes * (sizes - 1) / 2
+    und = cnt + cnt.T  # both triangles were counted: every unordered pair twice
+    und[np.diag_indices(k)] = np.diag(cnt)
+    und = und / 2
+    assert (np.abs(und - up * Ms) <= 5 * np.sqrt(up * Ms * (1 - Ms)) + 1e-9).all()
+    lm = sizes * np.diag(Ms)
+    assert (np.abs(per_block - lm) <= 5 * np.sqrt(lm) + 1e-9).all()
+    # dense, tiny: p = 1 gives every ordered pair (and every loop)
+    Wd, _ = engine.sbm_graph(np.zeros(50, dtype=np.int64), np.array([[1.0]]), seed=1, ctx=ctx, directed=True)
+    assert Wd.nnz == 50 * 49
+    Wd, _ = engine.sbm_graph(np.zeros(50, dtype=np.int64), np.array([[1.0]]), seed=1, ctx=ctx, directed=True,
+                             self_loops=True)
+    assert Wd.nnz == 50 * 50
+    Wd, _ = engine.sbm_graph(np.zeros(50, dtype=np.int64), np.array([[1.0]]), seed=1, ctx=ctx, self_loops=True)
+    assert Wd.nnz == 50 * 50 and abs(Wd - Wd.T).max() == 0
+    # the generator classes: directed graphs take the host route of Graph.__init__ (symmetrised Laplacian)
+    G = graphs.StochasticBlockModel(3000, k=3, p=0.02, q=0.002, directed=True, seed=2)
+    assert G.is_directed() and G.Ne == G.W.nnz and G.W.dtype == np.int64 and G.W.diagonal().max() == 0
+    assert list(G.info) == ["node_com", "comm_sizes", "world_rad"] and G.info["comm_sizes"].sum() == 3000
+    G = graphs.ErdosRenyi(2000, p=0.01, self_loops=True, seed=3)
+    assert not G.is_directed() and G.W.diagonal().sum() > 0
+    assert G.Ne == (G.W.nnz - np.count_nonzero(G.W.diagonal())) // 2 + np.count_nonzero(G.W.diagonal())
+    # connected=True: a dense enough model is connected at the first try, a sparse one never is
+    G = graphs.ErdosRenyi(3000, p=0.01, connected=True, seed=4)
+    assert G.is_connected() and G.connected
+    G = graphs.StochasticBlockModel(2000, k=2, p=0.02, q=0.002, directed=True, connected=True, n_try=20, seed=5)
+    assert G.is_connected() and G.is_directed()
+    with pytest.raises(ValueError, match="could not be connected after 3 trials"):
+        graphs.ErdosRenyi(3000, p=1e-4, connected=True, n_try=3, seed=6)
+    assert graphs.Graph(np.array([[0, 3, 0, 0], [3, 0, 4, 0], [0, 4, 0, 2], [0, 0, 2, 0.0]])).is_connected()
+    assert not graphs.Graph(np.array([[0, 3, 0, 0], [3, 0, 4, 0], [0, 0, 0, 2], [0, 0, 2, 0.0]])).is_connected()
     G = graphs.StochasticBlockModel(2000, k=3, seed=7)       # defaults p = 0.7, q = 0.1
     assert G.W.shape == (2000, 2000) and np.array_equal(G.z, np.sort(np.random.default_rng(7).integers(0, 3, 2000)))
 

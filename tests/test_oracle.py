@@ -168,6 +168,30 @@ def test_ops_sensor123(golden_ops):
         assert abs(D.dot(D.T) - L).max() < 1e-13
 
 
+def test_ops_directed_and_self_loops():
+    """difference.py:160-166 through the oracle against the real reference (tests/golden/ops_directed.npz): a
+    directed weighted graph (every stored entry an edge, D / sqrt(2)) and an undirected one with self-loops."""
+    g = load_golden("ops_directed.npz")
+    x, X4 = g["x"], g["X4"]
+    for name in ("dir", "loops"):
+        W = csr_from(g, "W" + name)
+        src, dst, w = ops.get_edge_list(W)
+        np.testing.assert_array_equal(src, g["src_" + name])
+        np.testing.assert_array_equal(dst, g["dst_" + name])
+        np.testing.assert_array_equal(w, g["w_" + name])
+        assert src.size == int(g["ne_" + name]) and np.all(np.diff(src) >= 0)
+        np.testing.assert_allclose(ops.degree(W), g["dw_" + name], rtol=1e-15)
+        for lt in ("combinatorial", "normalized"):
+            key = "{}_{}".format(name, lt)
+            D = ops.differential_operator(W, lt)
+            np.testing.assert_allclose(D.toarray(), g["D_" + key], rtol=0, atol=1e-15)
+            np.testing.assert_allclose(ops.laplacian(W, lt).toarray(), g["L_" + key], rtol=0, atol=1e-15)
+            assert rel_err(ops.grad(D, x), g["grad_" + key]) < 1e-15
+            assert rel_err(ops.grad(D, X4), g["grad4_" + key]) < 1e-15
+            assert rel_err(ops.div(D, ops.grad(D, x)), g["div_" + key]) < 1e-15
+            assert rel_err(ops.div(D, ops.grad(D, X4)), g["div4_" + key]) < 1e-15
+
+
 def test_ops_tikhonov(golden_ops):
     g = golden_ops
     L = ops.laplacian(csr_from(g, "W"))
