@@ -327,6 +327,8 @@ struct Options {
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
                                 // (a single signal only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
+  int64_t tile_regroup = 1;     // 1: rows of 3 / 5 / 6 / 7 / 10 / 12 / 14 sixteen-byte pieces run the builds whose compute
+                                // phases regroup the lanes by pieces (k_step_tile<..., CL>); 0: the power-of-two builds
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
@@ -559,6 +561,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
+  if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
   if (!strcmp(key, "tile_min_row")) return &o.tile_min_row;
   if (!strcmp(key, "tile_pad")) return &o.tile_pad;
   if (!strcmp(key, "knn_f32")) return &o.knn_f32;
@@ -1737,8 +1740,26 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
        k_step_tile<T, 1, 4, true, false, 256>, k_step_tile<T, 1, 8, true>},
       {k_step_tile<T, 1, 1, false, true, 64>, k_step_tile<T, 1, 2, false, true, 128>,
        k_step_tile<T, 1, 4, false, true, 256>, k_step_tile<T, 1, 8, false, true>}};
-  const kern_t kern = narrow ? slim[flavour][lg == 1 ? 0 : lg == 2 ? 1 : lg == 4 ? 2 : 3] : wide[flavour][ncol <= 2 ? ncol : 0];
-  const unsigned threads = narrow ? 64u * (unsigned)lg : 512u;
+  kern_t kern = narrow ? slim[flavour][lg == 1 ? 0 : lg == 2 ? 1 : lg == 4 ? 2 : 3] : wide[flavour][ncol <= 2 ? ncol : 0];
+  unsigned threads = narrow ? 64u * (unsigned)lg : 512u;
+  // rows of fewer 16-byte pieces than the lanes they are staged with: the builds whose compute phases regroup the
+  // threads by pieces (template parameter CL), in workgroups of 64 x pieces (one row per group) or 32 x pieces (two
+  // rows) threads.  Measured per piece count, A/B on one box (profiles/r04_regroup_ab*.json): 3 pieces (48-byte rows:
+  // 5 / 6 fp64, 10 / 12 fp32 signals) +6...8 %, 5 pieces (80 bytes: 10 fp64) +2.5 %, 10 pieces (160 bytes: 20 fp64)
+  // +6 %; 6, 7, 12 and 14 pieces -2...0 % (idle compute lanes are not what bounds those passes) - they keep the
+  // power-of-two builds.
+  const int pieces = (int)(rowb / 16);
+  if (opt.tile_regroup && ncol == 1 && flavour != 1 && pieces < lg) {
+#define GSPX_CL(LG_, CL_, NT_) \
+  (flavour == 2 ? (kern_t)k_step_tile<T, 1, LG_, false, true, NT_, CL_> : (kern_t)k_step_tile<T, 1, LG_, false, false, NT_, CL_>)
+    kern_t k2 = nullptr;
+    unsigned nt2 = 0;
+    if (lg == 4 && pieces == 3) k2 = GSPX_CL(4, 3, 192), nt2 = 192;
+    else if (lg == 8 && pieces == 5) k2 = GSPX_CL(8, 5, 320), nt2 = 320;
+    else if (lg == 16 && pieces == 10) k2 = GSPX_CL(16, 10, 320), nt2 = 320;
+#undef GSPX_CL
+    if (k2) kern = k2, threads = nt2;
+  }
   // dynamic LDS: the wide builds take the tile budget the blocks were classified with; a narrow build's tile
   // rows are 16 lg bytes, so the largest staged block needs far less - and more workgroups fit a CU
   size_t lds = g->gt_lds;

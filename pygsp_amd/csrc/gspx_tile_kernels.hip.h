@@ -94,9 +94,19 @@ template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
 // that the analysis path does not carry their registers across the row products
 // (A bound of five waves per SIMD for the 4-lane build - five resident workgroups instead of four - costs 20-50
 // bytes of scratch and 20 % of the fp64 build's speed: measured, dropped.)
-template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false, int NT = 512>
+// CL: lanes of a row group in the COMPUTE phases (row products, T_{k-2} / accumulator loads, stores), when a row
+// has fewer 16-byte pieces than the LG lanes its tile rows are staged with (rows of 80 - 240 bytes that are not a
+// power of two: 10 / 12 / 24 fp64 signals ...).  The LDS-DMA keeps its LG-lane layout (a wave instruction writes
+// 64 / LG tile rows of 16 LG bytes, the lanes beyond the row switched off by the bounds check); the compute phases
+// regroup the workgroup's NT = CL x (groups) threads into CL-lane groups, so every lane holds a piece of a row -
+// with LG-lane groups a quarter to three eighths of the lanes idled through every row product.  CL == LG: as before.
+// (two resident workgroups of 320 / 384 threads are 10 / 12 waves per CU, three per SIMD: those builds may use 168
+// registers; their longer row lists per staging group - 8 / 7 instead of 5 - would spill at 128)
+template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false, int NT = 512, int CL = LG>
 __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
-  static_assert(NT == 512 || (NT == 64 * LG && NCOL == 1), "narrow builds: one row per group, one chunk per row");
+  static_assert(NT == 512 || (NT == 64 * LG && NCOL == 1) || (CL < LG && NCOL == 1 && NT % 64 == 0 && NT % CL == 0),
+                "narrow builds: one row per group, one chunk per row");
+  static_assert(CL <= LG && (GSPX_TILE_BR % (NT / CL)) == 0, "compute groups must tile the block's rows");
   constexpr bool PF = TileSchedule<T, NCOL, LG, OLDNAT>::PF;
   constexpr bool META_AFTER = TileSchedule<T, NCOL, LG, OLDNAT>::META_AFTER;
   constexpr bool TILE_LAST = TileSchedule<T, NCOL, LG, OLDNAT>::TILE_LAST;
@@ -107,13 +117,16 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gspx_smem[];
 
   const int tid = threadIdx.x;
-  constexpr int NG = NT / LG;              // row groups per workgroup
-  constexpr int NE = 512 / NT;             // 16-byte pieces of matrix values a thread prefetches
-  constexpr int RPG = GSPX_TILE_BR / NG;   // rows of the block per group
-  constexpr int ST = (GSPX_TILE_MAXN1 + NG - 1) / NG;  // tile rows a group stages
+  constexpr int NGD = NT / LG;             // staging (LDS-DMA) groups per workgroup: LG lanes each
+  constexpr int NG = NT / CL;              // compute row groups per workgroup: CL lanes each
+  constexpr int NE = (512 + NT - 1) / NT;  // 16-byte pieces of matrix values a thread prefetches
+  constexpr int RPG = GSPX_TILE_BR / NG;   // rows of the block per compute group
+  constexpr int ST = (GSPX_TILE_MAXN1 + NGD - 1) / NGD;  // tile rows a staging group loads
   constexpr int RB = LG * 16;              // bytes of a tile row
-  const int lane16 = tid & (LG - 1);
-  const int grp = tid / LG;
+  const int lane_d = tid & (LG - 1);       // staging lane / group
+  const int grp_d = tid / LG;
+  const int lane16 = CL == LG ? lane_d : tid % CL;  // compute lane / group
+  const int grp = CL == LG ? grp_d : tid / CL;
   const int wave = tid >> 6;
   const int nwx = (int)(gridDim.x >> 3);
   const int xlo = (int)(blockIdx.x & 7) * a.per_xcd;
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
     const int n1 = h.y;
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
-      const int u = grp + NG * t;
+      const int u = grp_d + NGD * t;
       m.rows[t] = a.s1rows[h.x + (u < n1 ? u : 0)];
     }
     int r = phys(k) * GSPX_TILE_BR + grp * RPG;
@@ -163,12 +176,16 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   auto stage = [&](const Meta& m, int n1, u32 cb) {
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
-      if (grp + NG * t < n1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rcur, (lds_ptr)(gspx_smem + (wave * (64 / LG) + NG * t) * RB), 16,
+      if (grp_d + NGD * t < n1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rcur, (lds_ptr)(gspx_smem + (wave * (64 / LG) + NGD * t) * RB), 16,
                                                  (u32)m.rows[t] * ldb + cb, 0, 0, 0);
     }
   };
-  auto chunk_off = [&](int c) {
+  auto chunk_off_d = [&](int c) {  // the staging lane's piece of column chunk c
+    const u32 col0 = (c * LG + lane_d) * VEC;
+    return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
+  };
+  auto chunk_off = [&](int c) {    // the compute lane's
     const u32 col0 = (c * LG + lane16) * VEC;
     return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
   };
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   int k = k0, kn = k0 + nwx, knn = k0 + 2 * nwx;
   int4 Hn = uniform(load_hdr(kn < k1 ? kn : k0));
   if constexpr (!TILE_LAST) {
-    if (H.y >= 0) stage(M, H.y, chunk_off(0));
+    if (H.y >= 0) stage(M, H.y, chunk_off_d(0));
   }
   if constexpr (PF) prefetch_rows(M, k0, 0);
   if constexpr (PF_ENTRIES) {
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   }
   if constexpr (TILE_LAST) {  // the tile last, as inside the loop
     __builtin_amdgcn_sched_barrier(0);
-    if (H.y >= 0) stage(M, H.y, chunk_off(0));
+    if (H.y >= 0) stage(M, H.y, chunk_off_d(0));
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
       for (int q = 0; q < NE; ++q)
         if (tid + q * NT < nv16) *(u32x4*)((unsigned char*)mval + (tid + q * NT) * 16) = ev[q];
       if (tid < ni16) *(u32x4*)((unsigned char*)midx + tid * 16) = ei;
-      for (int i = tid + 512; i < nv16; i += NT)  // slices longer than 8 KiB of values: rare
+      for (int i = tid + NE * NT; i < nv16; i += NT)  // slices longer than 8 KiB of values: rare
         *(u32x4*)((unsigned char*)mval + i * 16) =
             __builtin_amdgcn_raw_buffer_load_b128(rv, (u32)rp0 * (u32)sizeof(T) + i * 16u, 0, 0);
       for (int i = tid + NT; i < ni16; i += NT)
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!PF) {  // next pass's tile: the next chunk of this block, or chunk 0 of the next block
-      if (more && H.y >= 0) stage(M, H.y, chunk_off(last ? 0 : c + 1));
+      if (more && H.y >= 0) stage(M, H.y, chunk_off_d(last ? 0 : c + 1));
     }
     // this pass's results (with PF: before the loads below, so that they are out of the way of the next
     // barrier's wait), ...
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
       if (more) {
         const int nc = last ? 0 : c + 1;
         if constexpr (!TILE_LAST) {
-          if (H.y >= 0) stage(M, H.y, chunk_off(nc));
+          if (H.y >= 0) stage(M, H.y, chunk_off_d(nc));
         }
         prefetch_rows(M, last ? kn : k, nc);
         if constexpr (PF_ENTRIES) {
@@ -383,7 +400,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
         }
         if constexpr (TILE_LAST) {  // the tile last: see the first barrier
           __builtin_amdgcn_sched_barrier(0);
-          if (H.y >= 0) stage(M, H.y, chunk_off(nc));
+          if (H.y >= 0) stage(M, H.y, chunk_off_d(nc));
           __builtin_amdgcn_sched_barrier(0);
         }
       }

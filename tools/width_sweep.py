@@ -27,17 +27,24 @@ def main():
         dev = G.device_graph()
         elt = np.dtype(dtype).itemsize
         x = np.random.default_rng(0).standard_normal((G.N, 64)).astype(dtype)
-        for w in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64):
+        widths = [int(v) for v in os.environ.get("WIDTHS", "1,2,3,4,5,6,8,10,12,16,24,32,48,64").split(",")]
+        ab = os.environ.get("AB")  # an option measured at 0 and at 1 for every width, alternating (e.g. AB=tile_regroup)
+        for w in widths:
             xs = np.ascontiguousarray(x[:, :w])
             bx, by = ctx.upload(xs), ctx.alloc(xs.nbytes)
-            ms = [dev.cheby_filter_dev(c, bx.ptr, by.ptr, w, float(G.lmax)) for _ in range(12)]
-            t = ctx.last_timing()
-            best = float(np.median(ms[3:]))
-            U = G.N * w * elt
-            b_alg = K * (dev.nnz_l * (elt + 4) + 4 * (G.N + 1) + 3 * U) + U
-            rows.append({"dtype": np.dtype(dtype).name, "signals": w, "row_bytes": w * elt, "ms": best,
-                         "ms_per_signal": best / w, "alg_GB": b_alg / 1e9, "frac_8TBs": b_alg / (best * 1e-3) / 8e12,
-                         "steps_ms": t["steps_ms"], "step_launches": t["step_launches"]})
+            for setting in ((0, 1, 0, 1) if ab else (None,)):
+                if ab:
+                    ctx.set_option(ab, setting)
+                ms = [dev.cheby_filter_dev(c, bx.ptr, by.ptr, w, float(G.lmax)) for _ in range(12)]
+                t = ctx.last_timing()
+                best = float(np.median(ms[3:]))
+                U = G.N * w * elt
+                b_alg = K * (dev.nnz_l * (elt + 4) + 4 * (G.N + 1) + 3 * U) + U
+                rows.append({"dtype": np.dtype(dtype).name, "signals": w, "row_bytes": w * elt, "ms": best,
+                             "ms_per_signal": best / w, "alg_GB": b_alg / 1e9, "frac_8TBs": b_alg / (best * 1e-3) / 8e12,
+                             "steps_ms": t["steps_ms"], "step_launches": t["step_launches"]})
+                if ab:
+                    rows[-1][ab] = setting
             bx.free()
             by.free()
         G.__dict__.pop("_dev", None)
