@@ -198,6 +198,22 @@ int gspx_graph_download_perm(gspx_graph* g, int32_t* perm);
  * np.identity(N)) produced where it is consumed. */
 int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int64_t w, void* out_dev);
 
+/* TWO orders of the three-term recurrence per launch (opt-in experiment of round 4): the tile
+ * data of pygsp_amd/tiling.py (levels = 2) for blocks of 64 / 128 / 256 rows of the graph's internal order - per
+ * block the row lists of its 1-hop (S1) and 2-hop (S2) closures, per stored entry of a block row its position in
+ * S1 (lidx1, 0xFFFF for pads), per (block, S1 row) occurrence where that row's entries' positions in S2 start in
+ * lidx2.  block_rows == 0 drops the tiles.  stats (may be NULL): blocks, largest S1, largest S2, most entries of
+ * a block's S1 rows, of its own rows, entries of lidx2. */
+int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr, const int32_t* s1rows,
+                                   const int32_t* s2ptr, const int32_t* s2rows, const uint16_t* lidx1,
+                                   const uint32_t* occ_off, int64_t n_lidx2, const uint16_t* lidx2, int64_t stats[6]);
+/* cheby_op (approximations.py:58-114) for ONE filter of even order M - 1 with those tiles: (M - 1) / 2 launches,
+ * each computing T_k on the block's 1-hop closure in LDS and T_{k+1} on its rows; column chunks of chunk_lanes
+ * (2 / 4 / 8 / 16) x 16 bytes.  x_dev, y_dev: N x Nsig row-major in the graph's own vertex order, rows of whole
+ * 16-byte pieces.  Same result as gspx_cheby_filter_dev up to the association order of the final sum. */
+int gspx_cheby_pair_filter_dev(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig,
+                               const void* x_dev, void* y_dev, int chunk_lanes, double* kernel_ms);
+
 /* PCI address ("0000:c1:00.0", NUL-terminated) of HIP device `device`: what a host driver needs to find the NUMA
  * node the GPU hangs off (/sys/bus/pci/devices/<address>/numa_node) and pin the thread - and the packing threads
  * libgspx starts from it - that feeds this GPU to the cores next to it (pygsp_amd.multi). */

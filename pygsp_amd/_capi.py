@@ -121,6 +121,9 @@ SIGNATURES = {
     "gspx_identity_panel_dev": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "gspx_planes_pack_dev": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _c.c_int]),
     "gspx_device_pci_bus_id": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_int]),
+    "gspx_graph_set_cheb_pair_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P, _P]),
+    "gspx_cheby_pair_filter_dev": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _c.c_int64, _P, _P, _c.c_int,
+                                              _c.POINTER(_c.c_double)]),
     "gspx_comm_available": (_c.c_int, []),
     "gspx_comm_unique_id": (_c.c_int, [_P]),
     "gspx_comm_create": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _c.POINTER(_P)]),

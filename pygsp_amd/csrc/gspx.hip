@@ -327,6 +327,7 @@ struct Options {
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
                                 // (a single signal only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
+  int64_t pair_workgroups_per_cu = 0;  // two-orders-per-launch kernel: at most that many resident workgroups per CU (0: what fits)
   int64_t tile_regroup = 1;     // 1: rows of 3 / 5 / 6 / 7 / 10 / 12 / 14 sixteen-byte pieces run the builds whose compute
                                 // phases regroup the lanes by pieces (k_step_tile<..., CL>); 0: the power-of-two builds
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
@@ -369,7 +370,7 @@ struct gspx_ctx {
   std::vector<struct gspx_comm*> comms;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev_pool;
-  double timing[5] = {0, 0, 0, 0, 0};
+  double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [5], [6]: LDS bytes / resident workgroups of the last pair-filter call
   // hipGraph replay of a repeated identical filter call (launch-bound small graphs)
   bool capturing = false;     // run_batch is being recorded: no copies, syncs or events inside
   // identity of a call = the full tuple of everything the recorded launches depend on, compared
@@ -398,6 +399,14 @@ struct gspx_buf {
 };
 
 static std::atomic<uint64_t> g_generation{1};  // handles are told apart by birth number, not by address
+
+// two-level row tiles of the two-orders-per-launch recurrence kernel (optional; gspx_chebpair.hip.h)
+struct ChebPairTiles {
+  DevMem hdr, desc, s2rows, lidx1, lidx2, src, val2, ownpos;
+  int rows = 0, nb = 0, n1max = 0, n2max = 0, e1max = 0, e2max = 0;
+  int64_t total2 = 0;
+  double val_lmax = -1.0;  // lmax the gathered factor values val2 were built for
+};
 
 struct gspx_graph {
   gspx_ctx* ctx = nullptr;
@@ -438,6 +447,7 @@ struct gspx_graph {
   bool edges_built = false;
   int64_t n_edges = 0;
   DevMem e_off, e_toff, e_src, e_dst, e_tedge, e_cs, e_ct, e_w;
+  ChebPairTiles cp;
 };
 
 static size_t elt_size(int dtype) { return dtype == GSPX_F32 ? 4 : 8; }
@@ -562,6 +572,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
   if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
+  if (!strcmp(key, "pair_workgroups_per_cu")) return &o.pair_workgroups_per_cu;
   if (!strcmp(key, "tile_min_row")) return &o.tile_min_row;
   if (!strcmp(key, "tile_pad")) return &o.tile_pad;
   if (!strcmp(key, "knn_f32")) return &o.knn_f32;
@@ -2981,3 +2992,4 @@ extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double*
 #include "gspx_ops.hip.h"
 #include "gspx_knn.hip.h"
 #include "gspx_setup.hip.h"
+#include "gspx_chebpair.hip.h"

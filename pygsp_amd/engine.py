@@ -883,6 +883,37 @@ def _newton_methods():
     def disable_gather_tiles(self):
         _capi.check(_capi.load().gspx_graph_set_gather_tiles(self._h, 0, 0, None, None, None, None))
 
+    def enable_cheb_pair_tiles(self, block_rows=128):
+        """Build (numpy, pygsp_amd/tiling.py) and upload the two-level tiles of the two-orders-per-launch
+        recurrence kernel (gspx_graph_set_cheb_pair_tiles; opt-in experiment).  Returns the tile statistics.
+        A graph set-up step: seconds at N = 1M."""
+        from . import tiling
+        rp, col = self.download_internal()
+        t = tiling.build_tiles(rp, col, self.N, int(block_rows))
+        c = np.ascontiguousarray
+        stats = np.zeros(6, dtype=np.int64)
+        _capi.check(_capi.load().gspx_graph_set_cheb_pair_tiles(
+            self._h, int(block_rows), t["nb"], _capi.ptr(c(t["s1ptr"])), _capi.ptr(c(t["s1rows"])),
+            _capi.ptr(c(t["s2ptr"])), _capi.ptr(c(t["s2rows"])), _capi.ptr(c(t["lidx1"])), _capi.ptr(c(t["occ_off"])),
+            t["lidx2"].size, _capi.ptr(c(t["lidx2"])), _capi.ptr(stats)))
+        return {"block_rows": int(block_rows), "nb": int(stats[0]), "max_n1": int(stats[1]), "max_n2": int(stats[2]),
+                "max_entries_s1": int(stats[3]), "max_entries_own": int(stats[4]), "entries_level2": int(stats[5]),
+                "mean_n1": t["mean_n1"], "mean_n2": t["mean_n2"]}
+
+    def disable_cheb_pair_tiles(self):
+        _capi.check(_capi.load().gspx_graph_set_cheb_pair_tiles(self._h, 0, 0, None, None, None, None, None, None, 0,
+                                                                None, None))
+
+    def cheby_pair_filter_dev(self, coeffs, x_ptr, y_ptr, nsig, lmax, chunk_lanes=4):
+        """One filter of even order, two recurrence orders per launch (gspx_cheby_pair_filter_dev); device
+        pointers in / out.  Returns device milliseconds of the whole call."""
+        c = np.ascontiguousarray(np.asarray(coeffs, dtype=np.float64).reshape(-1))
+        ms = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_cheby_pair_filter_dev(
+            self._h, float(lmax), c.size, _capi.ptr(c), int(nsig), ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr),
+            int(chunk_lanes), ctypes.byref(ms)))
+        return ms.value
+
     def disable_pair_tiles(self):
         _capi.check(_capi.load().gspx_graph_set_tiles(self._h, 0, 0, None, None, None, None, None,
                                                       None, 0, None, 0, 0))
@@ -896,6 +927,9 @@ def _newton_methods():
     DeviceGraph.auto_gather_tiles = auto_gather_tiles
     DeviceGraph.build_gather_tiles = build_gather_tiles
     DeviceGraph.disable_pair_tiles = disable_pair_tiles
+    DeviceGraph.enable_cheb_pair_tiles = enable_cheb_pair_tiles
+    DeviceGraph.disable_cheb_pair_tiles = disable_cheb_pair_tiles
+    DeviceGraph.cheby_pair_filter_dev = cheby_pair_filter_dev
 
 
 _newton_methods()
