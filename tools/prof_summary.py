@@ -7,6 +7,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+# kernels whose counters are listed (substrings of the kernel name; PROF_KERNELS=a,b,c replaces the default set)
+WANTED = [w for w in os.environ.get("PROF_KERNELS", "k_step,k_permute,k_combine").split(",") if w]
+STATS_ROWS = int(os.environ.get("PROF_STATS_ROWS", "12"))
 
 
 def find(pattern):
@@ -16,7 +19,7 @@ def find(pattern):
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f in find("stats/**/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
-    for r in rows[:12]:
+    for r in rows[:STATS_ROWS]:
         print("{:70.70s} calls={:>6} total_ns={:>12} avg_ns={:>10} pct={}".format(
             r.get("Name", ""), r.get("Calls", ""), r.get("TotalDurationNs", ""),
             r.get("AverageNs", ""), r.get("Percentage", "")))
@@ -48,7 +51,7 @@ for f in find("pmc_*/**/*counter_collection.csv"):
         acc[k][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0) or 0))
     print("--", os.path.relpath(f, out))
     for k, cs in acc.items():
-        if "k_step" not in k and "k_permute" not in k and "k_combine" not in k:
+        if not any(w in k for w in WANTED):
             continue
         for cn, vals in cs.items():
             print("   {:60.60s} {:28s} n={:4d} mean={:.6g}".format(k, cn, len(vals), sum(vals) / len(vals)))
