@@ -312,3 +312,66 @@ def test_graph_keeps_a_device_adjacency_until_w_is_read(monkeypatch):
     downloads.clear()
     H = graphs.Graph(FakeAdjacency(W))
     assert downloads == [1] and H._adj_dev is None and H.n_edges == 2 and built == ["combinatorial"]
+
+
+def test_cube_shape_truth_table():
+    """filters._cube_shape = the shape rules of Filter.filter (filter.py:267-290; SURVEY 8(b) truth table, N = 40) on
+    shapes alone - what the wrapped real Filter.filter and the DeviceArray path decide analysis / synthesis with."""
+    N = 40
+
+    class G:
+        pass
+
+    G.N = N
+    table = [((N,), (N, 1, 1), (N, 1, 1)), ((N, 1), (N, 1, 1), (N, 1, 1)), ((N, 1, 1), (N, 1, 1), (N, 1, 1)),
+             ((N, 4), (N, 4, 1), (N, 4, 1)), ((N, 4, 1), (N, 4, 1), (N, 4, 1)),
+             ((N, 6), (N, 6, 1), (N, 1, 6)), ((N, 1, 6), ValueError, (N, 1, 6)), ((N, 4, 6), ValueError, (N, 4, 6)),
+             ((N, 6, 6), ValueError, (N, 6, 6)), ((N, 6, 1), (N, 6, 1), (N, 6, 1)), ((N, 4, 3), ValueError, ValueError),
+             ((N, 2, 2, 1), ValueError, ValueError), ((N + 1,), ValueError, ValueError), ((), ValueError, ValueError),
+             ((N, 0), (N, 0, 1), (N, 0, 1))]
+    for shape, one, six in table:
+        for nf, expect in ((1, one), (6, six)):
+            if expect is ValueError:
+                with pytest.raises(ValueError):
+                    filters._cube_shape(G, nf, shape)
+            else:
+                assert filters._cube_shape(G, nf, shape) == expect, (shape, nf)
+    with pytest.raises(ValueError, match="At most 3 dimensions"):
+        filters._cube_shape(G, 1, (N, 2, 2, 1))
+    with pytest.raises(ValueError, match="First dimension must be the number of vertices"):
+        filters._cube_shape(G, 6, (N + 1, 6))
+    with pytest.raises(ValueError, match="Third dimension"):
+        filters._cube_shape(G, 6, (N, 4, 3))
+    # _shape_of never touches the data of an object that carries its shape (a DeviceArray would be downloaded)
+
+    class Shaped:
+        shape = (N, 3)
+
+        def __array__(self, *a, **k):
+            raise AssertionError("downloaded")
+
+    assert filters._shape_of(Shaped()) == (N, 3) and filters._shape_of([[1, 2], [3, 4]]) == (2, 2)
+
+
+def test_device_array_views_without_a_device():
+    """engine.DeviceArray's shape bookkeeping (no device needed: a stand-in buffer): cube vs squeezed shape, the
+    as-given shape of an upload, and that a tensor is handed out as-is when the call reads it the way it is stored."""
+    class Buf:
+        ctx = object()
+        nbytes = 0
+
+        def free(self):
+            self.freed = True
+
+    a = engine.DeviceArray(Buf(), (40, 1, 6), np.float64)
+    assert a.shape == (40, 6) and a.ndim == 2 and a.size == 240 and a.nbytes == 1920 and len(a) == 40
+    b = engine.DeviceArray(Buf(), (40, 5, 1), np.float32)
+    assert b.shape == (40, 5) and b.nbytes == 800
+    assert engine.DeviceArray(Buf(), (40, 1, 1), np.float64).shape == (40,)
+    with pytest.raises(ValueError):
+        a.planes(4, 2)  # 6 elements per vertex cannot be read as 4 x 2
+    buf = a._buf
+    a.free()
+    assert buf.freed and a._buf is None
+    with pytest.raises(ValueError):
+        a.ptr
