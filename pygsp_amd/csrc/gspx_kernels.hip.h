@@ -1485,6 +1485,41 @@ __global__ void k_internal_build(const int* __restrict__ lptr, const int* __rest
   }
   const int o = rptr[i];  // multiple of 4 (every row length is)
   rptr[i] = o | (npad - n);  // low 2 bits: number of pad entries closing this row
+  // Rows of at most CAP entries (all but hubs): read once into registers, every entry's final position - the
+  // diagonal first, the others by ascending internal column - is its rank among the row's entries (CAP^2 predicated
+  // compares on registers), written once.  (The insertion sort in global memory below cost 5.2 GB of traffic for
+  // 130 MB of matrix at N = 1M: profiles/r04_setup_hostpipe_rocprofv3_summary.txt.)
+  constexpr int CAP = sizeof(T) == 8 ? 24 : 32;  // (32 doubles + 32 columns would spill at the default register bound)
+  if (n <= CAP) {
+    int cc[CAP];
+    T vv[CAP];
+    const int len = e - s;
+#pragma unroll
+    for (int p = 0; p < CAP; ++p) {
+      const bool in = p < len;
+      const int c = in ? lcol[s + p] : 0;
+      cc[p] = in ? (iperm ? iperm[c] : c) : (p == len && !has_diag ? i : 0x7FFFFFFF);
+      vv[p] = in ? lval[s + p] : T(0);
+    }
+#pragma unroll
+    for (int p = 0; p < CAP; ++p) {
+      if (p < n) {
+        int pos = 0;
+        if (cc[p] != i) {
+          pos = 1;
+#pragma unroll
+          for (int q = 0; q < CAP; ++q) pos += (q < n && cc[q] != i && cc[q] < cc[p]) ? 1 : 0;
+        }
+        rcol[o + pos] = cc[p];
+        rval[o + pos] = vv[p];
+      }
+    }
+    for (int m2 = n; m2 < npad; ++m2) {
+      rcol[o + m2] = N;  // out-of-range sentinel: the gather's bounds check returns 0
+      rval[o + m2] = T(0);
+    }
+    return;
+  }
   int m = 0;
   for (int j = s; j < e; ++j) {
     rcol[o + m] = iperm ? iperm[lcol[j]] : lcol[j];
