@@ -106,3 +106,31 @@ def test_estimate_lmax_seam_on_the_real_graph_class():
     env["MPLBACKEND"] = "Agg"
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "seam ok" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
+
+
+def test_reference_doctests_give_the_same_results_through_the_seam(tmp_path):
+    """The reference's own doctests of the modules that reach the Chebyshev path (pygsp/filters/*.py, reduction.py,
+    features.py: ~350 examples, collected the way pygsp/tests/test_docstrings.py does) printed by the real package with
+    and without `plugin.install()`: the same examples pass and the same few fail either way (those need packages this
+    container lacks), and with the seam > 100 of the calls went through the product's cheby_op / Filter.filter."""
+    def run(seam):
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.pathsep.join([REF, ROOT, os.path.join(ROOT, "tests")])
+        env["PYTHONDONTWRITEBYTECODE"] = "1"
+        env["MPLBACKEND"] = "Agg"
+        env["GSPX_SEAM"] = "1" if seam else "0"
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "seam_doctests.py")], cwd=str(tmp_path), env=env,
+                             capture_output=True, text=True, timeout=1500)
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        return json.loads(res.stdout.strip().splitlines()[-1])
+
+    plain, seamed = run(False), run(True)
+    attempted = sum(v["attempted"] for v in plain["files"].values())
+    assert attempted >= 300 and plain["files"]["filters/filter.py"]["attempted"] >= 100
+    for rel, v in plain["files"].items():
+        w = seamed["files"][rel]
+        assert (w["attempted"], w["failed"], w["failing"]) == (v["attempted"], v["failed"], v["failing"]), rel
+    assert sum(v["failed"] for v in plain["files"].values()) <= attempted // 20  # (missing optional packages only)
+    calls = seamed["calls"]
+    assert calls["cheby_op"] >= 100 and calls["graphs"] >= 10 and calls["frames"] >= 1, calls
+    assert calls["synthesis_device_calls"] == calls["synthesis_filters"] >= 1, calls
