@@ -402,6 +402,7 @@ struct gspx_ctx {
   DevMem io_x, io_y;  // staging for the host-pointer entry point
   HostPipe* pipe = nullptr;  // its pipelined form (created on first use)
   CopyStage* copy = nullptr; // staged transfers of large buffers (created on first use)
+  bool counted = false;      // this context is in g_live_ctx
   // live RCCL communicators made on this context (gspx_comm_create): invalidated when the context goes
   std::mutex comms_mu;
   std::vector<struct gspx_comm*> comms;
@@ -419,6 +420,8 @@ struct gspx_ctx {
 
 // any other work on the context invalidates a recorded replay (it may have rewritten the weights,
 // the cached gather offsets or the workspace the graph refers to)
+static std::atomic<int> g_live_ctx[64];  // live contexts per device (zero-initialised)
+
 static void replay_reset(gspx_ctx* ctx) {
   if (!ctx) return;
   ctx->seen_key.clear();
@@ -531,9 +534,16 @@ extern "C" int gspx_ctx_create(int device, gspx_ctx** out) {
   HIPCHK(hipSetDevice(device));
   gspx_ctx* ctx = new gspx_ctx();
   ctx->device = device;
-  {  // the two workspaces the recurrence streams every step (GSPX_STREAMED_ALLOC=0: plain hipMalloc)
+  {  // the two workspaces the recurrence streams every step (GSPX_STREAMED_ALLOC=0: plain hipMalloc).  The chunked
+     // mapping retires address space whenever a workspace is re-created (see DevMem): worth 2-8 % to the one
+     // context that owns a GPU, not worth an address-space leak per context to a process that keeps several
+     // contexts on one device (a multi-tenant server) - those get plain allocations unless GSPX_STREAMED_ALLOC=1
+     // (or the option, per context) asks otherwise
     const char* env = getenv("GSPX_STREAMED_ALLOC");
-    ctx->opt.streamed_alloc = (env && env[0] == '0') ? 0 : 1;
+    const int others = g_live_ctx[device & 63].fetch_add(1);
+    ctx->counted = true;
+    if (env && (env[0] == '0' || env[0] == '1')) ctx->opt.streamed_alloc = env[0] == '1';
+    else ctx->opt.streamed_alloc = others == 0 ? 1 : 0;
     ctx->ws_t.streamed = ctx->ws_r.streamed = ctx->opt.streamed_alloc != 0;
   }
   if (hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device) !=
@@ -561,6 +571,7 @@ static void comm_invalidate_all(gspx_ctx* ctx);  // gspx_comm.hip.h
 extern "C" int gspx_ctx_destroy(gspx_ctx* ctx) {
   replay_reset(ctx);
   if (!ctx) return GSPX_OK;
+  if (ctx->counted) g_live_ctx[ctx->device & 63].fetch_sub(1);
   comm_invalidate_all(ctx);
   if (ctx->graph_exec) {
     (void)hipGraphExecDestroy(ctx->graph_exec);

@@ -45,6 +45,7 @@ def test_deferred_workspace_grows_and_is_recreated():
     rng = np.random.default_rng(0)
     for cycle in range(20):
         ctx = engine.Context(0)
+        ctx.set_option("streamed_alloc", 1)  # (a second context on a device gets plain workspaces by default)
         dev = engine.DeviceGraph.from_w(W, "normalized", dtype=np.float64, perm=engine.locality_order(W, coords), ctx=ctx)
         try:
             for order in (20, 43, 12, 59, 43):  # first use, grow, smaller, grow again, reuse
@@ -61,6 +62,7 @@ def test_fused_workspace_growth_beyond_reservation():
     (a reservation is max(2 x request, 1 GiB) only when the request is small: the 600 MB request of
     the last graph below forces a second reservation on the same context)."""
     ctx = engine.Context(0)
+    ctx.set_option("streamed_alloc", 1)
     rng = np.random.default_rng(1)
     try:
         W, coords = graphs.sensor_weights(130000, k=8, seed=11)
@@ -98,6 +100,11 @@ def test_two_contexts_interleaved():
     lmax = upper_lmax(W)
     rng = np.random.default_rng(2)
     ctxs = [engine.Context(0), engine.Context(0)]
+    # (a further context on a device that already has one gets plain workspaces by default - no retired address
+    # space per tenant; this test is about the chunked mode, so it asks for it)
+    assert [c.get_option("streamed_alloc") for c in ctxs][1] == 0
+    for c in ctxs:
+        c.set_option("streamed_alloc", 1)
     devs = [engine.DeviceGraph.from_w(W, dtype=np.float64, ctx=c) for c in ctxs]
     try:
         for nsig in (70, 100, 140, 200):  # 34 .. 96 MB panels
@@ -121,6 +128,9 @@ def test_plain_allocation_switch_and_retired_address_space():
     lmax = upper_lmax(W)
     rng = np.random.default_rng(4)
     ctx = engine.Context(0)
+    # the process-wide default context of this device exists already (other tests): a further context starts plain
+    assert ctx.get_option("streamed_alloc") == (0 if engine._default_ctx.get(0) is not None else 1)
+    ctx.set_option("streamed_alloc", 1)
     dev = engine.DeviceGraph.from_w(W, dtype=np.float64, ctx=ctx)
     try:
         assert ctx.get_option("streamed_alloc") == 1
@@ -147,6 +157,19 @@ def test_plain_allocation_switch_and_retired_address_space():
         dev.destroy()
         ctx.close()
         assert engine.default_context(0).get_option("retired_va_mb") == mid
+    finally:
+        del os.environ["GSPX_STREAMED_ALLOC"]
+    # several contexts on one device (a multi-tenant process): the first owns the chunked mode, the others start
+    # plain - unless the environment says 1
+    engine.default_context(0)
+    extra = engine.Context(0)
+    assert extra.get_option("streamed_alloc") == 0
+    extra.close()
+    os.environ["GSPX_STREAMED_ALLOC"] = "1"
+    try:
+        extra = engine.Context(0)
+        assert extra.get_option("streamed_alloc") == 1
+        extra.close()
     finally:
         del os.environ["GSPX_STREAMED_ALLOC"]
 
