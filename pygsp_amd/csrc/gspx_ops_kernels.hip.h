@@ -184,6 +184,51 @@ __global__ void k_cg_xr(T* __restrict__ x, T* __restrict__ r, const T* __restric
     }
   }
 }
+// The same update with ||r_new||^2 per column accumulated on the way (the next iteration's convergence test and
+// rho): thread layout, row order and summation order are k_coldot_partial's, so the sums equal a separate
+// coldot(r, r) bit for bit - and the panel r is not read a second time (14U -> 13U per iteration).
+template <typename T>
+__global__ __launch_bounds__(256) void k_cg_xr_dot(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+                                                   const T* __restrict__ q, int N, int ld, int ldp, CgScalars s,
+                                                   double* __restrict__ partial) {
+  __shared__ double ws[256];
+  const int c = threadIdx.x & (ldp - 1);
+  const int r0 = threadIdx.x / ldp;
+  const int rstep = 256 / ldp;
+  double acc = 0;
+  if (c < ld) {
+    const bool on = s.active[c] != 0;
+    const T al = on ? (T)s.alpha[c] : T(0);
+    auto upd = [&](size_t i) {
+      const size_t e = i * ld + c;
+      T rv = r[e];
+      if (on) {
+        x[e] += al * p[e];
+        rv -= al * q[e];
+        r[e] = rv;
+      }
+      return (double)rv * (double)rv;
+    };
+    const size_t stride = (size_t)gridDim.x * rstep;
+    size_t i = (size_t)blockIdx.x * rstep + r0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (; i + 3 * stride < (size_t)N; i += 4 * stride) {
+      a0 += upd(i);
+      a1 += upd(i + stride);
+      a2 += upd(i + 2 * stride);
+      a3 += upd(i + 3 * stride);
+    }
+    for (; i < (size_t)N; i += stride) a0 += upd(i);
+    acc = (a0 + a1) + (a2 + a3);
+  }
+  ws[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < ldp) {
+    double t = 0;
+    for (int k = 0; k < rstep; ++k) t += ws[k * ldp + threadIdx.x];
+    if ((int)threadIdx.x < ld) partial[(size_t)blockIdx.x * ld + threadIdx.x] = t;
+  }
+}
 __global__ void k_cg_init(CgScalars s, const double* __restrict__ bb, int ld, double rtol, double atol) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ld) return;
