@@ -360,6 +360,8 @@ struct Options {
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
                                 // (a single signal only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
+  int64_t pair_small = 0;         // 1: one- / two-signal calls on cache-resident graphs run two orders per launch (k_pair_small)
+  int64_t pair_small_mb = 20;     // ... when the internal matrix (values + columns) is smaller than that many MB
   int64_t staged_copy = 1;        // large gspx_buf_download (1) and also gspx_buf_upload (2) through pinned chunks and host threads
   int64_t staged_copy_min_mb = 32;  // ... from that many MB on
   int64_t copy_threads = 0;       // host threads of a staged copy (0: 8)
@@ -627,6 +629,8 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
   if (!strcmp(key, "pair_workgroups_per_cu")) return &o.pair_workgroups_per_cu;
   if (!strcmp(key, "staged_copy")) return &o.staged_copy;
+  if (!strcmp(key, "pair_small")) return &o.pair_small;
+  if (!strcmp(key, "pair_small_mb")) return &o.pair_small_mb;
   if (!strcmp(key, "staged_copy_min_mb")) return &o.staged_copy_min_mb;
   if (!strcmp(key, "copy_threads")) return &o.copy_threads;
   if (!strcmp(key, "tile_min_row")) return &o.tile_min_row;
@@ -1973,6 +1977,8 @@ static int prepare_coff(gspx_graph* g, const Shape& shape, unsigned ld, hipStrea
   return GSPX_OK;
 }
 
+#include "gspx_pairsmall.hip.h"
+
 template <typename T>
 static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp, const T* x,
                      unsigned ldx, T* y, unsigned ldy, unsigned ld, bool deferred,
@@ -1982,6 +1988,9 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const int K = M - 1;
+  // the latency case (one or two signals on a cache-resident graph): two orders per launch, gspx_pairsmall.hip.h
+  if (pair_small_usable<T>(g, opt, nf, M, ld, deferred, acc_existing, final_to_y))
+    return run_pair_small<T>(g, M, cp, x, ldx, y, ldy, ld, ev_idx);
   // Rows that are not made of 16-byte pieces (or a y the final flush cannot store such pieces into): the work
   // panels get padded rows of pitch ldw, so that the tile kernels take them all the same - zero columns cost
   // little next to kernels that are several times faster - and the result leaves through a copy.
