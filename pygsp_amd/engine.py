@@ -28,6 +28,7 @@ class Context:
         """Explicit teardown.  (No __del__: graphs and buffers hold a pointer to their context, so
         a context must outlive them; default contexts simply live until the process exits.)"""
         if getattr(self, "_h", None):
+            self.clear_pool()
             _capi.load().gspx_ctx_destroy(self._h)
             self._h = None
 
@@ -72,6 +73,35 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    # Buffers of device-resident arrays (DeviceArray) are recycled: a chain of filters allocates and drops a few
+    # panels of the same sizes per call, and hipMalloc / hipFree of gigabyte buffers cost milliseconds each (and a
+    # device synchronisation).  Exact-size matches only, a bounded amount kept (POOL_BYTES); clear_pool() frees it.
+    POOL_BYTES = 8 << 30
+
+    def take(self, nbytes):
+        nbytes = max(int(nbytes), 16)
+        pool = self.__dict__.setdefault("_pool", {})
+        stack = pool.get(nbytes)
+        if stack:
+            self._pooled -= nbytes
+            return stack.pop()
+        return DeviceBuffer(self, nbytes)
+
+    def give(self, buf):
+        pool = self.__dict__.setdefault("_pool", {})
+        held = self.__dict__.setdefault("_pooled", 0)
+        if not getattr(buf, "_h", None) or buf.ctx is not self or held + buf.nbytes > self.POOL_BYTES:
+            buf.free()
+            return
+        pool.setdefault(buf.nbytes, []).append(buf)
+        self._pooled = held + buf.nbytes
+
+    def clear_pool(self):
+        for stack in self.__dict__.get("_pool", {}).values():
+            for buf in stack:
+                buf.free()
+        self.__dict__["_pool"], self.__dict__["_pooled"] = {}, 0
 
     def bench_copy(self, nbytes=1 << 30, iters=10):
         """Measured read+write GB/s of the engine's streaming copy kernel (HBM ceiling)."""
@@ -187,7 +217,7 @@ class DeviceArray:
             raise ValueError("At most 3 dimensions: #nodes x #signals x #features.")
         cube = a.reshape(a.shape + (1,) * (3 - a.ndim))
         planes = np.ascontiguousarray(np.moveaxis(cube, 2, 0), dtype=dtype)
-        buf = ctx.alloc(max(planes.nbytes, 16))
+        buf = ctx.take(max(planes.nbytes, 16))
         if planes.nbytes:
             buf.upload(planes)
         out = cls(buf, cube.shape, dtype)
@@ -197,7 +227,7 @@ class DeviceArray:
     @classmethod
     def empty(cls, ctx, cube, dtype):
         n = int(np.prod(cube)) * np.dtype(dtype).itemsize
-        return cls(ctx.alloc(max(n, 16)), cube, dtype)
+        return cls(ctx.take(max(n, 16)), cube, dtype)
 
     @property
     def ndim(self):
@@ -265,9 +295,22 @@ class DeviceArray:
         return "DeviceArray(shape={}, dtype={}, device={})".format(self.shape, self.dtype, self.ctx.device)
 
     def free(self):
+        """Give the memory back (to the context's pool of recycled buffers: Context.give)."""
         if self._buf is not None:
-            self._buf.free()
-            self._buf = None
+            buf, self._buf = self._buf, None
+            if getattr(self.ctx, "_h", None):
+                self.ctx.sync()  # (nothing queued on the stream may still read or write it when it is handed out again)
+                self.ctx.give(buf)
+            else:
+                buf.free()
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def gather(parts, root_out):
