@@ -375,3 +375,54 @@ def test_device_array_views_without_a_device():
     assert buf.freed and a._buf is None
     with pytest.raises(ValueError):
         a.ptr
+
+
+def test_install_wraps_and_restores_the_filter_methods():
+    """plugin.install(wrap_filter=...) on a pygsp-shaped module (no device needed: nothing is filtered): the secondary
+    seam replaces Filter.filter / Filter.compute_frame, wrap_filter=False and uninstall() put the package's own methods
+    back, repeated installs keep the ORIGINAL methods (not a wrapper of a wrapper), and a package without a Filter
+    class (or without compute_cheby_coeff) gets the primary seam alone."""
+    import types
+
+    from pygsp_amd import plugin
+
+    def make(with_filter=True):
+        mod = types.ModuleType("pygsp")
+        mod.filters = types.ModuleType("pygsp.filters")
+        mod.filters.approximations = types.ModuleType("pygsp.filters.approximations")
+        mod.filters.approximations.cheby_op = mod.filters.cheby_op = lambda G, c, s, **kw: "reference"
+        mod.filters.approximations.compute_cheby_coeff = lambda f, m=30: np.ones(m + 1)
+        if with_filter:
+            class Filter:
+                def filter(self, s, method="chebyshev", order=30):
+                    return "own filter"
+
+                def compute_frame(self, **kwargs):
+                    return "own frame"
+            mod.filters.Filter = Filter
+        return mod
+
+    mod = make()
+    own_filter, own_frame = mod.filters.Filter.filter, mod.filters.Filter.compute_frame
+    try:
+        plugin.install(mod)
+        assert mod.filters.Filter.filter is plugin._filter_on_device
+        assert mod.filters.Filter.compute_frame is plugin._compute_frame_on_device
+        plugin.install(mod, dtype=np.float32)  # again: the saved originals are still the package's own
+        plugin.install(mod, wrap_filter=False)
+        assert mod.filters.Filter.filter is own_filter and mod.filters.Filter.compute_frame is own_frame
+        assert mod.filters.approximations.cheby_op is filters.cheby_op  # the primary seam stays
+        plugin.install(mod)
+        # everything but Chebyshev is answered by the package's own code, through the wrapper
+        assert mod.filters.Filter().filter(np.zeros(3), method="exact") == "own filter"
+        assert mod.filters.Filter().compute_frame(method="exact") == "own frame"
+        plugin.uninstall(mod)
+        assert mod.filters.Filter.filter is own_filter and mod.filters.Filter.compute_frame is own_frame
+        assert mod.filters.cheby_op(None, None, None) == "reference"
+        bare = make(with_filter=False)
+        plugin.install(bare)
+        assert bare.filters.cheby_op is filters.cheby_op and not hasattr(bare.filters, "Filter")
+        plugin.uninstall(bare)
+    finally:
+        plugin.uninstall(mod)
+        plugin._config.update(dtype=np.dtype(np.float64))
