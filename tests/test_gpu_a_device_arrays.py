@@ -302,3 +302,35 @@ def test_plugin_frame_of_20k_vertices_without_a_host_identity(monkeypatch):
     ref = orc.cheby_op(G.L, lmax, orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, 10), deltas)
     assert rel_err(F[picks, :].T, ref) < 1e-12
     assert np.isfinite(F).all() and np.count_nonzero(F[0]) < G.N // 4  # a localised kernel, not a dense row
+
+
+def test_plugin_wrap_in_float32_and_with_a_device_list():
+    """The wrapped seam in the fp32 engine (`install(dtype=np.float32)`: 1e-3 bar, DeviceArrays in float32) and with
+    a device list (`install(devices=[0, 0])`: analysis and the fused synthesis split their signal columns over two
+    contexts; DeviceArrays are refused there - they live on one GPU)."""
+    from pygsp_amd import plugin
+
+    W = random_graph(900, 6, 17)
+    lmax = upper_lmax(W)
+    fake = pygsp_like(W, lmax)
+    G = fake.RefGraph()
+    bank = fake.filters.Filter(G, orc.mexican_hat_kernels(lmax, 3))
+    rng = np.random.default_rng(8)
+    x, cube = rng.standard_normal((G.N, 5)), rng.standard_normal((G.N, 5, 3))
+    ref_a, ref_s = bank.filter(x, order=14), bank.filter(cube, order=14)
+    try:
+        plugin.install(fake, dtype=np.float32)
+        ya, ys = bank.filter(x, order=14), bank.filter(cube, order=14)
+        assert ya.dtype == np.float64 and rel_err(ya, ref_a) < 2e-5 and rel_err(ys, ref_s) < 2e-5
+        d = bank.filter(bank.filter(plugin.to_device(G, x), order=14), order=14)
+        assert d.dtype == np.float32 and d.shape == (G.N, 5)
+        assert rel_err(np.asarray(d), bank.filter(ref_a, order=14)) < 1e-4
+        plugin.install(fake, devices=[0, 0])
+        assert np.max(np.abs(bank.filter(x, order=14) - ref_a)) < 1e-12 * np.max(np.abs(ref_a))
+        assert np.max(np.abs(bank.filter(cube, order=14) - ref_s)) < 1e-12 * np.max(np.abs(ref_s))
+        with pytest.raises(ValueError):
+            bank.filter(plugin.to_device(G, x), order=14)
+    finally:
+        plugin.uninstall(fake)
+        plugin.install(fake)  # back to the single-device float64 configuration for whatever runs next
+        plugin.uninstall(fake)
