@@ -978,9 +978,11 @@ def main():
     newton = newton_pair = None
     if a.evaluation == "recurrence" and not a.no_newton:
         newton = time_newton()
-    if a.evaluation == "recurrence" and not a.no_newton and world == 1:
-        # the same, two orders per launch (fused pair kernel; needs the host-built row tiles: seconds of
-        # numpy per rank, so only in the single-GPU run)
+    if a.evaluation == "recurrence" and not a.no_newton and world == 1 and _capi.experimental:
+        # the same, two orders per launch (fused pair kernel of the EXPERIMENTAL build only - GSPX_LIB_PATH=
+        # .../libgspx_exp.so; needs the host-built row tiles: seconds of numpy per rank)
+        from pygsp_amd import experimental
+        experimental.attach()
         tiles = dev.enable_pair_tiles()
         newton_pair = time_newton() + (tiles,)
         dev.disable_pair_tiles()

@@ -83,14 +83,12 @@ int gspx_ctx_sync(gspx_ctx* ctx);
  *   "xcd_remap"     1 (default) contiguous row ranges per XCD in the plain gather kernels
  *   "tile_nt"       k_step_tile non-temporal accesses, bit 0 matrix entries, bit 1 accumulator, bit 2
  *                   T_{k-2} rows, bit 3 T_k stores; -1 (default): 5 for panels of 192 MiB and more
- *   "tile_workgroups" / "pair_workgroups"   persistent workgroups of k_step_tile / k_newton_pair (0: 2 per CU)
+ *   "tile_workgroups"   persistent workgroups of k_step_tile (0: 2 per CU; what fits for the small builds)
  *   "tile_pad"      1 (default) panels whose rows are not made of 16-byte pieces take k_step_tile with padded
  *                   rows (a single signal only on graphs beyond the L2s); 2 always; 0 never.  "tile_min_row"
  *                   (16) narrowest rows in bytes k_step_tile takes; "tile_lg" 2 / 4 / 8: no build narrower than that
  *   "vec", "rows_per_wave", "narrow_g_log2", "waves_per_block"   launch shapes of the plain gather
  *                   kernels (0 / -1 = auto)
- *   "newton_pair"   1 (default) Newton-form filtering runs two orders per launch when the graph carries
- *                   pair tiles (gspx_graph_set_tiles)
  *   "edge_vertex_walk" 1 (default) grad / div walk the vertices in the internal order; 0 edge order
  *   "host_pipeline" gspx_cheby_filter: 1 (default) large calls pipelined in column batches, 2 always, 0 never;
  *                   "host_batch" signals per batch, "host_edge" of the first / last one, "host_threads" (0 = auto)

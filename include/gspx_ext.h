@@ -28,21 +28,9 @@ int gspx_newton_filter_dev(gspx_graph* g, double lmax, int K, const double* node
 int gspx_newton_filter(gspx_graph* g, double lmax, int K, const double* nodes, const double* dcoef,
                        int64_t Nsig, const void* x_host, void* y_host, double* kernel_ms);
 
-/* Optional acceleration structure for gspx_newton_filter*: two-level row tiles (32-row blocks) of
- * the internal vertex order, computed on the host from the internal pattern
- * (pygsp_amd/tiling.py).  With tiles set (and option "newton_pair" = 1, the default) two Horner
- * steps run per launch with the panel staged in LDS: the pass moves fewer bytes than the
- * algorithmic count of two steps.  block_rows == 0 drops the tiles. */
+/* The internal padded CSR pattern (engine vertex order; rowptr low 2 bits = pad counts, pads have col == N): what
+ * host-built tiles (pygsp_amd/tiling.py) are computed from. */
 int gspx_graph_download_internal(gspx_graph* g, int32_t* rowptr, int32_t* col);
-int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
-                         const int32_t* s1rows, const int32_t* s2ptr, const int32_t* s2rows,
-                         const uint16_t* lidx1, const uint32_t* occ_off, int64_t n_lidx2,
-                         const uint16_t* lidx2, int max_n1, int max_n2);
-/* out[0] row blocks, out[1] blocks handled by the unstaged fallback kernel (tiles too large to hold
- * their matrix entries in LDS, or rows longer than 32 entries), out[2] dynamic LDS bytes per
- * workgroup of that fallback kernel (the staged kernel always takes 80 KB), out[3] rows per block
- * (0: no tiles set) */
-int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
 
 /* Optional acceleration structure for gspx_cheby_filter* with ONE filter: one-level row tiles
  * (64-row blocks of the internal vertex order: per block the distinct rows it gathers, s1ptr /
@@ -198,22 +186,6 @@ int gspx_graph_download_perm(gspx_graph* g, int32_t* perm);
  * np.identity(N)) produced where it is consumed. */
 int gspx_identity_panel_dev(gspx_ctx* ctx, int dtype, int64_t N, int64_t j0, int64_t w, void* out_dev);
 
-/* TWO orders of the three-term recurrence per launch (opt-in experiment of round 4; DESIGN.md section 7.1): the tile
- * data of pygsp_amd/tiling.py (levels = 2) for blocks of 64 / 128 / 256 rows of the graph's internal order - per
- * block the row lists of its 1-hop (S1) and 2-hop (S2) closures, per stored entry of a block row its position in
- * S1 (lidx1, 0xFFFF for pads), per (block, S1 row) occurrence where that row's entries' positions in S2 start in
- * lidx2.  block_rows == 0 drops the tiles.  stats (may be NULL): blocks, largest S1, largest S2, most entries of
- * a block's S1 rows, of its own rows, entries of lidx2. */
-int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr, const int32_t* s1rows,
-                                   const int32_t* s2ptr, const int32_t* s2rows, const uint16_t* lidx1,
-                                   const uint32_t* occ_off, int64_t n_lidx2, const uint16_t* lidx2, int64_t stats[6]);
-/* cheby_op (approximations.py:58-114) for ONE filter of even order M - 1 with those tiles: (M - 1) / 2 launches,
- * each computing T_k on the block's 1-hop closure in LDS and T_{k+1} on its rows; column chunks of chunk_lanes
- * (2 / 4 / 8 / 16) x 16 bytes.  x_dev, y_dev: N x Nsig row-major in the graph's own vertex order, rows of whole
- * 16-byte pieces.  Same result as gspx_cheby_filter_dev up to the association order of the final sum. */
-int gspx_cheby_pair_filter_dev(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig,
-                               const void* x_dev, void* y_dev, int chunk_lanes, double* kernel_ms);
-
 /* PCI address ("0000:c1:00.0", NUL-terminated) of HIP device `device`: what a host driver needs to find the NUMA
  * node the GPU hangs off (/sys/bus/pci/devices/<address>/numa_node) and pin the thread - and the packing threads
  * libgspx starts from it - that feeds this GPU to the cores next to it (pygsp_amd.multi). */
@@ -269,6 +241,45 @@ int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
  * (SBM), each XCD walking a contiguous eighth of the stream.  ms: per launch; gbps: row bytes per second. */
 int gspx_bench_gather(gspx_ctx* ctx, int64_t panel_rows, int row_bytes, int64_t n_gathers, int in_flight,
                       int blocks, double p_intra, int workgroups_per_cu, int iters, double* ms, double* gbps);
+
+/* ---- experimental build only (make -C pygsp_amd/csrc experimental: -DGSPX_EXPERIMENTAL -> _lib/libgspx_exp.so) -------
+ * Kernels that measured slower than what runs by default (the fused Newton pair of rounds 1-2, the small pair
+ * kernel of round 4) or that are not cleared to run at size (two orders of the three-term recurrence per launch:
+ * profiles/r04_pair_experiment.md, profiles/r05_pair_experiment.md).  The default libgspx.so exports none of them
+ * and rejects their context options ("newton_pair", "pair_workgroups", "pair_workgroups_per_cu", "pair_small",
+ * "pair_small_mb"). */
+#ifdef GSPX_EXPERIMENTAL
+/* Optional acceleration structure for gspx_newton_filter*: two-level row tiles (32-row blocks) of
+ * the internal vertex order, computed on the host from the internal pattern
+ * (pygsp_amd/tiling.py).  With tiles set (and option "newton_pair" = 1, the default) two Horner
+ * steps run per launch with the panel staged in LDS: the pass moves fewer bytes than the
+ * algorithmic count of two steps.  block_rows == 0 drops the tiles. */
+int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
+                         const int32_t* s1rows, const int32_t* s2ptr, const int32_t* s2rows,
+                         const uint16_t* lidx1, const uint32_t* occ_off, int64_t n_lidx2,
+                         const uint16_t* lidx2, int max_n1, int max_n2);
+/* out[0] row blocks, out[1] blocks handled by the unstaged fallback kernel (tiles too large to hold
+ * their matrix entries in LDS, or rows longer than 32 entries), out[2] dynamic LDS bytes per
+ * workgroup of that fallback kernel (the staged kernel always takes 80 KB), out[3] rows per block
+ * (0: no tiles set) */
+int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
+
+/* TWO orders of the three-term recurrence per launch (opt-in experiment of round 4; DESIGN.md section 7.1): the tile
+ * data of pygsp_amd/tiling.py (levels = 2) for blocks of 64 / 128 / 256 rows of the graph's internal order - per
+ * block the row lists of its 1-hop (S1) and 2-hop (S2) closures, per stored entry of a block row its position in
+ * S1 (lidx1, 0xFFFF for pads), per (block, S1 row) occurrence where that row's entries' positions in S2 start in
+ * lidx2.  block_rows == 0 drops the tiles.  stats (may be NULL): blocks, largest S1, largest S2, most entries of
+ * a block's S1 rows, of its own rows, entries of lidx2. */
+int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr, const int32_t* s1rows,
+                                   const int32_t* s2ptr, const int32_t* s2rows, const uint16_t* lidx1,
+                                   const uint32_t* occ_off, int64_t n_lidx2, const uint16_t* lidx2, int64_t stats[6]);
+/* cheby_op (approximations.py:58-114) for ONE filter of even order M - 1 with those tiles: (M - 1) / 2 launches,
+ * each computing T_k on the block's 1-hop closure in LDS and T_{k+1} on its rows; column chunks of chunk_lanes
+ * (2 / 4 / 8 / 16) x 16 bytes.  x_dev, y_dev: N x Nsig row-major in the graph's own vertex order, rows of whole
+ * 16-byte pieces.  Same result as gspx_cheby_filter_dev up to the association order of the final sum. */
+int gspx_cheby_pair_filter_dev(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig,
+                               const void* x_dev, void* y_dev, int chunk_lanes, double* kernel_ms);
+#endif /* GSPX_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,11 @@
 """ctypes binding of libgspx (C-ABI declared in include/gspx.h and include/gspx_ext.h).
 
-The library is built in-tree (pygsp_amd/_lib/libgspx.so) by ``pygsp_amd.build.build()`` /
+The library is built in-tree (pygsp_amd/_lib/libgspx.so) by ``__graft_entry__.build()`` /
 ``make -C pygsp_amd/csrc``.  There is NO CPU fallback: if the shared object is missing, or no
 HIP device is visible, every product entry point raises.
+
+``make -C pygsp_amd/csrc experimental`` builds _lib/libgspx_exp.so: the same library plus the kernels that do not run
+by default (SIGNATURES_EXPERIMENTAL below; pygsp_amd/experimental.py).  GSPX_LIB_PATH selects it.
 """
 import ctypes
 import os
@@ -105,9 +108,6 @@ SIGNATURES = {
     "gspx_sbm_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_uint64, _P]),
     "gspx_sbm_build_ex": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_uint64, _c.c_int, _P]),
     "gspx_radius_build": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _c.c_double, _c.c_double, _c.c_int, _P]),
-    "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),
-    "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,
-                                        _c.c_int, _c.c_int]),
     "gspx_last_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "gspx_last_host_timing": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "gspx_last_host_timeline": (_c.c_int, [_P, _P, _c.c_int, _P]),
@@ -121,9 +121,6 @@ SIGNATURES = {
     "gspx_identity_panel_dev": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "gspx_planes_pack_dev": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _c.c_int]),
     "gspx_device_pci_bus_id": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_int]),
-    "gspx_graph_set_cheb_pair_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P, _P]),
-    "gspx_cheby_pair_filter_dev": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _c.c_int64, _P, _P, _c.c_int,
-                                              _c.POINTER(_c.c_double)]),
     "gspx_comm_available": (_c.c_int, []),
     "gspx_comm_unique_id": (_c.c_int, [_P]),
     "gspx_comm_create": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _c.POINTER(_P)]),
@@ -133,6 +130,18 @@ SIGNATURES = {
                                      _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "gspx_bench_copy": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),
 }
+
+# exported only by the experimental build (-DGSPX_EXPERIMENTAL; include/gspx_ext.h, the section under that macro)
+SIGNATURES_EXPERIMENTAL = {
+    "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),
+    "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,
+                                        _c.c_int, _c.c_int]),
+    "gspx_graph_set_cheb_pair_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P, _P]),
+    "gspx_cheby_pair_filter_dev": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _c.c_int64, _P, _P, _c.c_int,
+                                              _c.POINTER(_c.c_double)]),
+}
+EXP_LIB_PATH = os.path.join(_HERE, "_lib", "libgspx_exp.so")
+experimental = False  # set by load(): the loaded library is the experimental build
 
 
 def load():
@@ -149,6 +158,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    global experimental
+    experimental = hasattr(lib, "gspx_cheby_pair_filter_dev")
+    if experimental:
+        for name, (res, args) in SIGNATURES_EXPERIMENTAL.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

@@ -8,6 +8,12 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gspx.hip -o libgspx.so
 #include "gspx_kernels.hip.h"
 #include "gspx_tile_kernels.hip.h"
+// Kernels that measured slower than what runs by default, or that are not yet safe at size (two orders per launch),
+// are compiled only into the experimental build: make EXTRA=-DGSPX_EXPERIMENTAL (include/gspx_ext.h lists their
+// entry points under the same macro; profiles/r04_pair_experiment.md).
+#ifdef GSPX_EXPERIMENTAL
+#include "experimental/gspx_newton_pair.hip.h"
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -350,8 +356,13 @@ struct Options {
   int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
   int64_t narrow_g_log2 = -1;  // -1 = auto (4 lanes per row in total)
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
+#ifdef GSPX_EXPERIMENTAL
   int64_t newton_pair = 1;      // use the fused two-step kernel when the graph carries tiles
-  int64_t pair_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU)
+  int64_t pair_workgroups = 0;  // persistent workgroups of the two-step / two-orders kernels (0: what fits a CU)
+  int64_t pair_small = 0;         // 1: one- / two-signal calls on cache-resident graphs run two orders per launch (k_pair_small)
+  int64_t pair_small_mb = 20;     // ... when the internal matrix (values + columns) is smaller than that many MB
+  int64_t pair_workgroups_per_cu = 0;  // two-orders-per-launch kernel: at most that many resident workgroups per CU (0: what fits)
+#endif
   int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU; what fits for the small builds)
@@ -360,12 +371,9 @@ struct Options {
   int64_t tile_pad = 1;         // 1: panels whose rows are not made of 16-byte pieces take the tile kernels with padded rows
                                 // (a single signal only on graphs beyond the L2s); 2: always; 0: never
   int64_t tile_min_row = 16;    // narrowest rows (bytes) the tile kernel takes; below: the sub-wave kernel
-  int64_t pair_small = 0;         // 1: one- / two-signal calls on cache-resident graphs run two orders per launch (k_pair_small)
-  int64_t pair_small_mb = 20;     // ... when the internal matrix (values + columns) is smaller than that many MB
   int64_t staged_copy = 1;        // large gspx_buf_download (1) and also gspx_buf_upload (2) through pinned chunks and host threads
   int64_t staged_copy_min_mb = 32;  // ... from that many MB on
   int64_t copy_threads = 0;       // host threads of a staged copy (0: 8)
-  int64_t pair_workgroups_per_cu = 0;  // two-orders-per-launch kernel: at most that many resident workgroups per CU (0: what fits)
   int64_t tile_regroup = 1;     // 1: rows of 3 / 5 / 6 / 7 / 10 / 12 / 14 sixteen-byte pieces run the builds whose compute
                                 // phases regroup the lanes by pieces (k_step_tile<..., CL>); 0: the power-of-two builds
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
@@ -442,13 +450,15 @@ struct gspx_buf {
 
 static std::atomic<uint64_t> g_generation{1};  // handles are told apart by birth number, not by address
 
-// two-level row tiles of the two-orders-per-launch recurrence kernel (optional; gspx_chebpair.hip.h)
+#ifdef GSPX_EXPERIMENTAL
+// two-level row tiles of the two-orders-per-launch recurrence kernel (experimental/gspx_chebpair.hip.h)
 struct ChebPairTiles {
   DevMem hdr, desc, s2rows, lidx1, lidx2, src, val2, ownpos;
   int rows = 0, nb = 0, n1max = 0, n2max = 0, e1max = 0, e2max = 0;
   int64_t total2 = 0;
   double val_lmax = -1.0;  // lmax the gathered factor values val2 were built for
 };
+#endif
 
 struct gspx_graph {
   gspx_ctx* ctx = nullptr;
@@ -465,12 +475,15 @@ struct gspx_graph {
   unsigned coff_ldb = 0;  // panel row bytes the cached byte offsets were built for
   DevMem perm, iperm;
   bool has_perm = false;
-  // two-level row tiles of the fused Newton-pair kernel (optional; pygsp_amd/tiling.py)
+#ifdef GSPX_EXPERIMENTAL
+  // two-level row tiles of the fused Newton-pair kernel (pygsp_amd/tiling.py)
   DevMem t_hdr, t_hdr_s, t_desc, t_s2rows, t_lidx1, t_lidx2, t_fb;
   int tile_nfb = 0;          // blocks the staged pair kernel leaves to the fallback kernel
   size_t tile_lds = 0;       // dynamic LDS bytes of the fallback pair kernel (its largest tiles)
   size_t tile_top = 0;       // staged pair kernel: bytes of the top part of its 80 KB
   int tile_rows = 0, tile_nb = 0, tile_max_n1 = 0, tile_max_n2 = 0;
+  ChebPairTiles cp;          // ... of the two-orders-per-launch recurrence kernel
+#endif
   double fval_lmax = -1.0;
   double build_ms = 0.0;
   // ingredients of Graph._get_upper_bound (graph.py:933-960), taken while W is on the device (fp64 graphs built
@@ -489,7 +502,6 @@ struct gspx_graph {
   bool edges_built = false;
   int64_t n_edges = 0;
   DevMem e_off, e_toff, e_src, e_dst, e_tedge, e_cs, e_ct, e_w;
-  ChebPairTiles cp;
 };
 
 static size_t elt_size(int dtype) { return dtype == GSPX_F32 ? 4 : 8; }
@@ -620,17 +632,19 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "waves_per_block")) return &o.waves_per_block;
   if (!strcmp(key, "alternate_sweep")) return &o.alternate_sweep;
   if (!strcmp(key, "synthesis")) return &o.synthesis;
+#ifdef GSPX_EXPERIMENTAL
   if (!strcmp(key, "newton_pair")) return &o.newton_pair;
   if (!strcmp(key, "pair_workgroups")) return &o.pair_workgroups;
+  if (!strcmp(key, "pair_workgroups_per_cu")) return &o.pair_workgroups_per_cu;
+  if (!strcmp(key, "pair_small")) return &o.pair_small;
+  if (!strcmp(key, "pair_small_mb")) return &o.pair_small_mb;
+#endif
   if (!strcmp(key, "tile_gather")) return &o.tile_gather;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
   if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
-  if (!strcmp(key, "pair_workgroups_per_cu")) return &o.pair_workgroups_per_cu;
   if (!strcmp(key, "staged_copy")) return &o.staged_copy;
-  if (!strcmp(key, "pair_small")) return &o.pair_small;
-  if (!strcmp(key, "pair_small_mb")) return &o.pair_small_mb;
   if (!strcmp(key, "staged_copy_min_mb")) return &o.staged_copy_min_mb;
   if (!strcmp(key, "copy_threads")) return &o.copy_threads;
   if (!strcmp(key, "tile_min_row")) return &o.tile_min_row;
@@ -1265,6 +1279,7 @@ extern "C" int gspx_graph_download_internal(gspx_graph* g, int32_t* rowptr, int3
   return GSPX_OK;
 }
 
+#ifdef GSPX_EXPERIMENTAL
 extern "C" int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
                                     const int32_t* s1rows, const int32_t* s2ptr,
                                     const int32_t* s2rows, const uint16_t* lidx1,
@@ -1389,6 +1404,7 @@ extern "C" int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]) {
   out[3] = g->tile_rows;
   return GSPX_OK;
 }
+#endif  // GSPX_EXPERIMENTAL
 
 extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
                                            const int32_t* s1rows, const uint16_t* lidx, int64_t* stats) {
@@ -1977,7 +1993,9 @@ static int prepare_coff(gspx_graph* g, const Shape& shape, unsigned ld, hipStrea
   return GSPX_OK;
 }
 
-#include "gspx_pairsmall.hip.h"
+#ifdef GSPX_EXPERIMENTAL
+#include "experimental/gspx_pairsmall.hip.h"
+#endif
 
 template <typename T>
 static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp, const T* x,
@@ -1988,9 +2006,11 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const int K = M - 1;
-  // the latency case (one or two signals on a cache-resident graph): two orders per launch, gspx_pairsmall.hip.h
+#ifdef GSPX_EXPERIMENTAL
+  // the latency case (one or two signals on a cache-resident graph): two orders per launch (opt-in, slower)
   if (pair_small_usable<T>(g, opt, nf, M, ld, deferred, acc_existing, final_to_y))
     return run_pair_small<T>(g, M, cp, x, ldx, y, ldy, ld, ev_idx);
+#endif
   // Rows that are not made of 16-byte pieces (or a y the final flush cannot store such pieces into): the work
   // panels get padded rows of pitch ldw, so that the tile kernels take them all the same - zero columns cost
   // little next to kernels that are several times faster - and the result leaves through a copy.
@@ -2512,6 +2532,9 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   a.wts = ctx->ws_w.as<T>();
   a.old = X;
 
+  int s_first_pair = K;  // steps >= this index run as fused pairs (experimental build, graph with two-level tiles)
+  (void)s_first_pair;
+#ifdef GSPX_EXPERIMENTAL
   // fused two-step kernel: needs tiles, 16-byte lanes on every panel it touches, and an LDS
   // footprint (h tile on S2 + g tile on S1, 256-byte row chunks) the CU can hold
   constexpr int PVEC = 16 / (int)sizeof(T);
@@ -2523,6 +2546,7 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
                        pair_lds <= 160 * 1024 && (size_t)N * ld * sizeof(T) < ((size_t)1 << 31) &&
                        (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31) &&
                        g->t_lidx2.bytes < ((size_t)1 << 31);
+#endif
   auto step_params = [&](int s, T& sc, T& be, T& ga) {
     const int j = K - 1 - s;
     if (s == 0) {
@@ -2535,12 +2559,11 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       ga = (T)dc[j];
     }
   };
+#ifdef GSPX_EXPERIMENTAL
   const int pair_ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
   // (one chunk: straight-line build; more: the runtime-count build, which measured faster than an
   // unrolled two-chunk build - that one spills)
   void (*pair_kernel)(const PairArgs<T>) = pair_ncol == 1 ? k_newton_pair<T, 1> : k_newton_pair<T, 0>;
-  const bool tile_ok = tile_usable<T>(g, opt, ld, y, ldy);
-  int s_first_pair = K;  // steps >= this index run as fused pairs
   if (pair_ok) s_first_pair = K & 1;
   int pair_cur = (pair_ok && (K & 1)) ? 0 : -1;  // panel holding h before the next pair (-1 = X)
   if (pair_ok) {
@@ -2549,7 +2572,10 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
     HIPCHK(hipFuncSetAttribute((const void*)k_newton_pair_g<T>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
   }
+#endif
+  const bool tile_ok = tile_usable<T>(g, opt, ld, y, ldy);
   for (int s = 0; s < K; ++s) {
+#ifdef GSPX_EXPERIMENTAL
     if (s >= s_first_pair) {
       PairArgs<T> p{};
       p.rowptr = g->rptr.as<int>();
@@ -2596,6 +2622,7 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       ++s;  // two steps done
       continue;
     }
+#endif
     const int j = K - 1 - s;
     if (tile_ok) {
       TileArgs<T> t{};
@@ -3137,4 +3164,6 @@ extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double*
 #include "gspx_ops.hip.h"
 #include "gspx_knn.hip.h"
 #include "gspx_setup.hip.h"
-#include "gspx_chebpair.hip.h"
+#ifdef GSPX_EXPERIMENTAL
+#include "experimental/gspx_chebpair.hip.h"
+#endif

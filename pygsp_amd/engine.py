@@ -866,24 +866,6 @@ def _newton_methods():
         _capi.check(_capi.load().gspx_graph_download_internal(self._h, _capi.ptr(rp), _capi.ptr(col)))
         return rp, col
 
-    def enable_pair_tiles(self):
-        """Build (numpy) and upload the two-level tiles of the fused Newton-pair kernel.
-        Returns the tile statistics.  A graph-setup step, ~seconds at N = 1M."""
-        from . import tiling
-        rp, col = self.download_internal()
-        t = tiling.build_tiles(rp, col, self.N, 32)
-        c = np.ascontiguousarray
-        _capi.check(_capi.load().gspx_graph_set_tiles(
-            self._h, 32, t["nb"], _capi.ptr(c(t["s1ptr"])), _capi.ptr(c(t["s1rows"])),
-            _capi.ptr(c(t["s2ptr"])), _capi.ptr(c(t["s2rows"])), _capi.ptr(c(t["lidx1"])),
-            _capi.ptr(c(t["occ_off"])), t["lidx2"].size, _capi.ptr(c(t["lidx2"])), t["max_n1"],
-            t["max_n2"]))
-        st = {k: t[k] for k in ("nb", "max_n1", "max_n2", "mean_n1", "mean_n2")}
-        out = np.zeros(4, dtype=np.int64)
-        _capi.check(_capi.load().gspx_graph_tile_stats(self._h, _capi.ptr(out)))
-        st["unstaged_blocks"], st["fallback_lds_bytes"] = int(out[1]), int(out[2])
-        return st
-
     def enable_gather_tiles(self):
         """Build (numpy) and upload the one-level row tiles of the LDS-staged recurrence step
         (k_step_tile): per 64-row block the distinct rows it gathers, per entry a 16-bit position in
@@ -926,53 +908,13 @@ def _newton_methods():
     def disable_gather_tiles(self):
         _capi.check(_capi.load().gspx_graph_set_gather_tiles(self._h, 0, 0, None, None, None, None))
 
-    def enable_cheb_pair_tiles(self, block_rows=128):
-        """Build (numpy, pygsp_amd/tiling.py) and upload the two-level tiles of the two-orders-per-launch
-        recurrence kernel (gspx_graph_set_cheb_pair_tiles; opt-in experiment).  Returns the tile statistics.
-        A graph set-up step: seconds at N = 1M."""
-        from . import tiling
-        rp, col = self.download_internal()
-        t = tiling.build_tiles(rp, col, self.N, int(block_rows))
-        c = np.ascontiguousarray
-        stats = np.zeros(6, dtype=np.int64)
-        _capi.check(_capi.load().gspx_graph_set_cheb_pair_tiles(
-            self._h, int(block_rows), t["nb"], _capi.ptr(c(t["s1ptr"])), _capi.ptr(c(t["s1rows"])),
-            _capi.ptr(c(t["s2ptr"])), _capi.ptr(c(t["s2rows"])), _capi.ptr(c(t["lidx1"])), _capi.ptr(c(t["occ_off"])),
-            t["lidx2"].size, _capi.ptr(c(t["lidx2"])), _capi.ptr(stats)))
-        return {"block_rows": int(block_rows), "nb": int(stats[0]), "max_n1": int(stats[1]), "max_n2": int(stats[2]),
-                "max_entries_s1": int(stats[3]), "max_entries_own": int(stats[4]), "entries_level2": int(stats[5]),
-                "mean_n1": t["mean_n1"], "mean_n2": t["mean_n2"]}
-
-    def disable_cheb_pair_tiles(self):
-        _capi.check(_capi.load().gspx_graph_set_cheb_pair_tiles(self._h, 0, 0, None, None, None, None, None, None, 0,
-                                                                None, None))
-
-    def cheby_pair_filter_dev(self, coeffs, x_ptr, y_ptr, nsig, lmax, chunk_lanes=4):
-        """One filter of even order, two recurrence orders per launch (gspx_cheby_pair_filter_dev); device
-        pointers in / out.  Returns device milliseconds of the whole call."""
-        c = np.ascontiguousarray(np.asarray(coeffs, dtype=np.float64).reshape(-1))
-        ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_cheby_pair_filter_dev(
-            self._h, float(lmax), c.size, _capi.ptr(c), int(nsig), ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr),
-            int(chunk_lanes), ctypes.byref(ms)))
-        return ms.value
-
-    def disable_pair_tiles(self):
-        _capi.check(_capi.load().gspx_graph_set_tiles(self._h, 0, 0, None, None, None, None, None,
-                                                      None, 0, None, 0, 0))
-
     DeviceGraph.newton_filter = newton_filter
     DeviceGraph.newton_filter_dev = newton_filter_dev
     DeviceGraph.download_internal = download_internal
-    DeviceGraph.enable_pair_tiles = enable_pair_tiles
     DeviceGraph.enable_gather_tiles = enable_gather_tiles
     DeviceGraph.disable_gather_tiles = disable_gather_tiles
     DeviceGraph.auto_gather_tiles = auto_gather_tiles
     DeviceGraph.build_gather_tiles = build_gather_tiles
-    DeviceGraph.disable_pair_tiles = disable_pair_tiles
-    DeviceGraph.enable_cheb_pair_tiles = enable_cheb_pair_tiles
-    DeviceGraph.disable_cheb_pair_tiles = disable_cheb_pair_tiles
-    DeviceGraph.cheby_pair_filter_dev = cheby_pair_filter_dev
 
 
 _newton_methods()

@@ -1,4 +1,6 @@
-"""Two-level row tiles for the fused Newton-pair kernel (k_newton_pair in pygsp_amd/csrc).
+"""Row tiles: one level for the LDS-staged recurrence step (k_step_tile; the device builds the same lists itself,
+gspx_graph_build_gather_tiles - this module is its host-side model and the CPU tests' reference), two levels for
+the kernels of the experimental build (k_newton_pair, k_cheb_pair in pygsp_amd/csrc/experimental).
 
 One launch of that kernel applies TWO Horner steps
 

@@ -623,51 +623,12 @@ def test_plugin_estimate_lmax_seam(ctx):
     assert RefGraph.estimate_lmax is original
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_pair_small_two_orders_per_launch(ctx, dtype):
-    """Option pair_small: one- / two-signal calls on a cache-resident graph run two recurrence orders per launch
-    (k_pair_small: T_k on the block's 1-hop closure in LDS, T_{k+1} on its rows).  Same polynomial as the single-step
-    path - oracle parity at the same tolerance - for even orders 2 ... 30, eager and replayed as a hipGraph; odd orders,
-    wider panels and filterbanks keep the single-step path."""
-    G = graphs.Sensor(40000, k=7, seed=12, compute_dtype=dtype)
-    G.estimate_lmax("bounds")
-    lmax = float(G.lmax)
-    dev = G.device_graph()
-    assert G.tile_stats and G.tile_stats["enabled"]
-    L = orc.laplacian(G.W)
-    rng = np.random.default_rng(3)
-    tol = TOL[np.dtype(dtype)]
-    try:
-        for nsig in (1, 2):
-            if nsig == 2 and dtype == np.float32:
-                pass  # (2 fp32 signals = 8-byte rows: covered like the others)
-            x = rng.standard_normal((G.N, nsig)).astype(dtype)
-            bx, by = ctx.upload(x), ctx.alloc(x.nbytes)
-            for K in (2, 4, 6, 30, 7):
-                c = orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, K)
-                ref = orc.cheby_op(L, lmax, c, x.astype(np.float64))
-                ctx.set_option("pair_small", 0)
-                dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, lmax)
-                y0 = by.download(x.shape, dtype)
-                ctx.set_option("pair_small", 1)
-                outs = []
-                for _ in range(4):  # the second identical call is recorded, the third and fourth replay the graph
-                    dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, lmax)
-                    outs.append(by.download(x.shape, dtype))
-                assert rel_err(outs[0], ref) < tol and rel_err(y0, ref) < tol, (nsig, K)
-                assert all(np.array_equal(o, outs[0]) for o in outs[1:]), (nsig, K)
-                if K == 7:  # odd order: the single-step path either way
-                    assert np.array_equal(outs[0], y0)
-            bx.free()
-            by.free()
-        # three signals, and a bank of two filters: not this path (bits equal the default)
-        x = rng.standard_normal((G.N, 3)).astype(dtype)
-        c2 = np.array([orc.compute_cheby_coeff(orc.heat_kernel(t, lmax), lmax, 8) for t in (5, 9)])
-        ctx.set_option("pair_small", 0)
-        a3, _ = dev.cheby_filter(c2[0], x, lmax)
-        b1, _ = dev.cheby_filter(c2, x[:, :1], lmax)
-        ctx.set_option("pair_small", 1)
-        assert np.array_equal(dev.cheby_filter(c2[0], x, lmax)[0], a3)
-        assert np.array_equal(dev.cheby_filter(c2, x[:, :1], lmax)[0], b1)
-    finally:
-        ctx.set_option("pair_small", 0)
+def test_default_library_has_no_experimental_options(ctx):
+    """The default build neither exports the experimental kernels' entry points (tests/test_capi.py) nor knows their
+    context options: a caller cannot switch a slower / uncleared kernel on by accident."""
+    if _capi.experimental:
+        pytest.skip("the experimental build is loaded (GSPX_LIB_PATH)")
+    for key in ("pair_small", "pair_small_mb", "newton_pair", "pair_workgroups", "pair_workgroups_per_cu"):
+        with pytest.raises(ValueError, match="unknown option"):
+            ctx.set_option(key, 1)
+    assert not hasattr(engine.DeviceGraph, "cheby_pair_filter_dev")

@@ -67,46 +67,3 @@ def test_newton_form_through_filter_api(golden_sensor123, golden_logo):
         filters.set_evaluation("recurrence")
     assert rel_err(filters.cheby_op(G, filters.compute_cheby_coeff(h, m=30), g["signal"],
                                     evaluation="newton"), g["heat10_y"]) < 1e-12
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_newton_pair_kernel(ctx, dtype):
-    tol = TOL[np.dtype(dtype)] * 10
-    rng = np.random.default_rng(21)
-    W, coords = graphs.sensor_weights(20000, k=8, seed=9)
-    L = orc.laplacian(W)
-    lmax = upper_lmax(W)
-    for perm in (engine.locality_order(W, coords), None):
-        dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
-        stats = dev.enable_pair_tiles()
-        assert stats["max_n1"] <= stats["max_n2"]
-        if perm is not None:  # locality order: (nearly) every block stages its entries in LDS
-            assert stats["unstaged_blocks"] * 20 < stats["nb"], stats
-        for nsig in (4, 8, 32, 64, 100, 128):
-            x = rng.standard_normal((W.shape[0], nsig))
-            for order in (30, 7, 2, 1):
-                c = orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, order)
-                nodes, d = filters.cheb_to_newton(c)
-                ref = orc.cheby_op(L, lmax, c, x.astype(dtype).astype(np.float64))
-                ctx.set_option("newton_pair", 1)
-                y1, _ = dev.newton_filter(nodes, d, x, lmax)
-                ctx.set_option("newton_pair", 0)
-                y0, _ = dev.newton_filter(nodes, d, x, lmax)
-                ctx.set_option("newton_pair", 1)
-                assert rel_err(y0, ref) < tol, (nsig, order, "single")
-                assert rel_err(y1, ref) < tol, (nsig, order, "pair")
-        dev.disable_pair_tiles()
-        dev.destroy()
-    # a graph with isolated vertices, a hub and ragged rows
-    Wr = random_graph(5000, 7, seed=31, hub=True, isolated=5)
-    Lr = orc.laplacian(Wr)
-    lm = upper_lmax(Wr)
-    dev = engine.DeviceGraph.from_w(Wr, dtype=dtype, perm=engine.locality_order(Wr, None), ctx=ctx)
-    st = dev.enable_pair_tiles()
-    assert st["unstaged_blocks"] >= 1  # the hub's row is longer than 32 entries
-    x = rng.standard_normal((5000, 16))
-    c = orc.compute_cheby_coeff(orc.heat_kernel(9, lm), lm, 12)
-    nodes, d = filters.cheb_to_newton(c)
-    y, _ = dev.newton_filter(nodes, d, x, lm)
-    assert rel_err(y, orc.cheby_op(Lr, lm, c, x.astype(dtype).astype(np.float64))) < tol
-    dev.destroy()

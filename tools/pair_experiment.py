@@ -24,6 +24,8 @@ def main():
     blocks = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "128").split(",")]
     lanes = [int(v) for v in (sys.argv[5] if len(sys.argv) > 5 else "4").split(",")]
     K = 30
+    from pygsp_amd import experimental
+    experimental.attach()  # raises on the default library: GSPX_LIB_PATH=pygsp_amd/_lib/libgspx_exp.so
     ctx = engine.default_context(0)
     for kv in sys.argv[6:]:
         key, val = kv.split("=")

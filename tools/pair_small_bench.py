@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 1 (Sensor(100000), one fp64 signal, Heat, order 30) and its neighbours: the replayed call with
-option pair_small = 0 / 1 (single steps vs two orders per launch).  GPU box only."""
+option pair_small = 0 / 1 (single steps vs two orders per launch).  GPU box only; the option exists in the EXPERIMENTAL
+build only (make -C pygsp_amd/csrc experimental; GSPX_LIB_PATH=pygsp_amd/_lib/libgspx_exp.so)."""
 import json
 import os
 import sys
@@ -11,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import cheby_oracle as orc  # noqa: E402
 from pygsp_amd import engine, filters, graphs  # noqa: E402
 
+from pygsp_amd import experimental  # noqa: E402
+experimental.attach()  # raises on the default library
 ctx = engine.default_context(0)
 rows = []
 for n in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '50000,100000,200000').split(',')]:
