@@ -762,6 +762,7 @@ static int staged_copy(gspx_ctx* ctx, unsigned char* dev, unsigned char* host, s
         if (failed.load()) return;
         std::this_thread::yield();
       }
+      if (failed.load(std::memory_order_acquire)) return;  // a failed transfer releases everything: copy nothing stale
       const size_t off = (size_t)c * chunk, len = std::min(chunk, bytes - off);
       const size_t per = ((len + P - 1) / P + 63) & ~(size_t)63;
       const size_t lo = std::min(len, per * (size_t)t), hi = std::min(len, lo + per);
@@ -773,8 +774,19 @@ static int staged_copy(gspx_ctx* ctx, unsigned char* dev, unsigned char* host, s
       done[(size_t)c].fetch_add(1, std::memory_order_release);
     }
   };
+  // (nothing may throw across the C boundary: a thread that cannot be created ends the staged attempt - the ones
+  // already running are told to stop and joined - and the caller falls back to the plain copy)
   std::vector<std::thread> pool;
-  for (int t = 0; t < P; ++t) pool.emplace_back(worker, t);
+  try {
+    pool.reserve((size_t)P);
+    for (int t = 0; t < P; ++t) pool.emplace_back(worker, t);
+  } catch (...) {
+    failed.store(true, std::memory_order_release);
+    released.store(nchunks, std::memory_order_release);
+    for (auto& th : pool)
+      if (th.joinable()) th.join();
+    return set_err(GSPX_ERR_HIP, "staged copy: could not start %d host threads", P);
+  }
   auto wait_done = [&](int c) {
     while (done[(size_t)c].load(std::memory_order_acquire) < P) std::this_thread::yield();
   };
@@ -795,7 +807,7 @@ static int staged_copy(gspx_ctx* ctx, unsigned char* dev, unsigned char* host, s
     }
   }
   if (err != hipSuccess) {
-    failed.store(true);
+    failed.store(true, std::memory_order_release);  // before the release: no worker copies a chunk that never arrived
     released.store(nchunks, std::memory_order_release);
   }
   for (auto& th : pool) th.join();

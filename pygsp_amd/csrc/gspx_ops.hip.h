@@ -398,6 +398,11 @@ static int set_edge_list_t(gspx_graph* g, int64_t E, const int32_t* src, const i
   std::vector<T> wt((size_t)std::max<int64_t>(E, 1));
   for (int64_t k = 0; k < E; ++k) wt[(size_t)k] = (T)w[k];
   const size_t e = (size_t)std::max<int64_t>(E, 1);
+  // the buffers are replaced one by one (alloc releases the old one first): until the last copy is queued the graph
+  // has NO edge list, so that a failure half-way leaves grad / div to rebuild the default one instead of running on
+  // freed or mismatched buffers
+  g->edges_built = false;
+  g->n_edges = 0;
   CHK(g->e_off.alloc(((size_t)N + 1) * sizeof(int)));
   CHK(g->e_toff.alloc(((size_t)N + 1) * sizeof(int)));
   CHK(g->e_src.alloc(e * sizeof(int)));

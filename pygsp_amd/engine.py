@@ -76,32 +76,59 @@ class Context:
 
     # Buffers of device-resident arrays (DeviceArray) are recycled: a chain of filters allocates and drops a few
     # panels of the same sizes per call, and hipMalloc / hipFree of gigabyte buffers cost milliseconds each (and a
-    # device synchronisation).  Exact-size matches only, a bounded amount kept (POOL_BYTES); clear_pool() frees it.
+    # device synchronisation).  Exact-size matches only, a bounded amount kept (POOL_BYTES; the pool never holds more
+    # than that, and less as soon as device memory is short: every library call that may allocate goes through
+    # call(), which empties the pool and retries once when the allocation fails); clear_pool() frees it.  The pool is
+    # touched from DeviceArray.__del__ (any thread the collector runs on) and from user threads: one lock.
     POOL_BYTES = 8 << 30
+
+    def _pool_state(self):
+        d = self.__dict__
+        if "_pool_lock" not in d:
+            with _default_lock:
+                d.setdefault("_pool", {})
+                d.setdefault("_pooled", 0)
+                d.setdefault("_pool_lock", threading.RLock())
+        return d["_pool_lock"]
+
+    def pooled_bytes(self):
+        with self._pool_state():
+            return self._pooled
 
     def take(self, nbytes):
         nbytes = max(int(nbytes), 16)
-        pool = self.__dict__.setdefault("_pool", {})
-        stack = pool.get(nbytes)
-        if stack:
-            self._pooled -= nbytes
-            return stack.pop()
-        return DeviceBuffer(self, nbytes)
+        with self._pool_state():
+            stack = self._pool.get(nbytes)
+            if stack:
+                self._pooled -= nbytes
+                return stack.pop()
+        return DeviceBuffer(self, nbytes)  # (through call(): trims the pool and retries if the device is full)
 
     def give(self, buf):
-        pool = self.__dict__.setdefault("_pool", {})
-        held = self.__dict__.setdefault("_pooled", 0)
-        if not getattr(buf, "_h", None) or buf.ctx is not self or held + buf.nbytes > self.POOL_BYTES:
-            buf.free()
-            return
-        pool.setdefault(buf.nbytes, []).append(buf)
-        self._pooled = held + buf.nbytes
+        with self._pool_state():
+            if not getattr(buf, "_h", None) or buf.ctx is not self or self._pooled + buf.nbytes > self.POOL_BYTES:
+                buf.free()
+                return
+            self._pool.setdefault(buf.nbytes, []).append(buf)
+            self._pooled += buf.nbytes
 
     def clear_pool(self):
-        for stack in self.__dict__.get("_pool", {}).values():
+        with self._pool_state():
+            stacks, self._pool, self._pooled = list(self._pool.values()), {}, 0
+        for stack in stacks:
             for buf in stack:
                 buf.free()
-        self.__dict__["_pool"], self.__dict__["_pooled"] = {}, 0
+
+    def call(self, fn, *args):
+        """rc = fn(*args) for a libgspx entry point that may allocate device memory (buffers, workspaces, graph
+        builds), mapped to the reference's exception types.  A HIP failure while the pool holds recycled buffers
+        empties the pool and runs the call once more: memory kept for reuse must never be the reason a call fails
+        that would have succeeded without the pool."""
+        rc = fn(*args)
+        if rc == _capi.ERR_HIP and self.pooled_bytes() > 0:
+            self.clear_pool()
+            rc = fn(*args)
+        _capi.check(rc)
 
     def bench_copy(self, nbytes=1 << 30, iters=10):
         """Measured read+write GB/s of the engine's streaming copy kernel (HBM ceiling)."""
@@ -154,7 +181,7 @@ class DeviceBuffer:
 
     def __init__(self, ctx, nbytes):
         h = ctypes.c_void_p()
-        _capi.check(_capi.load().gspx_buf_alloc(ctx._h, int(nbytes), ctypes.byref(h)))
+        ctx.call(_capi.load().gspx_buf_alloc, ctx._h, int(nbytes), ctypes.byref(h))
         self._h = h
         self.ctx = ctx
         self.nbytes = int(nbytes)
@@ -617,10 +644,10 @@ class DeviceGraph:
         lap = _capi.LAP_COMBINATORIAL if lap_type == "combinatorial" else _capi.LAP_NORMALIZED
         p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
         h = ctypes.c_void_p()
-        _capi.check(_capi.load().gspx_graph_create_from_w(
+        ctx.call(_capi.load().gspx_graph_create_from_w,
             ctx._h, W.shape[0], W.nnz, _capi.ptr(W.indptr), _capi.ptr(W.indices), _capi.ptr(data),
             _capi.dtype_code(data.dtype), lap, _capi.dtype_code(dtype), _capi.ptr(p),
-            ctypes.byref(h)))
+            ctypes.byref(h))
         return cls(h, ctx, W.shape[0], dtype)
 
     ORDER_MODES = {"none": 0, None: 0, False: 0, "auto": 1, "morton": 2, "hilbert": 3}
@@ -656,10 +683,10 @@ class DeviceGraph:
         mode, xy, d, perm_in = cls._order_args(N, coords, order)
         report = np.zeros(12, dtype=np.int64)
         h = ctypes.c_void_p()
-        _capi.check(_capi.load().gspx_graph_setup(
+        ctx.call(_capi.load().gspx_graph_setup,
             ctx._h, N, W.nnz, _capi.ptr(c(indptr)), _capi.ptr(c(indices)), _capi.ptr(c(data)), code,
             _capi.LAP_COMBINATORIAL if lap_type == "combinatorial" else _capi.LAP_NORMALIZED, _capi.dtype_code(dtype),
-            _capi.ptr(xy), d, mode, _capi.ptr(perm_in), _capi.ptr(report), ctypes.byref(h)))
+            _capi.ptr(xy), d, mode, _capi.ptr(perm_in), _capi.ptr(report), ctypes.byref(h))
         return (cls(h, ctx, N, dtype) if h.value else None), cls._setup_report(report)
 
     @classmethod
@@ -696,9 +723,9 @@ class DeviceGraph:
         mode, xy, d, perm_in = cls._order_args(N, coords, order)
         report = np.zeros(12, dtype=np.int64)
         h = ctypes.c_void_p()
-        _capi.check(_capi.load().gspx_graph_setup_from_knn(
+        adjacency.ctx.call(_capi.load().gspx_graph_setup_from_knn,
             adjacency._h, _capi.LAP_COMBINATORIAL if lap_type == "combinatorial" else _capi.LAP_NORMALIZED,
-            _capi.dtype_code(dtype), _capi.ptr(xy), d, mode, _capi.ptr(perm_in), _capi.ptr(report), ctypes.byref(h)))
+            _capi.dtype_code(dtype), _capi.ptr(xy), d, mode, _capi.ptr(perm_in), _capi.ptr(report), ctypes.byref(h))
         return (cls(h, adjacency.ctx, N, dtype) if h.value else None), cls._setup_report(report)
 
     def lmax_bounds(self):
@@ -730,9 +757,9 @@ class DeviceGraph:
         data = np.ascontiguousarray(data)
         p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
         h = ctypes.c_void_p()
-        _capi.check(_capi.load().gspx_graph_create_from_l(
+        ctx.call(_capi.load().gspx_graph_create_from_l,
             ctx._h, L.shape[0], L.nnz, _capi.ptr(L.indptr), _capi.ptr(L.indices), _capi.ptr(data),
-            _capi.dtype_code(data.dtype), _capi.dtype_code(dtype), _capi.ptr(p), ctypes.byref(h)))
+            _capi.dtype_code(data.dtype), _capi.dtype_code(dtype), _capi.ptr(p), ctypes.byref(h))
         return cls(h, ctx, L.shape[0], dtype)
 
     def destroy(self):
@@ -791,8 +818,8 @@ class DeviceGraph:
         v = ctypes.c_double(0)
         it = ctypes.c_int(0)
         ok = ctypes.c_int(0)
-        _capi.check(_capi.load().gspx_lanczos_lmax(self._h, int(max_iter), float(tol), ctypes.byref(v),
-                                                   ctypes.byref(it), ctypes.byref(ok)))
+        self.ctx.call(_capi.load().gspx_lanczos_lmax, self._h, int(max_iter), float(tol), ctypes.byref(v),
+                                                   ctypes.byref(it), ctypes.byref(ok))
         if not ok.value:
             raise ValueError("The Lanczos method did not converge. Try to use bounds.")
         return v.value, it.value
@@ -817,9 +844,9 @@ class DeviceGraph:
             nsig = x.shape[2]
             y = np.empty((self.N, nsig), dtype=self.dtype)
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_cheby_filter(
+        self.ctx.call(_capi.load().gspx_cheby_filter,
             self._h, float(lmax), Nf, M, _capi.ptr(c), nsig, _capi.ptr(x), _capi.ptr(y), mode,
-            ctypes.byref(ms)))
+            ctypes.byref(ms))
         return y, ms.value
 
     def cheby_filter_dev(self, coeffs, x_ptr, y_ptr, nsig, lmax, mode=_capi.ANALYSIS):
@@ -827,9 +854,9 @@ class DeviceGraph:
         c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.float64)))
         Nf, M = c.shape
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_cheby_filter_dev(
+        self.ctx.call(_capi.load().gspx_cheby_filter_dev,
             self._h, float(lmax), Nf, M, _capi.ptr(c), int(nsig), ctypes.c_void_p(x_ptr),
-            ctypes.c_void_p(y_ptr), mode, ctypes.byref(ms)))
+            ctypes.c_void_p(y_ptr), mode, ctypes.byref(ms))
         return ms.value
 
 
@@ -845,18 +872,18 @@ def _newton_methods():
             raise ValueError("input must be (N, Nsig), got {}".format(x.shape))
         y = np.empty_like(x)
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_newton_filter(
+        self.ctx.call(_capi.load().gspx_newton_filter,
             self._h, float(lmax), int(nodes.size), _capi.ptr(nodes), _capi.ptr(dcoef), x.shape[1],
-            _capi.ptr(x), _capi.ptr(y), ctypes.byref(ms)))
+            _capi.ptr(x), _capi.ptr(y), ctypes.byref(ms))
         return y, ms.value
 
     def newton_filter_dev(self, nodes, dcoef, x_ptr, y_ptr, nsig, lmax):
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
         dcoef = np.ascontiguousarray(dcoef, dtype=np.float64)
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_newton_filter_dev(
+        self.ctx.call(_capi.load().gspx_newton_filter_dev,
             self._h, float(lmax), int(nodes.size), _capi.ptr(nodes), _capi.ptr(dcoef), int(nsig),
-            ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), ctypes.byref(ms)))
+            ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), ctypes.byref(ms))
         return ms.value
 
     def download_internal(self):
@@ -888,7 +915,7 @@ def _newton_methods():
         """The same tiles as enable_gather_tiles(), computed on the device (gspx_graph_build_gather_tiles):
         milliseconds instead of half a second of numpy at N = 1M."""
         stats = np.zeros(4, dtype=np.int64)
-        _capi.check(_capi.load().gspx_graph_build_gather_tiles(self._h, _capi.ptr(stats)))
+        self.ctx.call(_capi.load().gspx_graph_build_gather_tiles, self._h, _capi.ptr(stats))
         nb = int(stats[0])
         return {"nb": nb, "mean_n1": float(stats[3]) / max(nb, 1), "slow_blocks": int(stats[1]),
                 "lds_bytes": int(stats[2])}
@@ -934,8 +961,8 @@ def _ops_methods():
 
     def laplacian_apply_dev(self, x_ptr, y_ptr, nsig):
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_laplacian_apply_dev(
-            self._h, int(nsig), ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), ctypes.byref(ms)))
+        self.ctx.call(_capi.load().gspx_laplacian_apply_dev,
+            self._h, int(nsig), ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), ctypes.byref(ms))
         return ms.value
 
     def laplacian_apply(self, x):
@@ -953,8 +980,8 @@ def _ops_methods():
     def dirichlet_energy_dev(self, x_ptr, nsig):
         gram = np.zeros((int(nsig), int(nsig)), dtype=np.float64)
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_dirichlet_energy_dev(
-            self._h, int(nsig), ctypes.c_void_p(x_ptr), _capi.ptr(gram), ctypes.byref(ms)))
+        self.ctx.call(_capi.load().gspx_dirichlet_energy_dev,
+            self._h, int(nsig), ctypes.c_void_p(x_ptr), _capi.ptr(gram), ctypes.byref(ms))
         return gram, ms.value
 
     def dirichlet_energy(self, x):
@@ -972,9 +999,9 @@ def _ops_methods():
         maxiter = 10 * self.N if maxiter is None else int(maxiter)
         iters = np.zeros(max(int(nsig), 1), dtype=np.int32)
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_tikhonov_cg_dev(
+        self.ctx.call(_capi.load().gspx_tikhonov_cg_dev,
             self._h, float(tau), ctypes.c_void_p(mask_ptr), int(nsig), ctypes.c_void_p(y_ptr),
-            ctypes.c_void_p(x_ptr), float(rtol), float(atol), maxiter, _capi.ptr(iters), ctypes.byref(ms)))
+            ctypes.c_void_p(x_ptr), float(rtol), float(atol), maxiter, _capi.ptr(iters), ctypes.byref(ms))
         return iters[:int(nsig)], ms.value
 
     def tikhonov_cg(self, tau, mask, y, rtol=1e-5, atol=0.0, maxiter=None):
@@ -1032,14 +1059,14 @@ def _ops_methods():
 
     def grad_dev(self, x_ptr, y_ptr, nsig):
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_grad_dev(self._h, int(nsig), ctypes.c_void_p(x_ptr),
-                                               ctypes.c_void_p(y_ptr), ctypes.byref(ms)))
+        self.ctx.call(_capi.load().gspx_grad_dev, self._h, int(nsig), ctypes.c_void_p(x_ptr),
+                                               ctypes.c_void_p(y_ptr), ctypes.byref(ms))
         return ms.value
 
     def div_dev(self, y_ptr, z_ptr, nsig):
         ms = ctypes.c_double(0)
-        _capi.check(_capi.load().gspx_div_dev(self._h, int(nsig), ctypes.c_void_p(y_ptr),
-                                              ctypes.c_void_p(z_ptr), ctypes.byref(ms)))
+        self.ctx.call(_capi.load().gspx_div_dev, self._h, int(nsig), ctypes.c_void_p(y_ptr),
+                                              ctypes.c_void_p(z_ptr), ctypes.byref(ms))
         return ms.value
 
     def _edge_op(self, x, rows_in, rows_out, fn, what):

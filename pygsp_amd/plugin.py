@@ -16,7 +16,11 @@ from . import engine, filters as _filters
 
 import threading
 
-_saved = {}
+# The originals of everything install() replaces are kept ON the patched object itself (attribute _gspx_saved of the
+# approximations module, of the Filter class, of the Graph class), so that two pygsp-shaped modules can be patched
+# and restored independently (one global table restored the first module's functions into the second).
+_SAVED = "_gspx_saved"
+_installed = {}  # id(module) -> module, in installation order (uninstall() without an argument: the last one)
 _config = {"laplacian": "device", "dtype": np.float64, "device": 0, "reorder": "auto", "tiles": "auto",
            "devices": None}
 _cache_lock = threading.RLock()
@@ -90,7 +94,7 @@ def _estimate_lmax_on_device(self, method="lanczos"):
     against the upper bound, increased by 1 % (graph.py:919-920), ValueError when it does not converge - and the
     same caching through ``_lmax_method``; every other method is the reference's own code."""
     if method != "lanczos":
-        return _saved["estimate_lmax"](self, method)
+        return _saved_on(type(self))["estimate_lmax"](self, method)
     if method == self._lmax_method:
         return
     ritz = _lanczos_ritz(device_graph_for(self, dtype=np.float64))
@@ -118,9 +122,18 @@ def to_device(G, s):
     return engine.DeviceArray.from_host(dev.ctx, arr, dev.dtype)
 
 
+def _saved_on(cls):
+    """The originals saved on the patched class `cls` derives from (or is)."""
+    for k in cls.__mro__:
+        saved = k.__dict__.get(_SAVED)
+        if saved is not None:
+            return saved
+    raise RuntimeError("pygsp_amd.plugin: {} is not a patched class".format(cls.__name__))
+
+
 def _reference_coefficients(bank, m):
-    # the coefficients of the patched package itself (approximations.py:9-55): its own code, its own kernels
-    return _saved["module"].filters.approximations.compute_cheby_coeff(bank, m=m)
+    # the coefficients of the bank's own package (approximations.py:9-55): its own code, its own kernels
+    return _saved_on(type(bank))["approximations"].compute_cheby_coeff(bank, m=m)
 
 
 def _filter_on_device(self, s, method="chebyshev", order=30):
@@ -130,7 +143,7 @@ def _filter_on_device(self, s, method="chebyshev", order=30):
     filter.py:318-321 (Nf cheby_op calls, each with its own host round trip), and a DeviceArray stays on the
     device.  Everything else (method='exact', unknown methods) is the reference's own code."""
     if method != "chebyshev":
-        return _saved["filter"](self, s, method=method, order=order)
+        return _saved_on(type(self))["filter"](self, s, method=method, order=order)
     return _filters.filter_signals(self, s, method, order, None, _reference_coefficients)
 
 
@@ -141,7 +154,7 @@ def _compute_frame_on_device(self, **kwargs):
     filter.py:270), run the reference's own code."""
     extra = set(kwargs) - {"method", "order"}
     if kwargs.get("method", "chebyshev") != "chebyshev" or extra or self.G.N in (1, self.Nf):
-        return _saved["compute_frame"](self, **kwargs)
+        return _saved_on(type(self))["compute_frame"](self, **kwargs)
     if self.G.N > 2000:  # filter.py:593-596
         _filters_logger(self).warning("Creating a big matrix. You should prefer the filter method.")
     return _filters.frame_panels(self, kwargs.get("order", 30), coefficients=_reference_coefficients)
@@ -177,46 +190,66 @@ def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, r
     _config.update(laplacian=laplacian, dtype=np.dtype(dtype), device=int(device), reorder=reorder,
                    tiles=tiles, devices=devices)
     approx = pygsp_module.filters.approximations
-    if "cheby_op" not in _saved:
-        _saved["cheby_op"] = approx.cheby_op
-        _saved["alias"] = getattr(pygsp_module.filters, "cheby_op", None)
-    _saved["module"] = pygsp_module
+    if _SAVED not in approx.__dict__:
+        setattr(approx, _SAVED, {"cheby_op": approx.cheby_op, "alias": getattr(pygsp_module.filters, "cheby_op", None)})
+    _installed.pop(id(pygsp_module), None)
+    _installed[id(pygsp_module)] = pygsp_module
     approx.cheby_op = _filters.cheby_op
     pygsp_module.filters.cheby_op = _filters.cheby_op
     filter_cls = getattr(pygsp_module.filters, "Filter", None)
     can_wrap = filter_cls is not None and hasattr(approx, "compute_cheby_coeff")
     if wrap_filter and can_wrap:
-        if "filter" not in _saved:
-            _saved["filter"], _saved["compute_frame"] = filter_cls.filter, filter_cls.compute_frame
+        if _SAVED not in filter_cls.__dict__:
+            setattr(filter_cls, _SAVED, {"filter": filter_cls.filter, "compute_frame": filter_cls.compute_frame,
+                                         "approximations": approx})
         filter_cls.filter, filter_cls.compute_frame = _filter_on_device, _compute_frame_on_device
-    elif "filter" in _saved and filter_cls is not None:
-        filter_cls.filter, filter_cls.compute_frame = _saved.pop("filter"), _saved.pop("compute_frame")
+    elif filter_cls is not None:
+        _restore(filter_cls, ("filter", "compute_frame"))
     graph_cls = getattr(getattr(pygsp_module, "graphs", None), "Graph", None)
     if lmax == "device" and graph_cls is not None:
-        if "estimate_lmax" not in _saved:
-            _saved["estimate_lmax"] = graph_cls.estimate_lmax
+        if _SAVED not in graph_cls.__dict__:
+            setattr(graph_cls, _SAVED, {"estimate_lmax": graph_cls.estimate_lmax})
         graph_cls.estimate_lmax = _estimate_lmax_on_device
-    elif "estimate_lmax" in _saved and graph_cls is not None:
-        graph_cls.estimate_lmax = _saved.pop("estimate_lmax")
+    elif graph_cls is not None:
+        _restore(graph_cls, ("estimate_lmax",))
     return pygsp_module
 
 
+def _restore(obj, names):
+    """Put back the originals saved on `obj` (a class or a module) and drop the table; no-op when there is none."""
+    saved = obj.__dict__.get(_SAVED)
+    if saved is None:
+        return None
+    for n in names:
+        setattr(obj, n, saved[n])
+    delattr(obj, _SAVED)
+    return saved
+
+
 def uninstall(pygsp_module=None):
-    if "cheby_op" not in _saved:
-        return
+    """Restore what install() replaced in `pygsp_module` (default: the module patched last; the importable pygsp
+    when nothing is recorded).  Other patched modules stay patched."""
     if pygsp_module is None:
-        import pygsp as pygsp_module
-    pygsp_module.filters.approximations.cheby_op = _saved.pop("cheby_op")
-    alias = _saved.pop("alias")
-    if alias is not None:
-        pygsp_module.filters.cheby_op = alias
-    _saved.pop("module", None)
+        if _installed:
+            pygsp_module = list(_installed.values())[-1]
+        else:
+            try:
+                import pygsp as pygsp_module
+            except ImportError:
+                return
+    _installed.pop(id(pygsp_module), None)
+    approx = pygsp_module.filters.approximations
+    saved = _restore(approx, ("cheby_op",))
+    if saved is None:
+        return
+    if saved["alias"] is not None:
+        pygsp_module.filters.cheby_op = saved["alias"]
     filter_cls = getattr(pygsp_module.filters, "Filter", None)
-    if "filter" in _saved and filter_cls is not None:
-        filter_cls.filter, filter_cls.compute_frame = _saved.pop("filter"), _saved.pop("compute_frame")
+    if filter_cls is not None:
+        _restore(filter_cls, ("filter", "compute_frame"))
     graph_cls = getattr(getattr(pygsp_module, "graphs", None), "Graph", None)
-    if "estimate_lmax" in _saved and graph_cls is not None:
-        graph_cls.estimate_lmax = _saved.pop("estimate_lmax")
+    if graph_cls is not None:
+        _restore(graph_cls, ("estimate_lmax",))
 
 
 def use_backend(name, pygsp_module=None, **install_options):

@@ -423,6 +423,100 @@ def test_install_wraps_and_restores_the_filter_methods():
         plugin.install(bare)
         assert bare.filters.cheby_op is filters.cheby_op and not hasattr(bare.filters, "Filter")
         plugin.uninstall(bare)
+        # two pygsp-shaped modules patched at once: each keeps and gets back ITS OWN originals, a wrapped
+        # method answers with its own package's code and coefficients, and uninstalling one leaves the other patched
+        one, two = make(), make()
+        two.filters.Filter.filter = lambda self, s, method="chebyshev", order=30: "filter of two"
+        two.filters.approximations.compute_cheby_coeff = lambda f, m=30: np.full(m + 1, 2.0)
+        own_one, own_two = one.filters.Filter.filter, two.filters.Filter.filter
+        ref_one, ref_two = one.filters.approximations.cheby_op, two.filters.approximations.cheby_op
+        plugin.install(one)
+        plugin.install(two)
+        assert one.filters.Filter().filter(None, method="exact") == "own filter"
+        assert two.filters.Filter().filter(None, method="exact") == "filter of two"
+        assert plugin._reference_coefficients(one.filters.Filter(), 3).tolist() == [1.0] * 4
+        assert plugin._reference_coefficients(two.filters.Filter(), 3).tolist() == [2.0] * 4
+        plugin.uninstall(one)
+        assert one.filters.Filter.filter is own_one and one.filters.approximations.cheby_op is ref_one
+        assert two.filters.Filter.filter is plugin._filter_on_device and two.filters.cheby_op is filters.cheby_op
+        plugin.uninstall()  # no argument: the module patched last that is still patched
+        assert two.filters.Filter.filter is own_two and two.filters.approximations.cheby_op is ref_two
+        assert not plugin._installed
+        plugin.uninstall(two)  # nothing left to restore: a no-op
     finally:
         plugin.uninstall(mod)
         plugin._config.update(dtype=np.dtype(np.float64))
+
+
+def test_device_array_pool_is_locked_and_gives_way_to_allocations():
+    """the recycled-buffer pool of a Context (take / give) is mutated from DeviceArray.__del__ and from
+    user threads - one lock - and must never be the reason an allocation fails: Context.call() empties it and runs a
+    failed call once more.  No device needed: the pool logic with stand-in buffers."""
+    import threading
+    from pygsp_amd import _capi, engine
+    ctx = engine.Context.__new__(engine.Context)  # no device: only the pool is exercised
+    ctx._h = None
+
+    class Buf:
+        def __init__(self, n):
+            self._h, self.ctx, self.nbytes, self.freed = 1, ctx, n, False
+
+        def free(self):
+            self.freed, self._h = True, None
+
+    b = Buf(100)
+    ctx.give(b)
+    assert ctx.pooled_bytes() == 100 and ctx.take(100) is b and ctx.pooled_bytes() == 0
+    big = Buf(ctx.POOL_BYTES + 1)
+    ctx.give(big)  # beyond the cap: freed, not kept
+    assert big.freed and ctx.pooled_bytes() == 0
+    # a failing allocation with buffers in the pool: pool emptied, call repeated once
+    kept = [Buf(64), Buf(64), Buf(32)]
+    for k in kept:
+        ctx.give(k)
+    calls = []
+
+    def alloc(*args):
+        calls.append(args)
+        return _capi.ERR_HIP if len(calls) == 1 else _capi.OK
+    ctx.call(alloc, 1, 2)
+    assert calls == [(1, 2), (1, 2)] and ctx.pooled_bytes() == 0 and all(k.freed for k in kept)
+    # nothing in the pool: no second attempt, the failure surfaces as the library's exception
+    calls.clear()
+    with pytest.raises(_capi.GspxError):
+        ctx.call(lambda *a: calls.append(a) or _capi.ERR_HIP)
+    assert len(calls) == 1
+    # argument errors are never retried
+    ctx.give(Buf(8))
+    calls.clear()
+    with pytest.raises(ValueError):
+        ctx.call(lambda *a: calls.append(a) or _capi.ERR_INVALID)
+    assert len(calls) == 1 and ctx.pooled_bytes() == 8
+    ctx.clear_pool()
+    # many threads giving and taking: the byte count stays exact
+    def take_or_new(n):  # Context.take without the device allocation behind it
+        with ctx._pool_state():
+            stack = ctx._pool.get(n)
+            if stack:
+                ctx._pooled -= n
+                return stack.pop()
+        return Buf(n)
+
+    def worker(seed):
+        mine = []
+        for i in range(300):
+            if mine and (i + seed) % 3 == 0:
+                ctx.give(mine.pop())
+            else:
+                mine.append(take_or_new(16))
+        for m in mine:
+            ctx.give(m)
+    ts = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    with ctx._pool_state():
+        assert ctx._pooled == 16 * sum(len(v) for v in ctx._pool.values())
+    ctx.clear_pool()
+    assert ctx.pooled_bytes() == 0
