@@ -410,6 +410,38 @@ def run_batch_config(local, rank, world, ctx, gdist, rdev, fence, comm):
             "parity_vs_oracle": {"max_rel_err": err, "columns": 1, "tolerance": 1e-5}}
 
 
+def reference_cpu_baseline(W, lmax, scale, K, xs):
+    """The reference's own Filter.filter on the CPU (filter.py:146-328 -> approximations.py:58-114) for the sample `xs`,
+    when a real pygsp is importable here ($PYGSP_PATH first, then an installed package): (seconds, result,
+    (version, location)) or None.  Never the product path: the plugin is not installed in this process."""
+    import importlib
+    extra = os.environ.get("PYGSP_PATH")
+    added = False
+    if extra and os.path.isdir(os.path.join(extra, "pygsp")) and extra not in sys.path:
+        sys.path.insert(0, extra)
+        added = True
+    try:
+        pygsp = importlib.import_module("pygsp")
+        approx = pygsp.filters.approximations
+        if getattr(approx.cheby_op, "__module__", "").startswith("pygsp_amd"):
+            return None  # patched: that would time the device, not the reference
+        G = pygsp.graphs.Graph(W)
+        G._lmax = lmax
+        G._lmax_method = "bounds"
+        flt = pygsp.filters.Heat(G, scale)
+        flt.filter(xs[:, :1], method="chebyshev", order=K)  # warm-up (builds G.L)
+        t0 = time.perf_counter()
+        y = flt.filter(xs, method="chebyshev", order=K)
+        dt = time.perf_counter() - t0
+        return dt, np.asarray(y).reshape(xs.shape), (getattr(pygsp, "__version__", "?"), os.path.dirname(pygsp.__file__))
+    except Exception as e:
+        sys.stderr.write("bench.py: no reference CPU baseline ({!r})\n".format(e))
+        return None
+    finally:
+        if added:
+            sys.path.remove(extra)
+
+
 def headline_other_dtype(a, ctx, G, c, x, lmax, dtype, oracle=True):
     """The headline workload (same graph, coefficients and signals) in `dtype`: device-resident rate, roofline of the
     recurrence step from its HIP-event times, parity of 2 columns against the float64 oracle."""
@@ -440,6 +472,7 @@ def headline_other_dtype(a, ctx, G, c, x, lmax, dtype, oracle=True):
     avg = steps_ms / max(launches, 1)
     res = {"dtype": "f32" if elt == 4 else "f64", "value": N * nsig * K * a.steps / elapsed,
            "unit": "vertex*signal*order/s", "ms_per_step": elapsed / a.steps * 1e3, "steps": a.steps,
+           "frac_whole_call": b_launch * K / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
            "roofline": {"bound": "hbm", "achieved": b_launch / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": b_launch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_launch,
                         "avg_launch_ms": avg, "launches_timed": launches, "traffic": None},
@@ -789,6 +822,8 @@ def main_threads(a):
         errs = [r.parity(2) for r in ranks]
         parity = {"max_rel_err": max(errs), "columns": 2, "ranks": n, "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
 
+    from pygsp_amd import engine
+    seen = engine.comm_info()  # after the gather: the device set ncclCommInitAll built, as RCCL reports it
     r0 = ranks[0]
     nnz_l = r0.dev.nnz_l
     U = N * nsig * elt
@@ -807,7 +842,9 @@ def main_threads(a):
             "N": N, "Nsig": nsig, "order": K, "Nf": 1, "nnz_W": int(r0.W.nnz), "nnz_L": int(nnz_l),
             "n_edges": int(r0.G.n_edges), "lmax": r0.lmax, "lmax_method": "bounds",
             "parallelism": "graph-parallel x{} (independent graphs, no data-path collective; one final gather)".format(n),
-            "evaluation": "recurrence", "engine_options": a.opt, "gather_tiles": r0.G.tile_stats},
+            "evaluation": "recurrence", "engine_options": a.opt, "gather_tiles": r0.G.tile_stats,
+            "gather_impl": gather["gather_impl"] if gather else None, "rccl_version": seen["rccl_version"],
+            "rccl_nranks_seen": seen["nranks"], "distinct_devices": group.n_distinct},
         "launcher": "one process, one driver thread + one libgspx context per GPU (no torch)",
         "devices": devices,
         "driver_thread_cores": [len(p) if p else None for p in group.pinned],  # NUMA pinning (multi.pin_thread_near)
@@ -993,6 +1030,7 @@ def main():
     # ---- the path's one collective, outside the timed region: outputs -> rank 0 ----------------
     gather_ms, gather_impl = None, None
     comm = None
+    comm_seen = None
     if torch is not None and not a.no_gather:
         fence()
         # in the library: RCCL grouped send / recv (gspx_comm_gather); torch only carried the 128-byte id
@@ -1057,6 +1095,7 @@ def main():
         if comm is not None:
             gather_ms = gdist.max_over_ranks(t_lib, rdev)
             gather_impl = "libgspx gspx_comm_gather: RCCL grouped ncclSend/ncclRecv, one xGMI link per peer"
+            comm_seen = comm.info()  # what RCCL itself says this communicator spans (ncclCommCount)
         else:
             fence()
             tg = time.perf_counter()
@@ -1167,6 +1206,10 @@ def main():
                                   if G._internal_order() is not None else "none",
                 "evaluation": a.evaluation,
                 "engine_options": a.opt, "gather_tiles": G.tile_stats,
+                # the path's one collective as this run executed it (self-validating on a multi-GPU node: the ranks RCCL
+                # itself reports must equal n_gpus)
+                "gather_impl": gather_impl, "rccl_version": (comm_seen or engine.comm_info())["rccl_version"],
+                "rccl_nranks_seen": comm_seen["nranks"] if comm_seen else 0, "launcher_world_size": world,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1279,6 +1322,19 @@ def main():
                       "present), {:.1f} s".format(cols, nsig, K, os.cpu_count(), t_cpu),
             "multi_core": cpu_all,
         }
+        # the reference ITSELF beside it whenever a real pygsp can be imported on this box (installed,
+        # or $PYGSP_PATH - /root/reference does not travel to the driver's GPU box, so the driver's line says "port")
+        ref_run = reference_cpu_baseline(W, lmax, a.scale, K, xs)
+        if ref_run is not None:
+            t_ref, y_ref, where = ref_run
+            out["cpu_baseline"].update(
+                kind="reference", value=N * cols * K / t_ref, port_value=N * cols * K / t_cpu,
+                sample="pygsp {} itself ({}): filters.Heat(G, {:g}).filter(x[:, :{}], method='chebyshev', order={}) "
+                       "on the same W and lmax, float64, one core, {:.1f} s; port_value = the oracle port on the same "
+                       "sample ({:.1f} s)".format(where[0], where[1], a.scale, cols, K, t_ref, t_cpu),
+                reference_vs_port_max_rel_diff=float(np.max(np.abs(y_ref - ref)) / np.max(np.abs(ref))))
+            out["parity_vs_reference"] = {"max_rel_err": float(np.max(np.abs(y[:, :cols] - y_ref)) / np.max(np.abs(y_ref))),
+                                          "columns": cols, "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
         out["parity_vs_oracle"] = {"max_rel_err": err, "columns": cols,
                                    "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
     # ---- the other BASELINE configs (N=1 only), appended after the headline keys ---------------------
@@ -1295,6 +1351,24 @@ def main():
             out["configs"] = {"error": repr(e)}
     if rank == 0 and parity_multi is not None:
         out["parity_vs_oracle"] = parity_multi
+    if rank == 0:
+        # the numbers a reader of the driver's record needs sit INSIDE `roofline` (the driver keeps that dict whole and
+        # only the names of the other extra keys): the same bytes over the whole call, the bytes measured over the
+        # bytes counted, the fp32 headline, the Newton form, the parity, the other configs' fractions
+        rf = out["roofline"]
+        rf["frac_whole_call"] = b_alg_call / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        rf["traffic_over_algorithmic"] = (traffic / b_alg_launch) if traffic else None
+        par = out.get("parity_vs_oracle") or {}
+        rf["parity_max_rel_err"], rf["parity_tolerance"] = par.get("max_rel_err"), par.get("tolerance")
+        f32 = out.get("headline_f32") or {}
+        rf["f32_frac"] = (f32.get("roofline") or {}).get("frac")
+        rf["f32_frac_whole_call"] = f32.get("frac_whole_call")
+        rf["f32_parity_max_rel_err"] = (f32.get("parity_vs_oracle") or {}).get("max_rel_err")
+        rf["newton_frac"] = (out.get("newton_form") or {}).get("frac_of_8TBps")
+        cfgs = out.get("configs")
+        if isinstance(cfgs, list):
+            rf["configs_frac"] = {"{}_{}".format(c_.get("key", i), c_.get("dtype", "")): (c_.get("roofline") or {}).get("frac")
+                                  for i, c_ in enumerate(cfgs) if isinstance(c_, dict)}
     if rank == 0 and batch5 is not None:
         out["batch_config4"] = batch5
     # C-level stdio first (RCCL prints a version banner through printf when a communicator is created; on a

@@ -242,6 +242,12 @@ int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
 int gspx_bench_gather(gspx_ctx* ctx, int64_t panel_rows, int row_bytes, int64_t n_gathers, int in_flight,
                       int blocks, double p_intra, int workgroups_per_cu, int iters, double* ms, double* gbps);
 
+/* What RCCL itself reports, for self-validating multi-GPU records (bench.py --gpus N): out[0] RCCL version code
+ * (ncclGetVersion, e.g. 22203; 0 when RCCL cannot be loaded), out[1] ranks the communicator spans as the communicator
+ * says (ncclCommCount) - for comm == NULL the device set of this process's last RCCL gspx_gather (0: none ran) -,
+ * out[2] this handle's rank (ncclCommUserRank; -1 for NULL). */
+int gspx_comm_info(gspx_comm* comm, int64_t out[3]);
+
 /* ---- experimental build only (make -C pygsp_amd/csrc experimental: -DGSPX_EXPERIMENTAL -> _lib/libgspx_exp.so) -------
  * Kernels that measured slower than what runs by default (the fused Newton pair of rounds 1-2, the small pair
  * kernel of round 4) or that are not cleared to run at size (two orders of the three-term recurrence per launch:

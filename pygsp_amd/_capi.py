@@ -125,6 +125,7 @@ SIGNATURES = {
     "gspx_comm_unique_id": (_c.c_int, [_P]),
     "gspx_comm_create": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _c.POINTER(_P)]),
     "gspx_comm_destroy": (_c.c_int, [_P]),
+    "gspx_comm_info": (_c.c_int, [_P, _P]),
     "gspx_comm_gather": (_c.c_int, [_P, _P, _P, _c.c_int, _P, _c.POINTER(_c.c_double)]),
     "gspx_bench_gather": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int,
                                      _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),

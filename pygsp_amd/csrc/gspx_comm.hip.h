@@ -29,6 +29,9 @@ struct Api {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;              // optional (reporting only)
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   std::string why;  // why loading failed
 };
 
@@ -66,7 +69,11 @@ static Api& instance() {
     if (!ok) {
       dlclose(a.lib);
       a.lib = nullptr;
+      return;
     }
+    a.GetVersion = (decltype(a.GetVersion))dlsym(a.lib, "ncclGetVersion");
+    a.CommCount = (decltype(a.CommCount))dlsym(a.lib, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(a.lib, "ncclCommUserRank");
   });
   return a;
 }
@@ -227,6 +234,7 @@ struct DeviceSet {
   std::mutex busy;
 };
 static std::mutex g_sets_mu;
+static std::atomic<int> g_last_set_ranks{0};  // ranks of the device set the last RCCL gspx_gather ran on (0: none yet)
 static std::vector<std::unique_ptr<DeviceSet>> g_sets;
 
 static DeviceSet* device_set(Api* R, const std::vector<int>& devs) {
@@ -304,10 +312,40 @@ static int gather_rccl(int n, gspx_buf** parts, gspx_buf* root_out, bool force) 
   }
   note(R->GroupEnd());
   RCCLCHK(bad);
+  {  // what the communicator itself says it spans (gspx_comm_info): not what this function was asked for
+    int cnt = (int)devs.size();
+    if (R->CommCount && R->CommCount(set->comms[(size_t)rr], &cnt) != ncclSuccess) cnt = -1;
+    gspx_rccl::g_last_set_ranks.store(cnt);
+  }
   for (size_t d = 0; d < devs.size(); ++d) {
     HIPCHK(hipSetDevice(devs[d]));
     HIPCHK(hipStreamSynchronize(lead[d]->stream));
   }
   HIPCHK(hipSetDevice(root->device));
+  return GSPX_OK;
+}
+
+// Reporting: what RCCL itself says.  out[0] = RCCL version code (ncclGetVersion; 0 when RCCL cannot be loaded or
+// does not export it), out[1] = ranks of the communicator as the communicator reports them (ncclCommCount; for
+// h == NULL: of the device set the last RCCL gspx_gather of this process ran on, 0 when there was none),
+// out[2] = this handle's rank in it (ncclCommUserRank; -1 for h == NULL).
+extern "C" int gspx_comm_info(gspx_comm* h, int64_t out[3]) {
+  if (!out) return set_err(GSPX_ERR_INVALID, "gspx_comm_info: null output");
+  out[0] = out[1] = 0;
+  out[2] = -1;
+  gspx_rccl::Api* R = gspx_rccl::api();
+  if (!R) return GSPX_OK;
+  int v = 0;
+  if (R->GetVersion && R->GetVersion(&v) == ncclSuccess) out[0] = v;
+  if (!h) {
+    out[1] = gspx_rccl::g_last_set_ranks.load();
+    return GSPX_OK;
+  }
+  if (!h->ctx || !h->comm) return set_err(GSPX_ERR_INVALID, "gspx_comm_info: the communicator's context was destroyed");
+  int cnt = h->nranks, rk = h->rank;
+  if (R->CommCount) RCCLCHK(R->CommCount(h->comm, &cnt));
+  if (R->CommUserRank) RCCLCHK(R->CommUserRank(h->comm, &rk));
+  out[1] = cnt;
+  out[2] = rk;
   return GSPX_OK;
 }

@@ -364,6 +364,14 @@ def comm_unique_id():
     return bytes(buf)
 
 
+def comm_info(comm=None):
+    """{"rccl_version", "nranks", "rank"} as RCCL reports them (gspx_comm_info): of `comm`, or - without one - of the
+    device set this process's last RCCL gspx_gather ran on (nranks 0: none has run).  Version 0: RCCL is unavailable."""
+    out = np.zeros(3, dtype=np.int64)
+    _capi.check(_capi.load().gspx_comm_info(comm._h if comm is not None else None, _capi.ptr(out)))
+    return {"rccl_version": int(out[0]), "nranks": int(out[1]), "rank": int(out[2])}
+
+
 class Comm:
     """RCCL communicator of one rank (gspx_comm): the one-process-per-GPU form of the path's only
     collective, the gather of the ranks' output blocks to a root over xGMI."""
@@ -387,6 +395,10 @@ class Comm:
             self._h, ctypes.c_void_p(part_ptr), _capi.ptr(table), int(root),
             ctypes.c_void_p(root_out_ptr) if root_out_ptr else None, ctypes.byref(ms)))
         return ms.value
+
+    def info(self):
+        """What RCCL itself reports about this communicator (gspx_comm_info): version code, ranks, own rank."""
+        return comm_info(self)
 
     def close(self):
         # (after its context is gone the handle is an empty shell inside libgspx - gspx_ctx_destroy took the RCCL
