@@ -349,7 +349,12 @@ static int cheb_pair_dev_t(gspx_graph* g, double lmax, int M, const double* c, i
   per_cu = std::max(1, std::min(per_cu, 4));
   if (ctx->opt.pair_workgroups_per_cu > 0) per_cu = (int)std::min<int64_t>(per_cu, ctx->opt.pair_workgroups_per_cu);
   unsigned nwg = (unsigned)std::max<int64_t>(8, ((int64_t)per_cu * ctx->cu_count) / 8 * 8);
+  // option "pair_workgroups" (absolute; round 5): a small grid makes every workgroup walk many blocks - the shape of
+  // the full-size runs - on a graph of a few thousand vertices (tools/pair_ladder.py)
+  if (ctx->opt.pair_workgroups > 0)
+    nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(ctx->opt.pair_workgroups, (int64_t)nwg) / 8 * 8);
   nwg = std::min(nwg, 8u * (unsigned)std::max(a.per_xcd, 1));
+  ctx->timing[7] = (double)nwg;
   ctx->timing[5] = (double)lds;
   ctx->timing[6] = (double)per_cu;
 
@@ -405,7 +410,7 @@ static int cheb_pair_dev_t(gspx_graph* g, double lmax, int M, const double* c, i
   ctx->timing[1] = f12;
   ctx->timing[2] = launches;
   ctx->timing[3] = f01;
-  ctx->timing[4] = 0;
+  ctx->timing[4] = ctx->timing[7];  // (experimental: the grid size, where the default path reports combine_ms)
   return GSPX_OK;
 }
 
