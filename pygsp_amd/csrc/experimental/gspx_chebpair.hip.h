@@ -30,12 +30,18 @@ template <typename T> struct ChebPairArgs {
   const u16* lidx2;      // [total2] positions in S2
   const u16* lidx1;      // [nnz_int] positions in S1 (own rows)
   const u16* ownpos;     // [N]
+  const int2* owndesc;   // [N]: the row's entry offset | padded length << 24 in its block's slice, offset of its S1 positions
   const T *P, *Q;
   T *A, *B, *R, *y;
   const int* perm;
   int N, BR, nb, per_xcd, ncol;
   u32 ld, ldy, panel_bytes;
   int off_g, off_val, off_idx1, off_idx2;  // LDS byte offsets (tile_h at 0)
+  int off_ms2, off_ms1, off_mown;          // k_cheb_pair2: the block's row lists / descriptors in LDS (first copy)
+  int meta_bytes;                          // ... and the distance to the second copy
+  u32 s2rows_bytes, desc_bytes, owndesc_bytes;
+  u32 val2_bytes, lidx2_bytes, lidx1_bytes;
+  unsigned long long* dbg;                 // GSPX_PAIR_DEBUG=1: per workgroup 8 cycle sums (wave 0), else null
   T sA, gA, sB, gB;
   T wB, wA, wP, wQ;
   int flush;   // 0 none, 1 write R, 2 accumulate into R
@@ -178,6 +184,288 @@ __global__ __launch_bounds__(512, 4) void k_cheb_pair(const ChebPairArgs<T> a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_cheb_pair2 (round 5): the same two orders per launch with the memory round trips taken off the critical path.
+// Round 5 measured the kernel above at size for the first time (tools/pair_ladder.py: parity-green at N = 1M, 0.40 of
+// 8 TB/s against 0.62 for single steps): every pass waited for chains of dependent global loads - the S2 row list
+// before each LDS-DMA instruction, the S1 descriptors and then the T_{k-2} rows inside phase 1, ownpos -> descriptor ->
+// rowptr -> rows inside phase 2, the block's entries at its first pass.  Here
+//   * a block's row lists / descriptors / own-row records live in LDS (two copies: the next block's are written during
+//     the current block's last pass), its matrix entries next to them: all loaded ONCE per block (its column chunks
+//     reuse them), fetched into registers one pass ahead;
+//   * the next tile's LDS-DMA and the T_{k-2} rows of the next phase 1 are issued right after the second barrier -
+//     the tile of the NEXT BLOCK's first chunk too - so they are in flight during phase 2; the own rows' T_{k-1} /
+//     T_{k-2} / accumulator values follow after the stores;
+//   * the LDS-DMA instructions of a tile are issued back to back (row numbers come from LDS);
+//   * row products fetch the next four entries while the tile rows of the current four are in flight.
+// A per-pass cycle breakdown (GSPX_PAIR_DEBUG=1, DBG builds) guided this: profiles/r05_pair_experiment.md.
+// IT1 / IT2: rows of S1 / of the block a row group handles per pass (IT1 * NG >= largest S1, IT2 * NG >= block rows).
+template <typename T, typename V, int LG, typename I>
+__device__ __forceinline__ V lds_row_dot_pf(const T* val, const I* idx, int len, const V* tile, int lane, V& self) {
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  typedef I I4 __attribute__((ext_vector_type(4)));
+  V acc = 0;
+  self = 0;
+  if (len <= 0) return acc;
+  I4 ia = *(const I4*)idx;
+  T4 va = *(const T4*)val;
+  for (int j = 0; j < len; j += 4) {
+    const int jn = j + 4 < len ? j + 4 : j;
+    const I4 ib = *(const I4*)(idx + jn);  // the next four entries: in flight with this trip's tile rows
+    const T4 vb = *(const T4*)(val + jn);
+    const V t0 = tile[ia.x * LG + lane];
+    const V t1 = tile[ia.y * LG + lane];
+    const V t2 = tile[ia.z * LG + lane];
+    const V t3 = tile[ia.w * LG + lane];
+    if (j == 0) self = t0;
+    acc += va.x * t0;
+    acc += va.y * t1;
+    acc += va.z * t2;
+    acc += va.w * t3;
+    ia = ib;
+    va = vb;
+  }
+  return acc;
+}
+
+template <typename T, int CW, int IT1, int IT2, bool DBG = false>
+__global__ __launch_bounds__(512, 4) void k_cheb_pair2(const ChebPairArgs<T> a) {
+  typedef unsigned long long u64;
+  u64 dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DBG: cycles of wave 0 in: tile wait, barrier A, phase 1, barrier B, phase 2, issue, passes, block change
+  constexpr int NT = 512, NG = NT / CW, RB = CW * 16, WR = 64 / CW;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int NEV = sizeof(T) == 8 ? 3 : 2;  // 16-byte pieces of matrix values a thread carries across a block boundary
+  typedef typename VT<T, VEC>::t V;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gspx_smem[];
+  constexpr u32 POISON = 0x80000000u;
+
+  const int tid = threadIdx.x, lane = tid % CW, grp = tid / CW, wave = tid >> 6;
+  const int nwx = (int)(gridDim.x >> 3);
+  const int xlo = (int)(blockIdx.x & 7) * a.per_xcd;
+  int k1 = xlo + a.per_xcd;
+  if (k1 > a.nb) k1 = a.nb;
+  int k = xlo + (int)(blockIdx.x >> 3);
+  if (k >= k1) return;
+
+  const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.P, 0, a.panel_bytes, 0x00020000);
+  const rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)a.Q, 0, a.Q ? a.panel_bytes : 0, 0x00020000);
+  const rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)a.R, 0, a.R ? a.panel_bytes : 0, 0x00020000);
+  const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.panel_bytes, 0x00020000);
+  const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, a.panel_bytes, 0x00020000);
+  const rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)a.val2, 0, a.val2_bytes, 0x00020000);
+  const rsrc_t rI2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.lidx2, 0, a.lidx2_bytes, 0x00020000);
+  const rsrc_t rI1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.lidx1, 0, a.lidx1_bytes, 0x00020000);
+  const u32 ldb = a.ld * (u32)sizeof(T);
+
+  V* const tile_h = (V*)gspx_smem;
+  V* const tile_g = (V*)(gspx_smem + a.off_g);
+  T* const val1 = (T*)(gspx_smem + a.off_val);
+  u16* const idx1 = (u16*)(gspx_smem + a.off_idx1);
+  u16* const idx2 = (u16*)(gspx_smem + a.off_idx2);
+  // the lists of a block, two copies mb = 0 / 1 (a.meta_bytes apart): rows of S2; per S1 row its row and entry
+  // offset | padded length << 24; per own row the same descriptor word and the offset of its entries' S1 positions
+  auto ms2 = [&](int mb) { return (int*)(gspx_smem + a.off_ms2 + mb * a.meta_bytes); };
+  auto ms1 = [&](int mb) { return (int2*)(gspx_smem + a.off_ms1 + mb * a.meta_bytes); };
+  auto mown = [&](int mb) { return (int2*)(gspx_smem + a.off_mown + mb * a.meta_bytes); };
+
+  struct Hdr { int4 p, q; };  // p: s1lo, n1, s2lo, n2; q: occ_base, ent1, rp0, ent2
+  auto load_hdr = [&](int kk) {
+    Hdr h;
+    h.p = *(const int4*)(a.hdr + (size_t)kk * 8);
+    h.q = *(const int4*)(a.hdr + (size_t)kk * 8 + 4);
+    return h;
+  };
+  auto uniform = [](Hdr h) {
+    Hdr u;
+    u.p.x = __builtin_amdgcn_readfirstlane(h.p.x); u.p.y = __builtin_amdgcn_readfirstlane(h.p.y);
+    u.p.z = __builtin_amdgcn_readfirstlane(h.p.z); u.p.w = __builtin_amdgcn_readfirstlane(h.p.w);
+    u.q.x = __builtin_amdgcn_readfirstlane(h.q.x); u.q.y = __builtin_amdgcn_readfirstlane(h.q.y);
+    u.q.z = __builtin_amdgcn_readfirstlane(h.q.z); u.q.w = __builtin_amdgcn_readfirstlane(h.q.w);
+    return u;
+  };
+  const rsrc_t rS2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.s2rows, 0, a.s2rows_bytes, 0x00020000);
+  const rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)a.desc, 0, a.desc_bytes, 0x00020000);
+  const rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)a.owndesc, 0, a.owndesc_bytes, 0x00020000);
+  // A contiguous slice of global memory -> LDS by LDS-DMA, no registers: n pieces of PB (4 or 16) bytes; a wave
+  // instruction moves 64 consecutive pieces.  Completion is tracked by vmcnt like the tile loads.
+  auto dma16 = [&](rsrc_t r, u32 src, int n, unsigned char* dst) {
+    for (int i0 = wave * 64; i0 < n; i0 += NT) {  // (wave-uniform)
+      const int i = i0 + (tid & 63);
+      if (i < n) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)(dst + i0 * 16), 16, src + (u32)i * 16u, 0, 0, 0);
+    }
+  };
+  auto dma4 = [&](rsrc_t r, u32 src, int n, unsigned char* dst) {
+    for (int i0 = wave * 64; i0 < n; i0 += NT) {
+      const int i = i0 + (tid & 63);
+      if (i < n) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)(dst + i0 * 4), 4, src + (u32)i * 4u, 0, 0, 0);
+    }
+  };
+  // a block's lists -> list copy mb (rows of S2, S1 descriptors, own-row records) ...
+  auto stage_meta = [&](const Hdr& h, int kk, int mb) {
+    dma4(rS2, (u32)h.p.z * 4u, h.p.w, (unsigned char*)ms2(mb));
+    dma4(rD, (u32)h.p.x * 8u, h.p.y * 2, (unsigned char*)ms1(mb));
+    int nown = a.N - kk * a.BR;
+    if (nown > a.BR) nown = a.BR;
+    dma4(rO, (u32)kk * (u32)a.BR * 8u, nown * 2, (unsigned char*)mown(mb));
+  };
+  // ... and its matrix entries (values, positions in S2 of the S1 rows' entries, positions in S1 of the own rows')
+  auto stage_entries = [&](const Hdr& h) {
+    const int ent1 = h.q.y, rp0 = h.q.z, ent2 = h.q.w;
+    const u32 occ = (u32)h.q.x;
+    dma16(rV, occ * (u32)sizeof(T), (ent1 * (int)sizeof(T) + 15) >> 4, (unsigned char*)val1);
+    dma16(rI2, occ * 2u, (ent1 * 2 + 15) >> 4, (unsigned char*)idx1);
+    dma16(rI1, (u32)rp0 * 2u, (ent2 * 2 + 15) >> 4, (unsigned char*)idx2);
+  };
+  auto chunk_off = [&](int c) {
+    const u32 col0 = (c * CW + lane) * VEC;
+    return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
+  };
+  // T_{k-1} on the S2 rows (list copy mb), column chunk at cb -> tile_h by LDS-DMA: a wave instruction writes WR tile rows
+  auto stage = [&](int mb, int n2, u32 cb) {
+    const int* rows = ms2(mb);
+    for (int t = 0; grp - (grp % WR) + NG * t < n2; ++t) {  // (wave-uniform trip count)
+      const int u = grp + NG * t;
+      if (u < n2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (lds_ptr)(gspx_smem + (wave * WR + NG * t) * RB), 16,
+                                                 (u32)rows[u] * ldb + cb, 0, 0, 0);
+    }
+  };
+  // the rows a pass reads from global memory, one pass ahead: T_{k-2} on the group's S1 rows (phase 1) ...
+  V q1[IT1], pp[IT2], qq[IT2], ra[IT2];
+  auto prefetch_q1 = [&](int mb, int n1, u32 cb) {
+    const int2* d1 = ms1(mb);
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+      const int o = grp + NG * it;
+      u32 off = POISON;
+      if (o < n1 && cb != POISON && a.gA != T(0)) off = (u32)d1[o].x * ldb + cb;
+      q1[it] = VT<T, VEC>::bload(rQ, off);
+    }
+  };
+  // ... and T_{k-1} / T_{k-2} / the accumulator on its own rows (phase 2)
+  auto prefetch_own = [&](int r0, u32 cb) {
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+      const int rr = grp + NG * it, row = r0 + rr;
+      const u32 off = (rr < a.BR && row < a.N && cb != POISON) ? (u32)row * ldb + cb : POISON;
+      pp[it] = VT<T, VEC>::bload(rP, off);
+      qq[it] = VT<T, VEC>::bload(rQ, (a.flush && a.wQ != T(0)) ? off : POISON);
+      ra[it] = VT<T, VEC>::bload(rR, a.flush == 2 ? off : POISON);
+    }
+  };
+
+  Hdr H = uniform(load_hdr(k));
+  int kn = k + nwx;
+  Hdr Hv = load_hdr(kn < k1 ? kn : k);
+  int mb = 0;  // the list copy of the current block
+  stage_meta(H, k, 0);
+  stage_entries(H);
+  Hdr Hn = uniform(Hv);
+  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+  __syncthreads();  // the first block's lists are in LDS
+  prefetch_q1(0, H.p.y, chunk_off(0));
+  stage(0, H.p.w, chunk_off(0));
+  prefetch_own(k * a.BR, chunk_off(0));
+  for (;;) {
+    const int n1 = H.p.y, n2 = H.p.w;
+    const int r0 = k * a.BR;
+    const int knn = kn + nwx;
+    const bool more = kn < k1;
+    for (int c = 0; c < a.ncol; ++c) {
+      const u32 cb = chunk_off(c);
+      const bool on = cb != POISON;
+      const u32 col0 = (c * CW + lane) * VEC;
+      const bool last = c == a.ncol - 1;
+      // every wave waits for its own tile loads (`buffer_load ... lds` is tracked by vmcnt only) and row prefetches
+      const u64 t0 = DBG ? __builtin_readcyclecounter() : 0;
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+      const u64 t1 = DBG ? __builtin_readcyclecounter() : 0;
+      __syncthreads();                     // tile_h (and a new block's entries) in place; tile_g free
+      const u64 t2 = DBG ? __builtin_readcyclecounter() : 0;
+      if (c == 0 && more) stage_meta(Hn, kn, mb ^ 1);  // the next block's lists -> the other copy, read from the last pass on
+      if (last) Hv = load_hdr(knn < k1 ? knn : k);     // ... and the header after it
+      const int2* const d1 = ms1(mb);
+      // ---- phase 1: A on S1 ---------------------------------------------------------------------------
+#pragma unroll
+      for (int it = 0; it < IT1; ++it) {
+        const int o = grp + NG * it;
+        if (o < n1) {
+          const int2 d = d1[o];
+          const int row = d.x, off = d.y & 0xFFFFFF, len = (int)((unsigned)d.y >> 24);
+          V self;
+          const V acc = lds_row_dot_pf<T, V, CW, u16>(val1 + off, idx1 + off, len, tile_h, lane, self);
+          const V av = a.sA * acc + a.gA * q1[it];
+          tile_g[o * CW + lane] = av;
+          if (on && row >= r0 && row < r0 + a.BR) VT<T, VEC>::bstore(rA, (u32)row * ldb + cb, av);
+        }
+      }
+      const u64 t3 = DBG ? __builtin_readcyclecounter() : 0;
+      if (a.ncol == 1) __builtin_amdgcn_s_waitcnt(0x0070);  // (one chunk per block: the lists staged in this very pass)
+      __syncthreads();  // tile_g complete; everybody is done with tile_h
+      const u64 t4 = DBG ? __builtin_readcyclecounter() : 0;
+      // the next pass's T_{k-2} rows and tile - of this block's next chunk, or of the next block's first - go in flight
+      // now: phase 2 does not touch tile_h
+      if (!last) {
+        prefetch_q1(mb, n1, chunk_off(c + 1));
+        stage(mb, n2, chunk_off(c + 1));
+      } else if (more) {
+        prefetch_q1(mb ^ 1, Hn.p.y, chunk_off(0));
+        stage(mb ^ 1, Hn.p.w, chunk_off(0));
+      }
+      const u64 t5 = DBG ? __builtin_readcyclecounter() : 0;
+      // ---- phase 2: B on the own rows -----------------------------------------------------------------
+#pragma unroll
+      for (int it = 0; it < IT2; ++it) {
+        const int rr = grp + NG * it, row = r0 + rr;
+        if (rr < a.BR && row < a.N) {
+          const int2 m = mown(mb)[rr];
+          const int off = m.x & 0xFFFFFF, len = (int)((unsigned)m.x >> 24);
+          V self;
+          const V acc = lds_row_dot_pf<T, V, CW, u16>(val1 + off, idx2 + m.y, len, tile_g, lane, self);
+          const V bv = a.sB * acc + a.gB * pp[it];
+          if (on) {
+            const u32 ro = (u32)row * ldb + cb;
+            VT<T, VEC>::bstore(rB, ro, bv);
+            if (a.flush) {
+              V res = a.wB * bv + a.wA * self + a.wP * pp[it] + a.wQ * qq[it];
+              if (a.flush == 2) res += ra[it];
+              if (a.final) {
+                const size_t orow = a.perm ? (size_t)a.perm[row] : (size_t)row;
+                *(V*)(a.y + orow * a.ldy + col0) = res;
+              } else {
+                VT<T, VEC>::bstore(rR, ro, res);
+              }
+            }
+          }
+        }
+      }
+      // the own rows of the next pass, after this pass's stores
+      if (!last) prefetch_own(r0, chunk_off(c + 1));
+      else if (more) prefetch_own(kn * a.BR, chunk_off(0));
+      if (DBG) {
+        const u64 t6 = __builtin_readcyclecounter();
+        dsum[0] += t1 - t0; dsum[1] += t2 - t1; dsum[2] += t3 - t2; dsum[3] += t4 - t3; dsum[4] += t6 - t5;
+        dsum[5] += t5 - t4; dsum[6] += 1;
+      }
+    }
+    if (!more) break;
+    const u64 tb0 = DBG ? __builtin_readcyclecounter() : 0;
+    __syncthreads();  // everybody is done with this block's entries
+    stage_entries(Hn);  // (complete at the next pass's wait, visible after its first barrier)
+    mb ^= 1;
+    H = Hn;
+    Hn = uniform(Hv);
+    k = kn;
+    kn = knn;
+    if (DBG) dsum[7] += __builtin_readcyclecounter() - tb0;
+  }
+  if (DBG && a.dbg && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = dsum[i];
+  }
+}
+
 // val2[i] = fval[src[i]]: the factor values per (block, S1 row) occurrence (rebuilt when lmax changes)
 template <typename T>
 __global__ void k_gather_vals(const T* __restrict__ fval, const int* __restrict__ src, size_t n, T* __restrict__ out) {
@@ -212,6 +500,7 @@ extern "C" int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int
   if ((int64_t)occ_off[n_s1] != n_lidx2) return set_err(GSPX_ERR_INVALID, "pair tiles: occ_off does not end at n_lidx2");
   std::vector<int> hdr((size_t)nb * 8), desc((size_t)n_s1 * 2), src((size_t)n_lidx2);
   std::vector<uint16_t> ownpos((size_t)N, 0), l1((size_t)g->nnz_int), l2((size_t)n_lidx2);
+  std::vector<int> owndesc((size_t)N * 2, 0);
   int n1max = 0, n2max = 0, e1max = 0, e2max = 0;
   for (int b = 0; b < nb; ++b) {
     const int lo = s1ptr[b], hi = s1ptr[b + 1];
@@ -230,6 +519,8 @@ extern "C" int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int
       for (int j = 0; j < len; ++j) src[(size_t)occ_off[o] + j] = rp[r] + j;
       if (r >= r0 && r < r1) {
         ownpos[r] = (uint16_t)(o - lo);
+        owndesc[(size_t)r * 2] = (int)rel | (len << 24);
+        owndesc[(size_t)r * 2 + 1] = rp[r] - rp[r0];
         ++found;
       }
     }
@@ -260,6 +551,7 @@ extern "C" int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int
   CHK(cp.src.alloc((size_t)n_lidx2 * 4 + 64));
   CHK(cp.val2.alloc((size_t)n_lidx2 * esz + 64));
   CHK(cp.ownpos.alloc((size_t)N * 2 + 64));
+  CHK(cp.owndesc.alloc((size_t)N * 8 + 64));
   HIPCHK(hipMemcpy(cp.hdr.p, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cp.desc.p, desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cp.s2rows.p, s2rows, (size_t)n_s2 * 4, hipMemcpyHostToDevice));
@@ -267,6 +559,9 @@ extern "C" int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int
   HIPCHK(hipMemcpy(cp.lidx2.p, l2.data(), (size_t)n_lidx2 * 2, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cp.src.p, src.data(), (size_t)n_lidx2 * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cp.ownpos.p, ownpos.data(), (size_t)N * 2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cp.owndesc.p, owndesc.data(), (size_t)N * 8, hipMemcpyHostToDevice));
+  cp.n_s1 = n_s1;
+  cp.n_s2 = n_s2;
   cp.rows = block_rows;
   cp.nb = nb;
   cp.n1max = n1max;
@@ -322,6 +617,10 @@ static int cheb_pair_dev_t(gspx_graph* g, double lmax, int M, const double* c, i
   a.lidx2 = cp.lidx2.as<gspx::u16>();
   a.lidx1 = cp.lidx1.as<gspx::u16>();
   a.ownpos = cp.ownpos.as<gspx::u16>();
+  a.owndesc = (const int2*)cp.owndesc.p;
+  a.s2rows_bytes = (unsigned)((size_t)cp.n_s2 * 4);
+  a.desc_bytes = (unsigned)((size_t)cp.n_s1 * 8);
+  a.owndesc_bytes = (unsigned)((size_t)N * 8);
   a.perm = perm;
   a.N = N;
   a.BR = cp.rows;
@@ -338,11 +637,41 @@ static int cheb_pair_dev_t(gspx_graph* g, double lmax, int M, const double* c, i
   a.off_val = (int)(sz_h + sz_g);
   a.off_idx1 = (int)(a.off_val + r16((size_t)cp.e1max * sizeof(T)));
   a.off_idx2 = (int)(a.off_idx1 + r16((size_t)cp.e1max * 2));
-  const size_t lds = (size_t)a.off_idx2 + r16((size_t)cp.e2max * 2) + 64;
-  if (lds > (size_t)160 * 1024) return set_err(GSPX_ERR_INVALID, "pair filter: tiles need %zu bytes of LDS", lds);
+  size_t lds = (size_t)a.off_idx2 + r16((size_t)cp.e2max * 2) + 64;
   typedef void (*kern_t)(const gspx::ChebPairArgs<T>);
-  const kern_t kern = CW == 2 ? (kern_t)gspx::k_cheb_pair<T, 2> : CW == 4 ? (kern_t)gspx::k_cheb_pair<T, 4> : CW == 8 ? (kern_t)gspx::k_cheb_pair<T, 8>
-                                                                                                              : (kern_t)gspx::k_cheb_pair<T, 16>;
+  kern_t kern = CW == 2 ? (kern_t)gspx::k_cheb_pair<T, 2> : CW == 4 ? (kern_t)gspx::k_cheb_pair<T, 4> : CW == 8 ? (kern_t)gspx::k_cheb_pair<T, 8>
+                                                                                                        : (kern_t)gspx::k_cheb_pair<T, 16>;
+  // option "pair_kernel": 2 (default) the pipelined build (k_cheb_pair2) when one exists for this shape, 1 the first one
+  if (ctx->opt.pair_kernel >= 2) {
+    const int NG = 512 / CW;
+    const int it1 = (cp.n1max + NG - 1) / NG, it2 = (cp.rows + NG - 1) / NG;
+    kern_t k2 = nullptr;
+#define GSPX_PAIR2(cw, i1, i2) \
+    if (CW == cw && it1 <= i1 && it2 <= i2 && !k2) k2 = (kern_t)gspx::k_cheb_pair2<T, cw, i1, i2>;
+    GSPX_PAIR2(2, 1, 1) GSPX_PAIR2(2, 2, 1)
+    GSPX_PAIR2(4, 1, 1) GSPX_PAIR2(4, 2, 1) GSPX_PAIR2(4, 3, 2)
+    GSPX_PAIR2(8, 2, 1) GSPX_PAIR2(8, 3, 1) GSPX_PAIR2(8, 4, 2)
+#undef GSPX_PAIR2
+    static const bool dbg_on = getenv("GSPX_PAIR_DEBUG") != nullptr;
+    if (k2 && dbg_on && std::is_same<T, double>::value) {
+      if (k2 == (kern_t)gspx::k_cheb_pair2<T, 8, 3, 1>) k2 = (kern_t)gspx::k_cheb_pair2<T, 8, 3, 1, true>;
+      if (k2 == (kern_t)gspx::k_cheb_pair2<T, 4, 2, 1>) k2 = (kern_t)gspx::k_cheb_pair2<T, 4, 2, 1, true>;
+    }
+    if (k2) {
+      kern = k2;
+      a.off_ms2 = (int)r16(lds);
+      a.off_ms1 = (int)(a.off_ms2 + r16((size_t)cp.n2max * 4));
+      a.off_mown = (int)(a.off_ms1 + r16((size_t)cp.n1max * 8));
+      a.meta_bytes = (int)(a.off_mown + r16((size_t)cp.rows * 8) - a.off_ms2);
+      lds = (size_t)a.off_ms2 + 2 * (size_t)a.meta_bytes + 64;
+      a.val2_bytes = (unsigned)std::min<size_t>((size_t)cp.total2 * sizeof(T) + 64, ((size_t)1 << 31) - 1);
+      a.lidx2_bytes = (unsigned)std::min<size_t>((size_t)cp.total2 * 2 + 64, ((size_t)1 << 31) - 1);
+      a.lidx1_bytes = (unsigned)std::min<size_t>((size_t)g->nnz_int * 2 + 64, ((size_t)1 << 31) - 1);
+      if ((size_t)cp.total2 * sizeof(T) >= ((size_t)1 << 31))
+        return set_err(GSPX_ERR_INVALID, "pair filter: the gathered matrix values exceed 2 GiB");
+    }
+  }
+  if (lds > (size_t)160 * 1024) return set_err(GSPX_ERR_INVALID, "pair filter: tiles need %zu bytes of LDS", lds);
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 1;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds));
@@ -357,6 +686,12 @@ static int cheb_pair_dev_t(gspx_graph* g, double lmax, int M, const double* c, i
   ctx->timing[7] = (double)nwg;
   ctx->timing[5] = (double)lds;
   ctx->timing[6] = (double)per_cu;
+  a.dbg = nullptr;
+  if (getenv("GSPX_PAIR_DEBUG")) {
+    CHK(ctx->ws_w.ensure((size_t)nwg * 64 + 64));
+    HIPCHK(hipMemsetAsync(ctx->ws_w.p, 0, (size_t)nwg * 64, st));
+    a.dbg = (unsigned long long*)ctx->ws_w.p;
+  }
 
   // pair j = steps 2j - 1 and 2j.  Panels: P = T_{2j-2}, Q = T_{2j-3}; A = T_{2j-1}, B = T_{2j} go to the two free ones
   int iP = 0, iQ = -1, iA = 1, iB = 2, free2 = 3;
@@ -403,6 +738,17 @@ static int cheb_pair_dev_t(gspx_graph* g, double lmax, int M, const double* c, i
   HIPCHK(hipEventRecord(e2, st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
+  if (a.dbg) {  // cycles of wave 0 of every workgroup in the LAST launch, averaged per pass
+    std::vector<unsigned long long> h((size_t)nwg * 8);
+    HIPCHK(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (unsigned w = 0; w < nwg; ++w)
+      for (int i = 0; i < 8; ++i) sum[i] += (double)h[(size_t)w * 8 + i];
+    const double np = std::max(sum[6], 1.0);
+    fprintf(stderr, "pair debug (cycles per pass, wave 0, %u workgroups, %.0f passes): tile wait %.0f | barrier A %.0f | phase 1 %.0f | "
+                    "barrier B %.0f | phase 2 %.0f | issue %.0f | block change (per pass) %.0f\n", nwg, np, sum[0] / np, sum[1] / np,
+            sum[2] / np, sum[3] / np, sum[4] / np, sum[5] / np, sum[7] / np);
+  }
   float f01 = 0, f12 = 0;
   HIPCHK(hipEventElapsedTime(&f01, e0, e1));
   HIPCHK(hipEventElapsedTime(&f12, e1, e2));

@@ -362,6 +362,7 @@ struct Options {
   int64_t pair_small = 0;         // 1: one- / two-signal calls on cache-resident graphs run two orders per launch (k_pair_small)
   int64_t pair_small_mb = 20;     // ... when the internal matrix (values + columns) is smaller than that many MB
   int64_t pair_workgroups_per_cu = 0;  // two-orders-per-launch kernel: at most that many resident workgroups per CU (0: what fits)
+  int64_t pair_kernel = 2;        // two-orders-per-launch: 2 the pipelined build (k_cheb_pair2), 1 the first build
 #endif
   int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
@@ -453,8 +454,8 @@ static std::atomic<uint64_t> g_generation{1};  // handles are told apart by birt
 #ifdef GSPX_EXPERIMENTAL
 // two-level row tiles of the two-orders-per-launch recurrence kernel (experimental/gspx_chebpair.hip.h)
 struct ChebPairTiles {
-  DevMem hdr, desc, s2rows, lidx1, lidx2, src, val2, ownpos;
-  int rows = 0, nb = 0, n1max = 0, n2max = 0, e1max = 0, e2max = 0;
+  DevMem hdr, desc, s2rows, lidx1, lidx2, src, val2, ownpos, owndesc;
+  int rows = 0, nb = 0, n1max = 0, n2max = 0, e1max = 0, e2max = 0, n_s1 = 0, n_s2 = 0;
   int64_t total2 = 0;
   double val_lmax = -1.0;  // lmax the gathered factor values val2 were built for
 };
@@ -638,6 +639,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "pair_workgroups_per_cu")) return &o.pair_workgroups_per_cu;
   if (!strcmp(key, "pair_small")) return &o.pair_small;
   if (!strcmp(key, "pair_small_mb")) return &o.pair_small_mb;
+  if (!strcmp(key, "pair_kernel")) return &o.pair_kernel;
 #endif
   if (!strcmp(key, "tile_gather")) return &o.tile_gather;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;

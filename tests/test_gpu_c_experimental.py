@@ -76,9 +76,15 @@ def test_pair_tiles_of_a_random_graph_are_refused(ctx):
 @pair_optin
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("block_rows", [64, 128, 256])
-def test_pair_kernel_equals_the_oracle(ctx, dtype, block_rows):
+@pytest.mark.parametrize("build,grid", [(2, 0), (2, 8), (1, 8)])
+def test_pair_kernel_equals_the_oracle(ctx, dtype, block_rows, build, grid):
     """A k-NN graph in curve order (what the tiles are for) and a ragged random graph with isolated vertices:
-    every chunk width, panels narrower / wider than a chunk, orders 2 ... 30 (1, 2, odd and even pair counts)."""
+    every chunk width, panels narrower / wider than a chunk, orders 2 ... 30 (1, 2, odd and even pair counts).
+    build: 2 the pipelined kernel of round 5 (k_cheb_pair2; shapes it has no build for run the first one), 1 the
+    first kernel; grid 8: eight persistent workgroups, so that every one walks MANY blocks (the shape of the
+    full-size runs: profiles/r05_pair_experiment.md rung a), 0: what fits."""
+    ctx.set_option("pair_kernel", build)
+    ctx.set_option("pair_workgroups", grid)
     tol = TOL[np.dtype(dtype)]
     G = graphs.Sensor(9000, k=7, seed=5, compute_dtype=dtype)
     G.estimate_lmax("bounds")
@@ -122,6 +128,8 @@ def test_pair_kernel_equals_the_oracle(ctx, dtype, block_rows):
         with pytest.raises(ValueError):
             dev.cheby_pair_filter_dev(np.ones(5), bx.ptr, bx.ptr, vec, lmax)  # no tiles
         bx.free()
+    ctx.set_option("pair_kernel", 2)
+    ctx.set_option("pair_workgroups", 0)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
