@@ -156,12 +156,15 @@ int gspx_curve_order(gspx_ctx* ctx, int64_t N, int d, const double* coords, int 
  * nullable) feed the internal order: order_mode 0 none, 1 auto (Hilbert in 2-D / Morton in 3-D, kept only when
  * it beats the graph's own order by 0.05 of locality score), 2 Morton, 3 Hilbert, 4 the permutation perm_in.
  * report[12]: [0] NaN entries, [1] infinite, [2] negative, [3] explicit zeros, [4] non-zero diagonal entries
- * (self-loops), [5] entries whose mirror entry is missing or different (directed graph), [6] CSR violations,
+ * (self-loops), [5] entries that differ from their mirror entry, a mirror that is not stored counting as zero
+ * (> 0: W - W.T has a nonzero = Graph.is_directed), [6] CSR violations,
  * [7] 1 when an internal order is in use, [8] / [9] locality score x 1e9 of the graph's own / the curve order
  * (auto mode), [10] 0 = graph built, 1 = not built, [11] microseconds of the whole call.
- * NaN / inf / CSR violations: GSPX_ERR_INVALID with the reference's message.  A directed graph or explicit zeros:
- * GSPX_OK with *out == NULL and report[10] == 1 - the host layer symmetrises (utils.symmetrize, graph.py:613-616)
- * / drops the zeros and calls gspx_graph_create_from_w. */
+ * NaN / inf / CSR violations: GSPX_ERR_INVALID with the reference's message.  A directed graph, or explicit zeros:
+ * the Laplacian is built from (W + W.T) / 2 without stored zeros - utils.symmetrize(W, 'average'), graph.py:613-616,
+ * utils.py:247-248; graph.py:126-128 - prepared on the device in the same call (transpose by radix sort, row merge;
+ * degrees = its row sums = (in + out) / 2, graph.py:834-837); the caller keeps W itself (and drops its zeros).
+ * Only a union pattern beyond 32-bit indices returns GSPX_OK with *out == NULL and report[10] == 1. */
 int gspx_graph_setup(gspx_ctx* ctx, int64_t N, int64_t nnz, const int32_t* indptr, const int32_t* indices,
                      const void* data, int data_dtype, int lap_type, int compute_dtype, const double* coords,
                      int d, int order_mode, const int32_t* perm_in, int64_t report[12], gspx_graph** out);

@@ -15,15 +15,17 @@
 //                   along the Hilbert / Morton curve = numpy's stable argsort of the keys
 //   k_locality      share of stored entries whose two vertices are at most `reach` positions apart, in the
 //                   graph's own order and in the curve order (the order is kept only if it wins by 0.05)
-// and then the existing device build (degrees, Laplacian, internal layout).  Anything the fast path does not
-// cover - a directed graph (the reference symmetrises it with (W + W.T)/2), explicit zeros to drop - is reported
-// to the host layer, which prepares W the old way and calls again.
+// and then the existing device build (degrees, Laplacian, internal layout).  A directed graph - the reference builds
+// its Laplacian from utils.symmetrize(W, 'average') = (W + W.T) / 2, graph.py:613-616, utils.py:247-248 - and a W with
+// explicit zeros to drop are prepared on the device too (round 5): transpose by the same stable radix sort (keys = the
+// column indices), a two-pointer merge of row i of W with row i of its transpose, entries whose sum is zero dropped
+// as scipy's sparse addition drops them (k_sym_count / k_sym_fill).
 #pragma once
 
 namespace gspx {
 
 struct WReport {  // device-side counters
-  unsigned long long nan, inf, neg, zero, diag, asym, bad;
+  unsigned long long nan, inf, neg, zero, diag, asym, bad, differ;
 };
 
 template <typename TIn> __device__ __forceinline__ bool setup_isnan(TIn v) { return v != v; }
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void k_w_inspect(const int* __restrict__ ptr, 
                                                    const TIn* __restrict__ val, int N, long long nnz,
                                                    WReport* __restrict__ rep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  unsigned nan = 0, inf = 0, neg = 0, zero = 0, diag = 0, asym = 0, bad = 0;
+  unsigned nan = 0, inf = 0, neg = 0, zero = 0, diag = 0, asym = 0, bad = 0, differ = 0;
   if (i < N) {
     const long long s = ptr[i], e = ptr[i + 1];
     if (s < 0 || e < s || e > nnz || (i == 0 && s != 0) || (i == N - 1 && e != nnz)) {
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(256) void k_w_inspect(const int* __restrict__ ptr, 
         // the mirror entry (c, i): binary search in row c (its bounds are checked before any read)
         const long long cs = ptr[c], ce = ptr[c + 1];
         bool same = false;
+        TIn mirror = TIn(0);  // a mirror entry that is not stored is a zero
         if (cs >= 0 && ce >= cs && ce <= nnz) {
           long long lo = cs, hi = ce;
           while (lo < hi) {
@@ -70,9 +73,12 @@ __global__ __launch_bounds__(256) void k_w_inspect(const int* __restrict__ ptr, 
             if (col[mid] < i) lo = mid + 1;
             else hi = mid;
           }
-          same = lo < ce && col[lo] == i && (val[lo] == v || (setup_isnan(v) && setup_isnan(val[lo])));
+          const bool found = lo < ce && col[lo] == i;
+          if (found) mirror = val[lo];
+          same = found && (val[lo] == v || (setup_isnan(v) && setup_isnan(val[lo])));
         }
-        asym += !same;
+        asym += !same;                // the fast path needs every mirror STORED and equal bit for bit ...
+        differ += !(v == mirror);     // ... Graph.is_directed (graph.py:357-405) asks whether W - W.T has a nonzero
       }
     }
   }
@@ -89,12 +95,68 @@ __global__ __launch_bounds__(256) void k_w_inspect(const int* __restrict__ ptr, 
   flush(diag, &rep->diag);
   flush(asym, &rep->asym);
   flush(bad, &rep->bad);
+  flush(differ, &rep->differ);
 }
 
 template <typename TIn, typename T>
 __global__ void k_setup_convert(const TIn* __restrict__ in, size_t n, T* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = (T)in[i];
+}
+
+// ---- (W + W.T) / 2 of a canonical CSR matrix, zero sums dropped (utils.symmetrize 'average' on scipy matrices) ------
+// The value type of the sum is the input's (float: float; double and int64: double - an int64 sum is exact, scipy
+// divides it in float64), so the result equals scipy's bit for bit.
+template <typename TIn> struct SymType { typedef double t; };
+template <> struct SymType<float> { typedef float t; };
+template <typename TIn> __device__ __forceinline__ typename SymType<TIn>::t sym_half_sum(TIn a, TIn b) {
+  typedef typename SymType<TIn>::t TS;
+  return (TS)(a + b) * TS(0.5);  // (long long: the sum first, exactly; then one conversion)
+}
+
+__global__ void k_sym_keys(const int* __restrict__ ptr, const int* __restrict__ col, int N,
+                           unsigned long long* __restrict__ keys, int* __restrict__ rows, int* __restrict__ cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  for (int j = ptr[i]; j < ptr[i + 1]; ++j) {
+    const int c = col[j];
+    keys[j] = (unsigned long long)(unsigned)c;  // sorted by column, stable: by (column, row) = the rows of W.T in order
+    rows[j] = i;
+    atomicAdd(&cnt[c], 1);
+  }
+}
+
+// Row i of W (ascending columns) merged with row i of W.T (entries order[t], t in [tptr[i], tptr[i+1]): ascending
+// original rows).  FILL == false: the number of entries with a nonzero sum -> cnt[i]; true: the entries -> out.
+template <typename TIn, bool FILL>
+__global__ __launch_bounds__(256) void k_sym_merge(const int* __restrict__ ptr, const int* __restrict__ col,
+                                                   const TIn* __restrict__ val, const int* __restrict__ tptr,
+                                                   const int* __restrict__ order, const int* __restrict__ rows, int N,
+                                                   int* __restrict__ cnt, const int* __restrict__ optr,
+                                                   int* __restrict__ ocol, typename SymType<TIn>::t* __restrict__ oval) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int a = ptr[i], t = tptr[i];
+  const int ae = ptr[i + 1], te = tptr[i + 1];
+  int n = 0, o = FILL ? optr[i] : 0;
+  while (a < ae || t < te) {
+    const int ca = a < ae ? col[a] : 0x7FFFFFFF;
+    const int e = t < te ? order[t] : 0;
+    const int ct = t < te ? rows[e] : 0x7FFFFFFF;
+    const int c = ca < ct ? ca : ct;
+    const TIn va = ca == c ? val[a] : TIn(0), vt = ct == c ? val[e] : TIn(0);
+    a += ca == c;
+    t += ct == c;
+    if ((va + vt) != TIn(0)) {  // scipy's sparse sum keeps no zero (csr_binop_csr)
+      if (FILL) {
+        ocol[o] = c;
+        oval[o] = sym_half_sum<TIn>(va, vt);
+        ++o;
+      }
+      ++n;
+    }
+  }
+  if (!FILL) cnt[i] = n;
 }
 
 // ---- stable LSD radix sort of (64-bit key, 32-bit payload) pairs, 8 bits per pass -----------------------
@@ -225,6 +287,44 @@ extern "C" int gspx_curve_order(gspx_ctx* ctx, int64_t N, int d, const double* c
 
 #define GSPX_I64 2 /* data_dtype of gspx_graph_setup only: int64 adjacency (ER / SBM graphs of the reference) */
 
+// (W + W.T) / 2 without stored zeros, on the device: sptr / scol / sval receive a canonical CSR matrix
+template <typename TIn>
+static int symmetrize_dev(gspx_ctx* ctx, int N, int64_t nnz, const int* wptr, const int* wcol, const TIn* wval,
+                          DevMem& sptr, DevMem& scol, DevMem& sval, int64_t* snnz) {
+  typedef typename gspx::SymType<TIn>::t TS;
+  hipStream_t st = ctx->stream;
+  const int nb = std::max(1, (N + 255) / 256);
+  DevMem keys, rows, order, tptr;
+  CHK(keys.alloc((size_t)std::max<int64_t>(nnz, 1) * 8));
+  CHK(rows.alloc((size_t)std::max<int64_t>(nnz, 1) * 4));
+  CHK(order.alloc((size_t)std::max<int64_t>(nnz, 1) * 4));
+  CHK(tptr.alloc((size_t)(N + 1) * 4));
+  CHK(sptr.alloc((size_t)(N + 1) * 4));
+  HIPCHK(hipMemsetAsync(tptr.p, 0, (size_t)(N + 1) * 4, st));
+  HIPCHK(hipMemsetAsync(sptr.p, 0, (size_t)(N + 1) * 4, st));
+  hipLaunchKernelGGL(gspx::k_sym_keys, dim3(nb), dim3(256), 0, st, wptr, wcol, N, (unsigned long long*)keys.p,
+                     rows.as<int>(), tptr.as<int>());
+  HIPCHK(hipGetLastError());
+  CHK(scan_exclusive(ctx, tptr.as<int>(), tptr.as<int>(), N + 1));  // column counts -> row starts of W.T
+  int bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < (int64_t)N) ++bits;
+  CHK(radix_argsort(ctx, (const unsigned long long*)keys.p, (int)nnz, bits, order.as<int>()));
+  hipLaunchKernelGGL((gspx::k_sym_merge<TIn, false>), dim3(nb), dim3(256), 0, st, wptr, wcol, wval, tptr.as<int>(),
+                     order.as<int>(), rows.as<int>(), N, sptr.as<int>(), (const int*)nullptr, (int*)nullptr, (TS*)nullptr);
+  HIPCHK(hipGetLastError());
+  CHK(scan_exclusive(ctx, sptr.as<int>(), sptr.as<int>(), N + 1));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, sptr.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost));
+  *snnz = total;
+  CHK(scol.alloc((size_t)std::max(total, 1) * 4));
+  CHK(sval.alloc((size_t)std::max(total, 1) * sizeof(TS)));
+  hipLaunchKernelGGL((gspx::k_sym_merge<TIn, true>), dim3(nb), dim3(256), 0, st, wptr, wcol, wval, tptr.as<int>(),
+                     order.as<int>(), rows.as<int>(), N, (int*)nullptr, sptr.as<int>(), scol.as<int>(), sval.as<TS>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  return GSPX_OK;
+}
+
 // W already on the device (uploaded by graph_setup_t below, or left there by the neighbour / block-model builders)
 template <typename TIn, typename T>
 static int graph_setup_core(gspx_graph* g, int64_t nnz, const int* wptr_d, const int* wcol_d, const TIn* wraw_d,
@@ -274,13 +374,25 @@ static int graph_setup_core(gspx_graph* g, int64_t nnz, const int* wptr_d, const
   report[2] = (int64_t)r.neg;
   report[3] = (int64_t)r.zero;
   report[4] = (int64_t)r.diag;
-  report[5] = (int64_t)r.asym;
+  report[5] = (int64_t)r.differ;  // > 0: W - W.T has a nonzero = the graph is directed (graph.py:357-405)
   report[6] = (int64_t)r.bad;
   report[10] = 1;  // not built (yet)
   if (r.bad) return set_err(GSPX_ERR_INVALID, "W is not a canonical CSR matrix (row bounds, ascending column indices, range)");
   if (r.nan) return set_err(GSPX_ERR_INVALID, "Adjacency: there is a Not a Number (NaN).");  // graph.py:112-114
   if (r.inf) return set_err(GSPX_ERR_INVALID, "Adjacency: there is an infinite value.");       // graph.py:115-117
-  if (r.asym || r.zero) return GSPX_OK;  // directed graph / explicit zeros: the host layer prepares W and calls again
+  // A directed graph (some mirror entry missing or different) or explicit zeros: the Laplacian is built from
+  // (W + W.T) / 2 without stored zeros (graph.py:613-616 / :126-128), prepared here on the device.
+  typedef typename gspx::SymType<TIn>::t TS;
+  DevMem sptr, scol, sval;
+  const bool prepared = r.asym || r.zero;
+  if (prepared) {
+    if (2 * nnz >= ((int64_t)1 << 31) - 8 * (int64_t)N - 64) return GSPX_OK;  // (its union pattern may not fit int32: host route)
+    int64_t snnz = 0;
+    CHK(symmetrize_dev<TIn>(ctx, N, nnz, wptr_d, wcol_d, wraw_d, sptr, scol, sval, &snnz));
+    wptr_d = sptr.as<int>();
+    wcol_d = scol.as<int>();
+    nnz = snnz;
+  }
 
   // ---- internal vertex order -----------------------------------------------------------------------------
   const bool want_curve = coords && d >= 2 && N >= 2 && (order_mode == 1 || order_mode == 2 || order_mode == 3);
@@ -319,7 +431,16 @@ static int graph_setup_core(gspx_graph* g, int64_t nnz, const int* wptr_d, const
 
   // ---- values in the compute dtype, then the ordinary device build ----------------------------------------
   const T* vals = nullptr;
-  if (std::is_same<TIn, T>::value) {
+  if (prepared) {  // the symmetrised values (float or double) in the compute dtype
+    if (std::is_same<TS, T>::value) {
+      vals = (const T*)sval.p;
+    } else {
+      CHK(wval.alloc((size_t)std::max<int64_t>(nnz, 1) * sizeof(T)));
+      if (nnz > 0)
+        hipLaunchKernelGGL((gspx::k_setup_convert<TS, T>), dim3(2048), dim3(256), 0, st, sval.as<TS>(), (size_t)nnz, wval.as<T>());
+      vals = wval.as<T>();
+    }
+  } else if (std::is_same<TIn, T>::value) {
     vals = (const T*)wraw_d;
   } else {
     CHK(wval.alloc((size_t)std::max<int64_t>(nnz, 1) * sizeof(T)));

@@ -116,17 +116,22 @@ class Graph:
             if "canonical" in str(e):
                 return False  # duplicates / unsorted indices: the host route sums and sorts them
             raise
-        if dev is None:  # directed, or explicit zeros to drop
+        if dev is None:  # (a directed graph whose union pattern would not fit 32-bit indices)
             return False
         if rep["self_loops"]:
             self.logger.warning("Adjacency: there are self-loops (non-zeros on the diagonal). "
                                 "The Laplacian will not see them.")
         if rep["negative"]:
             self.logger.warning("Adjacency: there are negative edge weights.")
+        if rep["zeros"]:  # graph.py:126-128: W keeps no edge of weight 0 (in place, like the reference; the device
+            adjacency.eliminate_zeros()  # Laplacian was built without them)
         self._adjacency = adjacency
         self.n_vertices = self.N = adjacency.shape[0]
-        self._flags["directed"] = False
-        self.n_edges = self.Ne = (adjacency.nnz - rep["self_loops"]) // 2 + rep["self_loops"]
+        # directed (W - W.T has a nonzero, counted on the device): the Laplacian was built from (W + W.T) / 2 in the
+        # same device call (graph.py:613-616); n_edges: stored entries, or unordered pairs + self-loops (graph.py:135-140)
+        directed = self._flags["directed"] = rep["asymmetric"] > 0
+        stored, loops = adjacency.nnz, rep["self_loops"]
+        self.n_edges = self.Ne = stored if directed else (stored - loops) // 2 + loops
         self._perm_done, self._perm_lazy = True, dev if rep["reordered"] else None
         self.setup_report = rep
         if self.tiles == "auto":
@@ -139,7 +144,7 @@ class Graph:
     def _setup_from_device_adjacency(self, adjacency):
         """A generator class hands over the W its device builder produced (engine.DeviceAdjacency): checks, vertex
         order and Laplacian run on it where it lies (gspx_graph_setup_from_knn); the host copy behind G.W is made
-        when somebody asks for it.  False when the host route has to take over (a directed W)."""
+        when somebody asks for it.  False when the host route has to take over."""
         order = self.reorder
         if isinstance(order, str) and order == "rcm":
             return False
@@ -151,15 +156,18 @@ class Graph:
         if order in ("morton", "hilbert") and adjacency.shape[0] < 4096:
             return False
         dev, rep = engine.DeviceGraph.setup_from(adjacency, self.lap_type, self.compute_dtype, coords, order)
-        if dev is None:
+        if dev is None or rep["zeros"]:  # (explicit zeros: W itself has to lose them - the host route)
+            if dev is not None:
+                dev.destroy()
             return False
         if rep["self_loops"]:
             self.logger.warning("Adjacency: there are self-loops (non-zeros on the diagonal). "
                                 "The Laplacian will not see them.")
         self._adj_dev = adjacency
         self.n_vertices = self.N = adjacency.shape[0]
-        self._flags["directed"] = False
-        self.n_edges = self.Ne = (adjacency.nnz - rep["self_loops"]) // 2 + rep["self_loops"]
+        directed = self._flags["directed"] = rep["asymmetric"] > 0  # (a 'tril' / 'triu' neighbour graph, a directed block model)
+        stored, loops = adjacency.nnz, rep["self_loops"]
+        self.n_edges = self.Ne = stored if directed else (stored - loops) // 2 + loops
         self._perm_done, self._perm_lazy = True, dev if rep["reordered"] else None
         self.setup_report = rep
         if self.tiles == "auto":
@@ -265,8 +273,16 @@ class Graph:
         dt = np.dtype(dtype or self.compute_dtype)
         g = self._dev.get(dt)
         if g is None:
-            g = engine.DeviceGraph.from_w(self._symmetric_w(), self.lap_type, dtype=dt,
-                                          perm=self._internal_order(), ctx=self.context)
+            perm = self._internal_order()
+            if self.is_directed() and sparse.isspmatrix_csr(self.W):
+                # (W + W.T) / 2 on the device, in the same call as the Laplacian (gspx_graph_setup)
+                try:
+                    g, _ = engine.DeviceGraph.setup(self.W, self.lap_type, dt, None, perm if perm is not None else "none",
+                                                    ctx=self.context)
+                except ValueError:
+                    g = None
+            if g is None:
+                g = engine.DeviceGraph.from_w(self._symmetric_w(), self.lap_type, dtype=dt, perm=perm, ctx=self.context)
             if self.tiles == "auto":  # LDS tiles for the recurrence step, when the order is local
                 self.tile_stats = g.auto_gather_tiles()
             elif self.tiles:

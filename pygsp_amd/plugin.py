@@ -64,8 +64,8 @@ def device_graph_for(G, ctx=None, dtype=None):
         one_call = (_config["laplacian"] == "device" and sparse.isspmatrix_csr(G.W) and order in ("auto", "none", None, False)
                     and not (order == "auto" and coords is None and G.N >= 4096))  # (no coordinates: RCM is host work)
         if one_call:
-            # checks, directedness, vertex order and Laplacian in one device call on the uploaded G.W
-            # (gspx_graph_setup); a directed graph / explicit zeros come back as None and take the route below
+            # checks, directedness, (W + W.T) / 2 of a directed graph, vertex order and Laplacian in one device call on
+            # the uploaded G.W (gspx_graph_setup)
             try:
                 dev, _ = engine.DeviceGraph.setup(G.W, G.lap_type, dtype, coords, order, ctx=ctx)
             except ValueError:

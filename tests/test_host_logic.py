@@ -297,7 +297,7 @@ def test_graph_keeps_a_device_adjacency_until_w_is_read(monkeypatch):
         def auto_gather_tiles(self):
             return {"enabled": False}
 
-    report = {"self_loops": 0, "negative": 0, "reordered": False, "built": True}
+    report = {"self_loops": 0, "negative": 0, "zeros": 0, "asymmetric": 0, "reordered": False, "built": True}
     monkeypatch.setattr(engine.DeviceGraph, "setup_from",
                         classmethod(lambda cls, adj, lap, dt, coords, order: (FakeDev(), dict(report))))
     G = graphs.Graph(FakeAdjacency(W))
