@@ -283,8 +283,9 @@ def run_config(key, workload, G, bank, nsig, K, dtype, ctx, oracle_cols=2, reps=
         "ms": best, "value": N * nsig * K / (best * 1e-3), "unit": "vertex*signal*order/s",
         "steps_ms": tm["steps_ms"], "combine_ms": tm["combine_ms"], "permute_ms": tm["permute_ms"],
         "step_launches": tm["step_launches"], "avg_step_ms": step_ms,
-        "roofline": {"bound": "hbm", "achieved": b_alg / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": b_alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": b_alg},
+        "roofline": dict({"bound": "hbm", "achieved": b_alg / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": b_alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": b_alg},
+                         **config_traffic(key, "f64" if elt == 8 else "f32")),
         # what a graph without vertex locality is really bound by: every stored entry fetches one panel
         # row through the L2 -> Infinity Cache / HBM path
         "gather": {"bytes_per_step": gather_bytes, "rate_GBps": gather_bytes / (step_ms * 1e-3) / 1e9},
@@ -408,6 +409,19 @@ def run_batch_config(local, rank, world, ctx, gdist, rdev, fence, comm):
             "n_graphs": n_graphs, "n_gpus": world, "ms": wall * 1e3, "value": n_graphs * N5 * nsig * K / wall,
             "unit": "vertex*signal*order/s", "gather_ms": gather_ms,
             "parity_vs_oracle": {"max_rel_err": err, "columns": 1, "tolerance": 1e-5}}
+
+
+def config_traffic(key, dtype):
+    """Measured HBM traffic of a config's recurrence step from the committed PMC passes (profiles/traffic_configs.json,
+    tools/config_traffic.py: separate rocprofv3 --pmc runs of `bench.py --no-headline --only-config <key>`; counters
+    cannot be read from inside this process): traffic per step launch and its ratio to the algorithmic bytes."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs.json")))["{}_{}".format(key, dtype)]
+    except Exception:
+        return {"traffic": None}
+    return {"traffic": t["hbm_bytes_per_step_launch"], "traffic_over_algorithmic": t["traffic_over_algorithmic"],
+            "traffic_TBps_in_the_counted_run": t["hbm_TBps"], "tcc_hit_rate": t["tcc_hit_rate"],
+            "traffic_source": "profiles/traffic_configs.json: " + t["method"]}
 
 
 def reference_cpu_baseline(W, lmax, scale, K, xs):
