@@ -377,6 +377,8 @@ struct Options {
   int64_t copy_threads = 0;       // host threads of a staged copy (0: 8)
   int64_t tile_regroup = 1;     // 1: rows of 3 / 5 / 6 / 7 / 10 / 12 / 14 sixteen-byte pieces run the builds whose compute
                                 // phases regroup the lanes by pieces (k_step_tile<..., CL>); 0: the power-of-two builds
+  int64_t tile_br128 = 0;       // 1: 80- to 128-byte rows run the 8-lane build on 128-row blocks (round-5 experiment:
+                                // measured, see profiles/r05_narrow_rows.md)
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
@@ -498,6 +500,10 @@ struct gspx_graph {
   int gt_rows = 0, gt_nb = 0, gt_slow = 0;
   size_t gt_lds = 0;
   int gt_entmax = 0;  // most stored entries of a staged block (sizes the LDS of the narrow builds)
+  // the same lists for 128-row blocks (option "tile_br128": the 8-lane build on 80- to 128-byte rows; built on first use)
+  DevMem g2_hdr, g2_s1rows, g2_lidx;
+  int g2_nb = 0, g2_slow = 0, g2_entmax = 0;
+  bool g2_built = false;
   // differential operator (built on first use; gspx_ops.hip.h)
   int lap_type = GSPX_LAP_COMBINATORIAL;
   bool edges_built = false;
@@ -645,6 +651,7 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
+  if (!strcmp(key, "tile_br128")) return &o.tile_br128;
   if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
   if (!strcmp(key, "staged_copy")) return &o.staged_copy;
   if (!strcmp(key, "staged_copy_min_mb")) return &o.staged_copy_min_mb;
@@ -1493,16 +1500,14 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
 }
 
 // the same tiles, computed on the device from the internal CSR (no host arrays)
-extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
-  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
-  replay_reset(g->ctx);
+// the gather tiles of BR-row blocks, built on the device (k_tiles_unique / k_tiles_fill): lists, positions, headers
+template <int BR>
+static int build_tiles_dev(gspx_graph* g, size_t lds, DevMem& hdr, DevMem& s1rows, DevMem& lidx, int* out_nb, int* out_ns1,
+                           int* out_slow, int* out_entmax) {
   gspx_ctx* ctx = g->ctx;
-  HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
-  if (N < 1) return set_err(GSPX_ERR_INVALID, "empty graph");
-  const int nb = (N + GSPX_TILE_BR - 1) / GSPX_TILE_BR;
-  const size_t lds = (size_t)52 * 1024;
+  const int nb = (N + BR - 1) / BR;
   DevMem tmp, n1, keep, s1lo, nslow;
   CHK(tmp.alloc((size_t)nb * GSPX_TILE_TMPCAP * sizeof(int)));
   CHK(n1.alloc(((size_t)nb + 1) * sizeof(int)));
@@ -1510,7 +1515,7 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   CHK(s1lo.alloc(((size_t)nb + 1) * sizeof(int)));
   CHK(nslow.alloc(sizeof(int)));
   HIPCHK(hipMemsetAsync(nslow.p, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_tiles_unique, dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
+  hipLaunchKernelGGL((k_tiles_unique<BR>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
                      tmp.as<int>(), n1.as<int>());
   hipLaunchKernelGGL(k_tiles_keep, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, n1.as<int>(), nb,
                      keep.as<int>());
@@ -1518,20 +1523,34 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   int n_s1 = 0;
   HIPCHK(hipMemcpyAsync(&n_s1, s1lo.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  CHK(g->gt_hdr.alloc((size_t)nb * 4 * sizeof(int) + 64));
-  CHK(g->gt_s1rows.alloc((size_t)std::max(n_s1, 1) * 4 + 64));
-  CHK(g->gt_lidx.alloc((size_t)g->nnz_int + 128));
-  hipLaunchKernelGGL(k_tiles_fill, dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
+  CHK(hdr.alloc((size_t)nb * 4 * sizeof(int) + 64));
+  CHK(s1rows.alloc((size_t)std::max(n_s1, 1) * 4 + 64));
+  CHK(lidx.alloc((size_t)g->nnz_int + 128));
+  hipLaunchKernelGGL((k_tiles_fill<BR>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
                      tmp.as<int>(), n1.as<int>(), s1lo.as<int>(), (int)elt_size(g->dtype), (int)lds,
-                     g->gt_s1rows.as<int>(), g->gt_lidx.as<unsigned char>(), g->gt_hdr.as<int>(),
-                     nslow.as<int>());
+                     s1rows.as<int>(), lidx.as<unsigned char>(), hdr.as<int>(), nslow.as<int>());
   int slow = 0, entmax = 0;
   HIPCHK(hipMemcpyAsync(&slow, nslow.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemsetAsync(nslow.p, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_tiles_entmax, dim3((nb + 255) / 256), dim3(256), 0, st, g->gt_hdr.as<int>(), nb, nslow.as<int>());
+  hipLaunchKernelGGL(k_tiles_entmax, dim3((nb + 255) / 256), dim3(256), 0, st, hdr.as<int>(), nb, nslow.as<int>());
   HIPCHK(hipMemcpyAsync(&entmax, nslow.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
+  *out_nb = nb;
+  *out_ns1 = n_s1;
+  *out_slow = slow;
+  *out_entmax = entmax;
+  return GSPX_OK;
+}
+
+extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  replay_reset(g->ctx);
+  HIPCHK(hipSetDevice(g->ctx->device));
+  if (g->N < 1) return set_err(GSPX_ERR_INVALID, "empty graph");
+  const size_t lds = (size_t)52 * 1024;
+  int nb = 0, n_s1 = 0, slow = 0, entmax = 0;
+  CHK(build_tiles_dev<GSPX_TILE_BR>(g, lds, g->gt_hdr, g->gt_s1rows, g->gt_lidx, &nb, &n_s1, &slow, &entmax));
   g->gt_rows = GSPX_TILE_BR;
   g->gt_nb = nb;
   g->gt_ns1 = n_s1;
@@ -1539,6 +1558,7 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   g->gt_slow = slow;
   g->gt_lds = lds;
   g->gt_entmax = entmax;
+  g->g2_built = false;  // (the 128-row lists, if anybody asks for them, are rebuilt from the same pattern)
   if (stats) {
     stats[0] = nb;
     stats[1] = slow;
@@ -1941,6 +1961,20 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
 #undef GSPX_CL
     if (k2) kern = k2, threads = nt2;
   }
+  // round-5 experiment (option "tile_br128"): the 8-lane build on 128-row blocks for rows of 80 to 128 bytes
+  bool br128 = false;
+  if (opt.tile_br128 && lg == 8 && threads == 512 && flavour != 1 && g->N >= 4096) {
+    if (!g->g2_built) {
+      int ns1 = 0;
+      CHK(build_tiles_dev<128>(g, (size_t)72 * 1024, g->g2_hdr, g->g2_s1rows, g->g2_lidx, &g->g2_nb, &ns1, &g->g2_slow,
+                               &g->g2_entmax));
+      g->g2_built = true;
+    }
+    if (g->g2_slow * 50 <= g->g2_nb) {
+      br128 = true;
+      kern = flavour == 2 ? (kern_t)k_step_tile<T, 1, 8, false, true, 512, 8, 128> : (kern_t)k_step_tile<T, 1, 8, false, false, 512, 8, 128>;
+    }
+  }
   // dynamic LDS: the wide builds take the tile budget the blocks were classified with; a narrow build's tile
   // rows are 16 lg bytes, so the largest staged block needs far less - and more workgroups fit a CU
   size_t lds = g->gt_lds;
@@ -1948,6 +1982,9 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
     lds = std::min(lds, (size_t)GSPX_TILE_MAXN1 * 16 * lg + (((size_t)g->gt_entmax * sizeof(T) + 15) & ~(size_t)15) +
                             (((size_t)g->gt_entmax + 15) & ~(size_t)15) + 64);
   if (lg < 8) lds = (lds + 2047) & ~(size_t)2047;  // (graphs differ in their largest block: few distinct sizes)
+  if (br128)
+    lds = ((size_t)256 * 128 + (((size_t)g->g2_entmax * sizeof(T) + 15) & ~(size_t)15) + (((size_t)g->g2_entmax + 15) & ~(size_t)15) +
+           64 + 2047) & ~(size_t)2047;
   int per_cu = 2;
   {  // once per kernel build, device and LDS size (a driver call per launch would cost microseconds each)
     struct Known { size_t attr = 0; std::map<size_t, int> fit; };
@@ -1972,15 +2009,16 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   t.rowptr = g->rptr.as<int>();
   t.col = g->rcol.as<int>();
   t.val = vals ? vals : g->fval.as<T>();  // any values array on the internal pattern
-  t.hdr = g->gt_hdr.as<int>();
-  if (!t.s1rows) t.s1rows = g->gt_s1rows.as<int>();  // (the caller may pass the lists in its panel's row order)
-  t.lidx = g->gt_lidx.as<unsigned char>();
+  t.hdr = br128 ? g->g2_hdr.as<int>() : g->gt_hdr.as<int>();
+  if (br128) t.s1rows = g->g2_s1rows.as<int>();
+  else if (!t.s1rows) t.s1rows = g->gt_s1rows.as<int>();  // (the caller may pass the lists in its panel's row order)
+  t.lidx = br128 ? g->g2_lidx.as<unsigned char>() : g->gt_lidx.as<unsigned char>();
   t.N = (int)g->N;
   t.ld = ld;
   t.panel_bytes = (unsigned)((size_t)g->N * ld * sizeof(T));
   t.val_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
   t.lidx_bytes = (unsigned)((size_t)g->nnz_int);
-  t.nb = g->gt_nb;
+  t.nb = br128 ? g->g2_nb : g->gt_nb;
   t.ncol = ncol;
   t.per_xcd = (t.nb + 7) / 8;
   t.lds_bytes = (int)lds;

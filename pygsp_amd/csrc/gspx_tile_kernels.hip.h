@@ -102,11 +102,16 @@ template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
 // with LG-lane groups a quarter to three eighths of the lanes idled through every row product.  CL == LG: as before.
 // (two resident workgroups of 320 / 384 threads are 10 / 12 waves per CU, three per SIMD: those builds may use 168
 // registers; their longer row lists per staging group - 8 / 7 instead of 5 - would spill at 128)
-template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false, int NT = 512, int CL = LG>
+// BR: rows per block (64; 128 for the round-5 experiment on 80- to 128-byte rows: twice the bytes per pass against the
+// same two barriers, row lists and entry staging, 1.6 instead of 1.9 staged rows per row; its own tile set, positions
+// still 8 bits: a staged tile holds at most 256 rows)
+template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false, int NT = 512, int CL = LG,
+          int BR = GSPX_TILE_BR>
 __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   static_assert(NT == 512 || (NT == 64 * LG && NCOL == 1) || (CL < LG && NCOL == 1 && NT % 64 == 0 && NT % CL == 0),
                 "narrow builds: one row per group, one chunk per row");
-  static_assert(CL <= LG && (GSPX_TILE_BR % (NT / CL)) == 0, "compute groups must tile the block's rows");
+  static_assert(CL <= LG && (BR % (NT / CL)) == 0, "compute groups must tile the block's rows");
+  constexpr int MAXN1 = BR == GSPX_TILE_BR ? GSPX_TILE_MAXN1 : 256;
   constexpr bool PF = TileSchedule<T, NCOL, LG, OLDNAT>::PF;
   constexpr bool META_AFTER = TileSchedule<T, NCOL, LG, OLDNAT>::META_AFTER;
   constexpr bool TILE_LAST = TileSchedule<T, NCOL, LG, OLDNAT>::TILE_LAST;
@@ -120,8 +125,8 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   constexpr int NGD = NT / LG;             // staging (LDS-DMA) groups per workgroup: LG lanes each
   constexpr int NG = NT / CL;              // compute row groups per workgroup: CL lanes each
   constexpr int NE = (512 + NT - 1) / NT;  // 16-byte pieces of matrix values a thread prefetches
-  constexpr int RPG = GSPX_TILE_BR / NG;   // rows of the block per compute group
-  constexpr int ST = (GSPX_TILE_MAXN1 + NGD - 1) / NGD;  // tile rows a staging group loads
+  constexpr int RPG = BR / NG;   // rows of the block per compute group
+  constexpr int ST = (MAXN1 + NGD - 1) / NGD;  // tile rows a staging group loads
   constexpr int RB = LG * 16;              // bytes of a tile row
   const int lane_d = tid & (LG - 1);       // staging lane / group
   const int grp_d = tid / LG;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
       const int u = grp_d + NGD * t;
       m.rows[t] = a.s1rows[h.x + (u < n1 ? u : 0)];
     }
-    int r = phys(k) * GSPX_TILE_BR + grp * RPG;
+    int r = phys(k) * BR + grp * RPG;
 #pragma unroll
     for (int t = 0; t < RPG + 1; ++t) m.rp[t] = a.rowptr[(r + t) <= a.N ? (r + t) : a.N];
     if constexpr (OLDNAT) {
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
 #pragma unroll
   for (int q = 0; q < NE; ++q) ev[q] = 0;
   auto prefetch_rows = [&](const Meta& m, int blk, int c) {
-    const int r0 = phys(blk) * GSPX_TILE_BR + grp * RPG;
+    const int r0 = phys(blk) * BR + grp * RPG;
     const u32 cb = chunk_off(c);
 #pragma unroll
     for (int t = 0; t < RPG; ++t) {
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
     const bool fast = n1 >= 0;
     T* const mval = (T*)(tile + (fast ? n1 : 0) * LG);
     u8* const midx = (u8*)(mval + ent);
-    const int row0 = phys(k) * GSPX_TILE_BR + grp * RPG;
+    const int row0 = phys(k) * BR + grp * RPG;
     int rs[RPG + 1];
 #pragma unroll
     for (int t = 0; t < RPG + 1; ++t) rs[t] = M.rp[t] & ~3;
@@ -438,13 +443,14 @@ namespace gspx {
 constexpr int GSPX_TILE_SORTCAP = 4096;  // entries of a block the LDS sort holds
 constexpr int GSPX_TILE_TMPCAP = 256;    // distinct rows kept per block (more: the block is "slow")
 
+template <int BR = GSPX_TILE_BR>
 __global__ __launch_bounds__(256) void k_tiles_unique(const int* __restrict__ rowptr,
                                                       const int* __restrict__ col, int N, int nb,
                                                       int* __restrict__ tmp, int* __restrict__ n1) {
   __shared__ unsigned keys[GSPX_TILE_SORTCAP];
   __shared__ int wsum[4];
   const int b = blockIdx.x;
-  const int r0 = b * GSPX_TILE_BR, r1 = min(r0 + GSPX_TILE_BR, N);
+  const int r0 = b * BR, r1 = min(r0 + BR, N);
   const int e0 = rowptr[r0] & ~3, e1 = rowptr[r1] & ~3;
   const int ent = e1 - e0;
   if (ent > GSPX_TILE_SORTCAP) {  // a hub: no tile for this block
@@ -498,19 +504,23 @@ __global__ __launch_bounds__(256) void k_tiles_unique(const int* __restrict__ ro
   if (threadIdx.x == 0) n1[b] = base;
 }
 
+// (BR = 64: tiles of 256-byte rows, at most 160 of them; BR = 128: the 8-lane builds' 128-byte rows, at most 256)
+template <int BR = GSPX_TILE_BR>
 __global__ __launch_bounds__(256) void k_tiles_fill(const int* __restrict__ rowptr,
                                                     const int* __restrict__ col, int N, int nb,
                                                     const int* __restrict__ tmp, const int* __restrict__ n1,
                                                     const int* __restrict__ s1lo, int esz, int lds_bytes,
                                                     int* __restrict__ s1rows, u8* __restrict__ lidx,
                                                     int* __restrict__ hdr, int* __restrict__ nslow) {
+  constexpr int MAXN1 = BR == GSPX_TILE_BR ? GSPX_TILE_MAXN1 : 256;
+  constexpr int ROWB = BR == GSPX_TILE_BR ? 256 : 128;
   const int b = blockIdx.x;
-  const int r0 = b * GSPX_TILE_BR, r1 = min(r0 + GSPX_TILE_BR, N);
+  const int r0 = b * BR, r1 = min(r0 + BR, N);
   const int e0 = rowptr[r0] & ~3, e1 = rowptr[r1] & ~3;
   const int ent = e1 - e0;
   const int n = n1[b];
-  const long need = (long)n * 256 + (((long)ent * esz + 15) & ~15L) + (((long)ent * 2 + 15) & ~15L) + 32;
-  const bool fast = n <= GSPX_TILE_MAXN1 && need <= lds_bytes;
+  const long need = (long)n * ROWB + (((long)ent * esz + 15) & ~15L) + (((long)ent * 2 + 15) & ~15L) + 32;
+  const bool fast = n <= MAXN1 && need <= lds_bytes;
   const int lo = s1lo[b];
   if (threadIdx.x == 0) {
     hdr[(size_t)b * 4 + 0] = lo;
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(256) void k_tiles_fill(const int* __restrict__ rowp
       }
       pos = a;
     }
-    lidx[e0 + i] = (u8)pos;  // fast blocks: pos < GSPX_TILE_MAXN1 <= 255
+    lidx[e0 + i] = (u8)pos;  // fast blocks: pos < MAXN1 <= 256
   }
 }
 // kept rows per block for the scan (a slow block beyond the cap contributes none)

@@ -32,11 +32,16 @@ def main():
         for w in widths:
             xs = np.ascontiguousarray(x[:, :w])
             bx, by = ctx.upload(xs), ctx.alloc(xs.nbytes)
+            y_first = None
             for setting in ((0, 1, 0, 1) if ab else (None,)):
                 if ab:
                     ctx.set_option(ab, setting)
                 ms = [dev.cheby_filter_dev(c, bx.ptr, by.ptr, w, float(G.lmax)) for _ in range(12)]
                 t = ctx.last_timing()
+                y = by.download(xs.shape, dtype)  # both settings must produce the same result
+                if y_first is None:
+                    y_first = y
+                diff = float(np.max(np.abs(y - y_first)) / max(float(np.max(np.abs(y_first))), 1e-300))
                 best = float(np.median(ms[3:]))
                 U = G.N * w * elt
                 b_alg = K * (dev.nnz_l * (elt + 4) + 4 * (G.N + 1) + 3 * U) + U
@@ -45,6 +50,7 @@ def main():
                              "steps_ms": t["steps_ms"], "step_launches": t["step_launches"]})
                 if ab:
                     rows[-1][ab] = setting
+                    rows[-1]["rel_diff_vs_setting_0"] = diff
             bx.free()
             by.free()
         G.__dict__.pop("_dev", None)
