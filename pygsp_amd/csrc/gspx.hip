@@ -377,8 +377,10 @@ struct Options {
   int64_t copy_threads = 0;       // host threads of a staged copy (0: 8)
   int64_t tile_regroup = 1;     // 1: rows of 3 / 5 / 6 / 7 / 10 / 12 / 14 sixteen-byte pieces run the builds whose compute
                                 // phases regroup the lanes by pieces (k_step_tile<..., CL>); 0: the power-of-two builds
-  int64_t tile_br128 = 0;       // 1: 80- to 128-byte rows run the 8-lane build on 128-row blocks (round-5 experiment:
-                                // measured, see profiles/r05_narrow_rows.md)
+#ifdef GSPX_EXPERIMENTAL
+  int64_t tile_br128 = 0;       // 1: 96- to 128-byte rows run the 8-lane build on 128-row blocks (round-5 experiment:
+                                // bit-identical, -3.7 ... +0.8 %: profiles/r05_narrow_rows.md)
+#endif
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
@@ -651,7 +653,9 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
+#ifdef GSPX_EXPERIMENTAL
   if (!strcmp(key, "tile_br128")) return &o.tile_br128;
+#endif
   if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
   if (!strcmp(key, "staged_copy")) return &o.staged_copy;
   if (!strcmp(key, "staged_copy_min_mb")) return &o.staged_copy_min_mb;
@@ -1961,9 +1965,12 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
 #undef GSPX_CL
     if (k2) kern = k2, threads = nt2;
   }
-  // round-5 experiment (option "tile_br128"): the 8-lane build on 128-row blocks for rows of 80 to 128 bytes
+  // round-5 experiment (option "tile_br128", experimental build only): the 8-lane build on 128-row blocks
   bool br128 = false;
-  if (opt.tile_br128 && lg == 8 && threads == 512 && flavour != 1 && g->N >= 4096) {
+#ifdef GSPX_EXPERIMENTAL
+  // (not the launches whose tile rows come from the caller's unpermuted panel - step 1 of a fused-input call passes
+  // its own row lists -: those lists exist for the 64-row blocks only)
+  if (opt.tile_br128 && lg == 8 && threads == 512 && flavour != 1 && !t.s1rows && g->N >= 4096) {
     if (!g->g2_built) {
       int ns1 = 0;
       CHK(build_tiles_dev<128>(g, (size_t)72 * 1024, g->g2_hdr, g->g2_s1rows, g->g2_lidx, &g->g2_nb, &ns1, &g->g2_slow,
@@ -1975,6 +1982,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
       kern = flavour == 2 ? (kern_t)k_step_tile<T, 1, 8, false, true, 512, 8, 128> : (kern_t)k_step_tile<T, 1, 8, false, false, 512, 8, 128>;
     }
   }
+#endif
   // dynamic LDS: the wide builds take the tile budget the blocks were classified with; a narrow build's tile
   // rows are 16 lg bytes, so the largest staged block needs far less - and more workgroups fit a CU
   size_t lds = g->gt_lds;

@@ -628,7 +628,8 @@ def test_default_library_has_no_experimental_options(ctx):
     context options: a caller cannot switch a slower / uncleared kernel on by accident."""
     if _capi.experimental:
         pytest.skip("the experimental build is loaded (GSPX_LIB_PATH)")
-    for key in ("pair_small", "pair_small_mb", "newton_pair", "pair_workgroups", "pair_workgroups_per_cu"):
+    for key in ("pair_small", "pair_small_mb", "newton_pair", "pair_workgroups", "pair_workgroups_per_cu", "pair_kernel",
+                "tile_br128"):
         with pytest.raises(ValueError, match="unknown option"):
             ctx.set_option(key, 1)
     assert not hasattr(engine.DeviceGraph, "cheby_pair_filter_dev")

@@ -223,3 +223,30 @@ def test_pair_small_two_orders_per_launch(ctx, dtype):
         assert np.array_equal(dev.cheby_filter(c2, x[:, :1], lmax)[0], b1)
     finally:
         ctx.set_option("pair_small", 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tile_kernel_on_128_row_blocks_is_bit_identical(ctx, dtype):
+    """Option tile_br128 (round-5 experiment, profiles/r05_narrow_rows.md): rows of 96 to 128 bytes run the 8-lane build
+    of k_step_tile on 128-row blocks (their own row lists, 8-bit positions in tiles of up to 256 rows).  Same row
+    products in the same order: the result equals the default's bit for bit, single filters and synthesis steps."""
+    G = graphs.Sensor(60000, k=7, seed=21, compute_dtype=dtype)
+    G.estimate_lmax("bounds")
+    assert G.tile_stats and G.tile_stats["enabled"]
+    rng = np.random.default_rng(5)
+    vec = 16 // np.dtype(dtype).itemsize
+    try:
+        for nsig in (6 * vec, 7 * vec, 8 * vec):  # 96-, 112-, 128-byte rows
+            x = rng.standard_normal((G.N, nsig)).astype(dtype)
+            outs = []
+            for setting in (0, 1):
+                ctx.set_option("tile_br128", setting)
+                y = filters.Heat(G, 10).filter(x, order=21)
+                bank = filters.MexicanHat(G, Nf=3)
+                z = bank.synthesize(bank.analyze(x[:, :nsig], order=12), order=12)
+                outs.append((y, z))
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), nsig
+            ref = orc.filter_chebyshev(orc.laplacian(G.W), G.lmax, [orc.heat_kernel(10, G.lmax)], x.astype(np.float64), 21)
+            assert rel_err(outs[1][0], ref) < TOL[np.dtype(dtype)]
+    finally:
+        ctx.set_option("tile_br128", 0)
