@@ -1026,17 +1026,9 @@ def main():
             n_elapsed = gdist.max_over_ranks(n_elapsed, rdev)
         return n_elapsed, n_ms
 
-    newton = newton_pair = None
+    newton = None
     if a.evaluation == "recurrence" and not a.no_newton:
         newton = time_newton()
-    if a.evaluation == "recurrence" and not a.no_newton and world == 1 and _capi.experimental:
-        # the same, two orders per launch (fused pair kernel of the EXPERIMENTAL build only - GSPX_LIB_PATH=
-        # .../libgspx_exp.so; needs the host-built row tiles: seconds of numpy per rank)
-        from pygsp_amd import experimental
-        experimental.attach()
-        tiles = dev.enable_pair_tiles()
-        newton_pair = time_newton() + (tiles,)
-        dev.disable_pair_tiles()
     if newton is not None:
         step_recurrence()  # leave the headline result in y for the parity check / the gather below
         fence()
@@ -1140,18 +1132,14 @@ def main():
 
     tiled = bool(G.tile_stats and G.tile_stats.get("enabled"))
 
-    def newton_report(r, pair):
+    def newton_report(r):
         ms_order = r[1] / (K * a.steps)
-        out = {"note": ("same polynomial in Newton form, two orders per launch with the h panel staged in "
-                        "LDS (fused pair kernel, opt-in: DeviceGraph.enable_pair_tiles())") if pair else
-                       ("same interpolating polynomial in Newton form (two-term Horner recurrence, no "
+        out = {"note": ("same interpolating polynomial in Newton form (two-term Horner recurrence, no "
                         "accumulator): opt-in evaluation='newton'; parity-tested against the reference"),
                "value": world * N * nsig * K * a.steps / r[0], "ms_per_step": r[0] / a.steps * 1e3,
                "ms_per_order": ms_order,
                "achieved_GBps_alg": b_alg_launch / (ms_order * 1e-3) / 1e9,
                "frac_of_8TBps": b_alg_launch / (ms_order * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if pair:
-            out["tiles"] = r[2]
         return out
 
     # the streaming-copy rate of THIS box and process, right after the timed region: the recurrence runs at
@@ -1236,8 +1224,7 @@ def main():
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "avg_launch_ms": avg_launch_ms, "launches_timed": launches,
             },
-            "newton_form": None if newton is None else newton_report(newton, False),
-            "newton_form_pair": None if newton_pair is None else newton_report(newton_pair, True),
+            "newton_form": None if newton is None else newton_report(newton),
             "device_ms_per_step": dev_ms / a.steps,
             "device_ms_recurrence_per_step": steps_ms_max / a.steps,
             "gather_ms": gather_ms, "gather_impl": gather_impl,

@@ -54,6 +54,7 @@ typedef struct gspx_buf gspx_buf;
 #define GSPX_ERR_COEFF 2   /* M < 2 (approximations.py:83-84)       -> TypeError   */
 #define GSPX_ERR_HIP 3     /* HIP runtime failure                   -> RuntimeError*/
 #define GSPX_ERR_NODEVICE 4
+#define GSPX_ERR_OOM 5     /* device allocation failed, nothing written yet -> RuntimeError (safe to retry) */
 
 const char* gspx_last_error(void);
 const char* gspx_version(void);

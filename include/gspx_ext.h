@@ -235,6 +235,20 @@ int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);
 /* Calibration: read-only GB/s of a `bytes`-sized buffer streamed `passes` times in one launch. */
 int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
 
+/* Calibration, the MIX CEILING of the LDS-staged recurrence step: exactly the call
+ * gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, NULL) would make - the same plan, the
+ * same M-1 k_step_tile launches on the same grid over the same buffers, the same LDS-DMA tile loads of the same row
+ * lists, the same T_{k-2} / accumulator loads, entry stream, stores, flush steps, sweep directions and cache bits - with
+ * the ARITHMETIC REMOVED from every launch: the per-entry LDS gathers and multiply-adds of the row products are
+ * replaced by one tile read per row.  mode 1 keeps the two workgroup barriers of a pass, mode 2 drops them as well
+ * (the access mix alone).  y_dev receives numbers without meaning.  Times are read with gspx_last_timing as after
+ * any filter call.  Only for calls that run the wide builds (gather tiles, rows of more than 128 bytes); the one
+ * launch per call that reads T_{k-2} from the caller's unpermuted panel (step 2, "fuse_input") runs unmodified.
+ * What it answers: step time == mix time  =>  the step is bound by the memory system serving this access mix (on
+ * this box), not by its arithmetic or LDS traffic; step time > mix time  =>  the compute phase is exposed. */
+int gspx_bench_step_mix(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig, const void* x_dev,
+                        void* y_dev, int mode);
+
 /* Calibration for graphs WITHOUT vertex locality (BASELINE configs 2, 3: Erdos-Renyi, block model): the rate
  * of random row gathers, measured with nothing else in the way.  n_gathers rows of row_bytes (64 / 128 / 256 /
  * 512; 16 bytes per lane, the step kernels' lane layout) are fetched from a panel of panel_rows rows by 32-bit
@@ -250,45 +264,6 @@ int gspx_bench_gather(gspx_ctx* ctx, int64_t panel_rows, int row_bytes, int64_t 
  * says (ncclCommCount) - for comm == NULL the device set of this process's last RCCL gspx_gather (0: none ran) -,
  * out[2] this handle's rank (ncclCommUserRank; -1 for NULL). */
 int gspx_comm_info(gspx_comm* comm, int64_t out[3]);
-
-/* ---- experimental build only (make -C pygsp_amd/csrc experimental: -DGSPX_EXPERIMENTAL -> _lib/libgspx_exp.so) -------
- * Kernels that measured slower than what runs by default (the fused Newton pair of rounds 1-2, the small pair
- * kernel of round 4) or that are not cleared to run at size (two orders of the three-term recurrence per launch:
- * profiles/r04_pair_experiment.md, profiles/r05_pair_experiment.md).  The default libgspx.so exports none of them
- * and rejects their context options ("newton_pair", "pair_workgroups", "pair_workgroups_per_cu", "pair_small",
- * "pair_small_mb"). */
-#ifdef GSPX_EXPERIMENTAL
-/* Optional acceleration structure for gspx_newton_filter*: two-level row tiles (32-row blocks) of
- * the internal vertex order, computed on the host from the internal pattern
- * (pygsp_amd/tiling.py).  With tiles set (and option "newton_pair" = 1, the default) two Horner
- * steps run per launch with the panel staged in LDS: the pass moves fewer bytes than the
- * algorithmic count of two steps.  block_rows == 0 drops the tiles. */
-int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
-                         const int32_t* s1rows, const int32_t* s2ptr, const int32_t* s2rows,
-                         const uint16_t* lidx1, const uint32_t* occ_off, int64_t n_lidx2,
-                         const uint16_t* lidx2, int max_n1, int max_n2);
-/* out[0] row blocks, out[1] blocks handled by the unstaged fallback kernel (tiles too large to hold
- * their matrix entries in LDS, or rows longer than 32 entries), out[2] dynamic LDS bytes per
- * workgroup of that fallback kernel (the staged kernel always takes 80 KB), out[3] rows per block
- * (0: no tiles set) */
-int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]);
-
-/* TWO orders of the three-term recurrence per launch (opt-in experiment of round 4): the tile
- * data of pygsp_amd/tiling.py (levels = 2) for blocks of 64 / 128 / 256 rows of the graph's internal order - per
- * block the row lists of its 1-hop (S1) and 2-hop (S2) closures, per stored entry of a block row its position in
- * S1 (lidx1, 0xFFFF for pads), per (block, S1 row) occurrence where that row's entries' positions in S2 start in
- * lidx2.  block_rows == 0 drops the tiles.  stats (may be NULL): blocks, largest S1, largest S2, most entries of
- * a block's S1 rows, of its own rows, entries of lidx2. */
-int gspx_graph_set_cheb_pair_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr, const int32_t* s1rows,
-                                   const int32_t* s2ptr, const int32_t* s2rows, const uint16_t* lidx1,
-                                   const uint32_t* occ_off, int64_t n_lidx2, const uint16_t* lidx2, int64_t stats[6]);
-/* cheby_op (approximations.py:58-114) for ONE filter of even order M - 1 with those tiles: (M - 1) / 2 launches,
- * each computing T_k on the block's 1-hop closure in LDS and T_{k+1} on its rows; column chunks of chunk_lanes
- * (2 / 4 / 8 / 16) x 16 bytes.  x_dev, y_dev: N x Nsig row-major in the graph's own vertex order, rows of whole
- * 16-byte pieces.  Same result as gspx_cheby_filter_dev up to the association order of the final sum. */
-int gspx_cheby_pair_filter_dev(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig,
-                               const void* x_dev, void* y_dev, int chunk_lanes, double* kernel_ms);
-#endif /* GSPX_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -3,9 +3,6 @@
 The library is built in-tree (pygsp_amd/_lib/libgspx.so) by ``__graft_entry__.build()`` /
 ``make -C pygsp_amd/csrc``.  There is NO CPU fallback: if the shared object is missing, or no
 HIP device is visible, every product entry point raises.
-
-``make -C pygsp_amd/csrc experimental`` builds _lib/libgspx_exp.so: the same library plus the kernels that do not run
-by default (SIGNATURES_EXPERIMENTAL below; pygsp_amd/experimental.py).  GSPX_LIB_PATH selects it.
 """
 import ctypes
 import os
@@ -20,7 +17,7 @@ F32, F64 = 0, 1
 LAP_COMBINATORIAL, LAP_NORMALIZED = 0, 1
 ANALYSIS, SYNTHESIS = 0, 1
 
-OK, ERR_INVALID, ERR_COEFF, ERR_HIP, ERR_NODEVICE = 0, 1, 2, 3, 4
+OK, ERR_INVALID, ERR_COEFF, ERR_HIP, ERR_NODEVICE, ERR_OOM = 0, 1, 2, 3, 4, 5
 
 _lib = None
 
@@ -130,19 +127,8 @@ SIGNATURES = {
     "gspx_bench_gather": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int,
                                      _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "gspx_bench_copy": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),
+    "gspx_bench_step_mix": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _c.c_int64, _P, _P, _c.c_int]),
 }
-
-# exported only by the experimental build (-DGSPX_EXPERIMENTAL; include/gspx_ext.h, the section under that macro)
-SIGNATURES_EXPERIMENTAL = {
-    "gspx_graph_tile_stats": (_c.c_int, [_P, _P]),
-    "gspx_graph_set_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P,
-                                        _c.c_int, _c.c_int]),
-    "gspx_graph_set_cheb_pair_tiles": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int64, _P, _P]),
-    "gspx_cheby_pair_filter_dev": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _c.c_int64, _P, _P, _c.c_int,
-                                              _c.POINTER(_c.c_double)]),
-}
-EXP_LIB_PATH = os.path.join(_HERE, "_lib", "libgspx_exp.so")
-experimental = False  # set by load(): the loaded library is the experimental build
 
 
 def load():
@@ -159,13 +145,6 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    global experimental
-    experimental = hasattr(lib, "gspx_cheby_pair_filter_dev")
-    if experimental:
-        for name, (res, args) in SIGNATURES_EXPERIMENTAL.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
     _lib = lib
     return lib
 
@@ -186,6 +165,8 @@ def check(rc):
         raise TypeError(msg)  # approximations.py:83-84
     if rc == ERR_NODEVICE:
         raise GspxError("no MI355X/HIP device: " + msg)
+    if rc == ERR_OOM:
+        raise GspxError("out of device memory: " + msg)
     raise GspxError(msg)
 
 

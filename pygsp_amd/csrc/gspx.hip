@@ -8,12 +8,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gspx.hip -o libgspx.so
 #include "gspx_kernels.hip.h"
 #include "gspx_tile_kernels.hip.h"
-// Kernels that measured slower than what runs by default, or that are not yet safe at size (two orders per launch),
-// are compiled only into the experimental build: make EXTRA=-DGSPX_EXPERIMENTAL (include/gspx_ext.h lists their
-// entry points under the same macro; profiles/r04_pair_experiment.md).
-#ifdef GSPX_EXPERIMENTAL
-#include "experimental/gspx_newton_pair.hip.h"
-#endif
+// (The kernels that measured slower than what runs by default - two recurrence orders per launch, the fused Newton
+// pair, the small pair kernel, 128-row blocks - were retired in round 6; their counter-backed records are
+// profiles/r04_pair_experiment.md, profiles/r05_pair_experiment.md and profiles/r05_narrow_rows.md.)
 
 #include <hip/hip_runtime.h>
 
@@ -217,7 +214,9 @@ struct DevMem {
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) {
       p = nullptr;
-      return set_err(GSPX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+      (void)hipGetLastError();  // an allocation failure is not sticky: the caller may free memory and try again
+      return set_err(e == hipErrorOutOfMemory ? GSPX_ERR_OOM : GSPX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", n,
+                     hipGetErrorString(e));
     }
     bytes = n;
     return GSPX_OK;
@@ -356,14 +355,8 @@ struct Options {
   int64_t rows_per_wave = 0;  // 0 = auto (4 for the scalar-metadata kernel, 16 for the LDS kernel)
   int64_t narrow_g_log2 = -1;  // -1 = auto (4 lanes per row in total)
   int64_t waves_per_block = 4;  // panel kernel (kernel 1): 4, 8 or 16
-#ifdef GSPX_EXPERIMENTAL
-  int64_t newton_pair = 1;      // use the fused two-step kernel when the graph carries tiles
-  int64_t pair_workgroups = 0;  // persistent workgroups of the two-step / two-orders kernels (0: what fits a CU)
-  int64_t pair_small = 0;         // 1: one- / two-signal calls on cache-resident graphs run two orders per launch (k_pair_small)
-  int64_t pair_small_mb = 20;     // ... when the internal matrix (values + columns) is smaller than that many MB
-  int64_t pair_workgroups_per_cu = 0;  // two-orders-per-launch kernel: at most that many resident workgroups per CU (0: what fits)
-  int64_t pair_kernel = 2;        // two-orders-per-launch: 2 the pipelined build (k_cheb_pair2), 1 the first build
-#endif
+  int64_t calib_mix = 0;        // NOT a user option (no key): set for the duration of gspx_bench_step_mix - the wide
+                                // k_step_tile launches run their calibration build (arithmetic removed; 2: barriers too)
   int64_t graph_launch = 2;     // replay a repeated identical call as one hipGraph: 0 never, 1 always, 2 when the panel is small (launch-bound)
   int64_t tile_gather = 1;      // recurrence steps stage the gathered panel in LDS when the graph carries gather tiles
   int64_t tile_workgroups = 0;  // persistent workgroups of that kernel (0: two per CU; what fits for the small builds)
@@ -377,10 +370,6 @@ struct Options {
   int64_t copy_threads = 0;       // host threads of a staged copy (0: 8)
   int64_t tile_regroup = 1;     // 1: rows of 3 / 5 / 6 / 7 / 10 / 12 / 14 sixteen-byte pieces run the builds whose compute
                                 // phases regroup the lanes by pieces (k_step_tile<..., CL>); 0: the power-of-two builds
-#ifdef GSPX_EXPERIMENTAL
-  int64_t tile_br128 = 0;       // 1: 96- to 128-byte rows run the 8-lane build on 128-row blocks (round-5 experiment:
-                                // bit-identical, -3.7 ... +0.8 %: profiles/r05_narrow_rows.md)
-#endif
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
@@ -455,15 +444,6 @@ struct gspx_buf {
 
 static std::atomic<uint64_t> g_generation{1};  // handles are told apart by birth number, not by address
 
-#ifdef GSPX_EXPERIMENTAL
-// two-level row tiles of the two-orders-per-launch recurrence kernel (experimental/gspx_chebpair.hip.h)
-struct ChebPairTiles {
-  DevMem hdr, desc, s2rows, lidx1, lidx2, src, val2, ownpos, owndesc;
-  int rows = 0, nb = 0, n1max = 0, n2max = 0, e1max = 0, e2max = 0, n_s1 = 0, n_s2 = 0;
-  int64_t total2 = 0;
-  double val_lmax = -1.0;  // lmax the gathered factor values val2 were built for
-};
-#endif
 
 struct gspx_graph {
   gspx_ctx* ctx = nullptr;
@@ -480,15 +460,6 @@ struct gspx_graph {
   unsigned coff_ldb = 0;  // panel row bytes the cached byte offsets were built for
   DevMem perm, iperm;
   bool has_perm = false;
-#ifdef GSPX_EXPERIMENTAL
-  // two-level row tiles of the fused Newton-pair kernel (pygsp_amd/tiling.py)
-  DevMem t_hdr, t_hdr_s, t_desc, t_s2rows, t_lidx1, t_lidx2, t_fb;
-  int tile_nfb = 0;          // blocks the staged pair kernel leaves to the fallback kernel
-  size_t tile_lds = 0;       // dynamic LDS bytes of the fallback pair kernel (its largest tiles)
-  size_t tile_top = 0;       // staged pair kernel: bytes of the top part of its 80 KB
-  int tile_rows = 0, tile_nb = 0, tile_max_n1 = 0, tile_max_n2 = 0;
-  ChebPairTiles cp;          // ... of the two-orders-per-launch recurrence kernel
-#endif
   double fval_lmax = -1.0;
   double build_ms = 0.0;
   // ingredients of Graph._get_upper_bound (graph.py:933-960), taken while W is on the device (fp64 graphs built
@@ -502,10 +473,6 @@ struct gspx_graph {
   int gt_rows = 0, gt_nb = 0, gt_slow = 0;
   size_t gt_lds = 0;
   int gt_entmax = 0;  // most stored entries of a staged block (sizes the LDS of the narrow builds)
-  // the same lists for 128-row blocks (option "tile_br128": the 8-lane build on 80- to 128-byte rows; built on first use)
-  DevMem g2_hdr, g2_s1rows, g2_lidx;
-  int g2_nb = 0, g2_slow = 0, g2_entmax = 0;
-  bool g2_built = false;
   // differential operator (built on first use; gspx_ops.hip.h)
   int lap_type = GSPX_LAP_COMBINATORIAL;
   bool edges_built = false;
@@ -641,21 +608,10 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "waves_per_block")) return &o.waves_per_block;
   if (!strcmp(key, "alternate_sweep")) return &o.alternate_sweep;
   if (!strcmp(key, "synthesis")) return &o.synthesis;
-#ifdef GSPX_EXPERIMENTAL
-  if (!strcmp(key, "newton_pair")) return &o.newton_pair;
-  if (!strcmp(key, "pair_workgroups")) return &o.pair_workgroups;
-  if (!strcmp(key, "pair_workgroups_per_cu")) return &o.pair_workgroups_per_cu;
-  if (!strcmp(key, "pair_small")) return &o.pair_small;
-  if (!strcmp(key, "pair_small_mb")) return &o.pair_small_mb;
-  if (!strcmp(key, "pair_kernel")) return &o.pair_kernel;
-#endif
   if (!strcmp(key, "tile_gather")) return &o.tile_gather;
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
-#ifdef GSPX_EXPERIMENTAL
-  if (!strcmp(key, "tile_br128")) return &o.tile_br128;
-#endif
   if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
   if (!strcmp(key, "staged_copy")) return &o.staged_copy;
   if (!strcmp(key, "staged_copy_min_mb")) return &o.staged_copy_min_mb;
@@ -1304,132 +1260,6 @@ extern "C" int gspx_graph_download_internal(gspx_graph* g, int32_t* rowptr, int3
   return GSPX_OK;
 }
 
-#ifdef GSPX_EXPERIMENTAL
-extern "C" int gspx_graph_set_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
-                                    const int32_t* s1rows, const int32_t* s2ptr,
-                                    const int32_t* s2rows, const uint16_t* lidx1,
-                                    const uint32_t* occ_off, int64_t n_lidx2, const uint16_t* lidx2,
-                                    int max_n1, int max_n2) {
-  if (g) replay_reset(g->ctx);
-  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
-  if (block_rows == 0) {  // drop the tiles
-    g->tile_rows = 0;
-    return GSPX_OK;
-  }
-  if (block_rows != 32) return set_err(GSPX_ERR_INVALID, "tiles must use 32-row blocks");
-  if (!s1ptr || !s1rows || !s2ptr || !s2rows || !lidx1 || !occ_off || !lidx2 || nb < 1 ||
-      nb != (int)((g->N + block_rows - 1) / block_rows) || max_n1 < 1 || max_n2 < max_n1)
-    return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: bad argument");
-  const int n_s1 = s1ptr[nb], n_s2 = s2ptr[nb];
-  HIPCHK(hipSetDevice(g->ctx->device));
-  // per-block header and per-(block, S1 row) descriptors: everything a workgroup needs to issue
-  // all of its loads at once (no pointer chasing through rowptr / occ_off on the device)
-  std::vector<int> rp((size_t)g->N + 1);
-  HIPCHK(hipMemcpy(rp.data(), g->rptr.p, ((size_t)g->N + 1) * sizeof(int), hipMemcpyDeviceToHost));
-  for (auto& r : rp) r &= ~3;
-  std::vector<int> hdr((size_t)nb * 8);
-  std::vector<int> desc((size_t)n_s1 * 4);
-  std::vector<int> fb, hdr_s;
-  // LDS: two workgroups per CU when the largest tiles fit 80 KB; what a block's tiles leave free
-  // holds its staged matrix entries
-  // LDS: the staged kernel takes 80 KB (two workgroups per CU); the fallback kernel as much as
-  // its largest tiles need
-  const size_t tiles_max = ((size_t)max_n1 + (size_t)max_n2) * 256;
-  const size_t lds_staged = (size_t)80 * 1024;
-  const size_t lds = std::max(tiles_max, (size_t)1024);
-  const size_t esz = elt_size(g->dtype) + 2;
-  std::vector<char> cand((size_t)nb, 0);
-  std::vector<size_t> need_bot((size_t)nb), need_top((size_t)nb);
-  for (int b = 0; b < nb; ++b) {
-    const int lo = s1ptr[b], hi = s1ptr[b + 1];
-    const int r0 = b * block_rows, r1 = (int)std::min<int64_t>((int64_t)r0 + block_rows, g->N);
-    bool longrow = false;
-    for (int o = lo; o < hi; ++o) {
-      const int r = s1rows[o];
-      if (r < 0 || r >= g->N) return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: bad S1 row");
-      const int len = rp[r + 1] - rp[r];
-      if ((int64_t)occ_off[o + 1] - (int64_t)occ_off[o] != len)
-        return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: occ_off does not match the rows");
-      desc[(size_t)o * 4 + 0] = r;
-      desc[(size_t)o * 4 + 1] = rp[r];
-      const int64_t rel = (int64_t)occ_off[o] - (int64_t)occ_off[lo];
-      const bool packable = rel < (1 << 24) && len < 128;
-      desc[(size_t)o * 4 + 2] = packable ? ((int)rel | (len << 24)) : 0;  // staged kernel
-      desc[(size_t)o * 4 + 3] = (int)rel;                                  // fallback kernel
-      longrow |= !packable;
-      longrow |= len > 32;
-    }
-    for (int r = r0; r < r1; ++r) longrow |= rp[r + 1] - rp[r] > 32;
-    int* h = &hdr[(size_t)b * 8];
-    h[0] = lo;
-    h[1] = hi - lo;
-    h[2] = s2ptr[b];
-    h[3] = s2ptr[b + 1] - s2ptr[b];
-    h[4] = (int)occ_off[lo];
-    h[5] = (int)(occ_off[hi] - occ_off[lo]);
-    h[6] = rp[r0];
-    h[7] = rp[r1] - rp[r0];
-    if (h[1] > max_n1 || h[3] > max_n2)
-      return set_err(GSPX_ERR_INVALID, "gspx_graph_set_tiles: max_n1 / max_n2 too small");
-    need_bot[b] = (size_t)h[3] * 256 + (size_t)h[5] * esz;
-    need_top[b] = (size_t)h[1] * 256 + (size_t)h[7] * esz;
-    cand[b] = !longrow && h[1] <= 128 && h[3] <= 256;
-  }
-  // split of the staged kernel's LDS into [bottom | top]: the split that stages the most blocks
-  size_t best_top = 0;
-  int best_cnt = -1;
-  for (size_t topb = 1024; topb + 1024 <= lds_staged; topb += 1024) {
-    int cnt = 0;
-    for (int b = 0; b < nb; ++b)
-      cnt += cand[b] && need_top[b] <= topb && need_bot[b] + 1024 <= lds_staged - topb;
-    if (cnt > best_cnt) {
-      best_cnt = cnt;
-      best_top = topb;
-    }
-  }
-  for (int b = 0; b < nb; ++b) {
-    const int* h = &hdr[(size_t)b * 8];
-    if (cand[b] && need_top[b] <= best_top && need_bot[b] + 1024 <= lds_staged - best_top) {
-      const int hs[8] = {h[0], h[1] | (h[3] << 16), h[2], b, h[4], h[5], h[6], h[7]};
-      hdr_s.insert(hdr_s.end(), hs, hs + 8);
-    } else {
-      fb.push_back(b);
-    }
-  }
-  g->tile_top = best_top;
-  CHK(g->t_hdr_s.alloc(hdr_s.size() * 4 + 64));
-  if (!hdr_s.empty())
-    HIPCHK(hipMemcpy(g->t_hdr_s.p, hdr_s.data(), hdr_s.size() * 4, hipMemcpyHostToDevice));
-  g->tile_nfb = (int)fb.size();
-  g->tile_lds = lds;
-  CHK(g->t_fb.alloc(fb.size() * 4 + 16));
-  if (!fb.empty()) HIPCHK(hipMemcpy(g->t_fb.p, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
-  CHK(g->t_hdr.alloc(hdr.size() * 4));
-  CHK(g->t_desc.alloc(desc.size() * 4 + 64));
-  CHK(g->t_s2rows.alloc((size_t)n_s2 * 4));
-  CHK(g->t_lidx1.alloc((size_t)g->nnz_int * 2 + 64));
-  CHK(g->t_lidx2.alloc((size_t)n_lidx2 * 2 + 64));
-  HIPCHK(hipMemcpy(g->t_hdr.p, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->t_desc.p, desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->t_s2rows.p, s2rows, (size_t)n_s2 * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->t_lidx1.p, lidx1, (size_t)g->nnz_int * 2, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g->t_lidx2.p, lidx2, (size_t)n_lidx2 * 2, hipMemcpyHostToDevice));
-  g->tile_rows = block_rows;
-  g->tile_nb = nb;
-  g->tile_max_n1 = max_n1;
-  g->tile_max_n2 = max_n2;
-  return GSPX_OK;
-}
-
-extern "C" int gspx_graph_tile_stats(gspx_graph* g, int64_t out[4]) {
-  if (!g || !out) return set_err(GSPX_ERR_INVALID, "null argument");
-  out[0] = g->tile_rows ? g->tile_nb : 0;
-  out[1] = g->tile_rows ? g->tile_nfb : 0;
-  out[2] = g->tile_rows ? (int64_t)g->tile_lds : 0;
-  out[3] = g->tile_rows;
-  return GSPX_OK;
-}
-#endif  // GSPX_EXPERIMENTAL
 
 extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb, const int32_t* s1ptr,
                                            const int32_t* s1rows, const uint16_t* lidx, int64_t* stats) {
@@ -1503,14 +1333,14 @@ extern "C" int gspx_graph_set_gather_tiles(gspx_graph* g, int block_rows, int nb
   return GSPX_OK;
 }
 
-// the same tiles, computed on the device from the internal CSR (no host arrays)
-// the gather tiles of BR-row blocks, built on the device (k_tiles_unique / k_tiles_fill): lists, positions, headers
-template <int BR>
+// the same tiles, computed on the device from the internal CSR (no host arrays):
+// the gather tiles of the 64-row blocks (k_tiles_unique / k_tiles_fill): lists, positions, headers
 static int build_tiles_dev(gspx_graph* g, size_t lds, DevMem& hdr, DevMem& s1rows, DevMem& lidx, int* out_nb, int* out_ns1,
                            int* out_slow, int* out_entmax) {
   gspx_ctx* ctx = g->ctx;
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
+  constexpr int BR = GSPX_TILE_BR;
   const int nb = (N + BR - 1) / BR;
   DevMem tmp, n1, keep, s1lo, nslow;
   CHK(tmp.alloc((size_t)nb * GSPX_TILE_TMPCAP * sizeof(int)));
@@ -1519,7 +1349,7 @@ static int build_tiles_dev(gspx_graph* g, size_t lds, DevMem& hdr, DevMem& s1row
   CHK(s1lo.alloc(((size_t)nb + 1) * sizeof(int)));
   CHK(nslow.alloc(sizeof(int)));
   HIPCHK(hipMemsetAsync(nslow.p, 0, sizeof(int), st));
-  hipLaunchKernelGGL((k_tiles_unique<BR>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
+  hipLaunchKernelGGL(k_tiles_unique, dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
                      tmp.as<int>(), n1.as<int>());
   hipLaunchKernelGGL(k_tiles_keep, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, n1.as<int>(), nb,
                      keep.as<int>());
@@ -1530,7 +1360,7 @@ static int build_tiles_dev(gspx_graph* g, size_t lds, DevMem& hdr, DevMem& s1row
   CHK(hdr.alloc((size_t)nb * 4 * sizeof(int) + 64));
   CHK(s1rows.alloc((size_t)std::max(n_s1, 1) * 4 + 64));
   CHK(lidx.alloc((size_t)g->nnz_int + 128));
-  hipLaunchKernelGGL((k_tiles_fill<BR>), dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
+  hipLaunchKernelGGL(k_tiles_fill, dim3(nb), dim3(256), 0, st, g->rptr.as<int>(), g->rcol.as<int>(), N, nb,
                      tmp.as<int>(), n1.as<int>(), s1lo.as<int>(), (int)elt_size(g->dtype), (int)lds,
                      s1rows.as<int>(), lidx.as<unsigned char>(), hdr.as<int>(), nslow.as<int>());
   int slow = 0, entmax = 0;
@@ -1554,7 +1384,7 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   if (g->N < 1) return set_err(GSPX_ERR_INVALID, "empty graph");
   const size_t lds = (size_t)52 * 1024;
   int nb = 0, n_s1 = 0, slow = 0, entmax = 0;
-  CHK(build_tiles_dev<GSPX_TILE_BR>(g, lds, g->gt_hdr, g->gt_s1rows, g->gt_lidx, &nb, &n_s1, &slow, &entmax));
+  CHK(build_tiles_dev(g, lds, g->gt_hdr, g->gt_s1rows, g->gt_lidx, &nb, &n_s1, &slow, &entmax));
   g->gt_rows = GSPX_TILE_BR;
   g->gt_nb = nb;
   g->gt_ns1 = n_s1;
@@ -1562,7 +1392,6 @@ extern "C" int gspx_graph_build_gather_tiles(gspx_graph* g, int64_t* stats) {
   g->gt_slow = slow;
   g->gt_lds = lds;
   g->gt_entmax = entmax;
-  g->g2_built = false;  // (the 128-row lists, if anybody asks for them, are rebuilt from the same pattern)
   if (stats) {
     stats[0] = nb;
     stats[1] = slow;
@@ -1947,6 +1776,17 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
        k_step_tile<T, 1, 4, false, true, 256>, k_step_tile<T, 1, 8, false, true>}};
   kern_t kern = narrow ? slim[flavour][lg == 1 ? 0 : lg == 2 ? 1 : lg == 4 ? 2 : 3] : wide[flavour][ncol <= 2 ? ncol : 0];
   unsigned threads = narrow ? 64u * (unsigned)lg : 512u;
+  // calibration (gspx_bench_step_mix): the same launch with the row products removed (gspx_tile_kernels.hip.h, MIX)
+  bool mix = false;
+  if (opt.calib_mix && !narrow && flavour == 0) {
+    static const kern_t mixk[2][3] = {
+        {k_step_tile<T, 0, 16, false, false, 512, 16, 1>, k_step_tile<T, 1, 16, false, false, 512, 16, 1>,
+         k_step_tile<T, 2, 16, false, false, 512, 16, 1>},
+        {k_step_tile<T, 0, 16, false, false, 512, 16, 2>, k_step_tile<T, 1, 16, false, false, 512, 16, 2>,
+         k_step_tile<T, 2, 16, false, false, 512, 16, 2>}};
+    kern = mixk[opt.calib_mix == 2 ? 1 : 0][ncol <= 2 ? ncol : 0];
+    mix = true;
+  }
   // rows of fewer 16-byte pieces than the lanes they are staged with: the builds whose compute phases regroup the
   // threads by pieces (template parameter CL), in workgroups of 64 x pieces (one row per group) or 32 x pieces (two
   // rows) threads.  Measured per piece count, A/B on one box (profiles/r04_regroup_ab*.json): 3 pieces (48-byte rows:
@@ -1954,7 +1794,7 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   // +6 %; 6, 7, 12 and 14 pieces -2...0 % (idle compute lanes are not what bounds those passes) - they keep the
   // power-of-two builds.
   const int pieces = (int)(rowb / 16);
-  if (opt.tile_regroup && ncol == 1 && flavour != 1 && pieces < lg) {
+  if (opt.tile_regroup && ncol == 1 && flavour != 1 && pieces < lg && !mix) {
 #define GSPX_CL(LG_, CL_, NT_) \
   (flavour == 2 ? (kern_t)k_step_tile<T, 1, LG_, false, true, NT_, CL_> : (kern_t)k_step_tile<T, 1, LG_, false, false, NT_, CL_>)
     kern_t k2 = nullptr;
@@ -1965,24 +1805,6 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
 #undef GSPX_CL
     if (k2) kern = k2, threads = nt2;
   }
-  // round-5 experiment (option "tile_br128", experimental build only): the 8-lane build on 128-row blocks
-  bool br128 = false;
-#ifdef GSPX_EXPERIMENTAL
-  // (not the launches whose tile rows come from the caller's unpermuted panel - step 1 of a fused-input call passes
-  // its own row lists -: those lists exist for the 64-row blocks only)
-  if (opt.tile_br128 && lg == 8 && threads == 512 && flavour != 1 && !t.s1rows && g->N >= 4096) {
-    if (!g->g2_built) {
-      int ns1 = 0;
-      CHK(build_tiles_dev<128>(g, (size_t)72 * 1024, g->g2_hdr, g->g2_s1rows, g->g2_lidx, &g->g2_nb, &ns1, &g->g2_slow,
-                               &g->g2_entmax));
-      g->g2_built = true;
-    }
-    if (g->g2_slow * 50 <= g->g2_nb) {
-      br128 = true;
-      kern = flavour == 2 ? (kern_t)k_step_tile<T, 1, 8, false, true, 512, 8, 128> : (kern_t)k_step_tile<T, 1, 8, false, false, 512, 8, 128>;
-    }
-  }
-#endif
   // dynamic LDS: the wide builds take the tile budget the blocks were classified with; a narrow build's tile
   // rows are 16 lg bytes, so the largest staged block needs far less - and more workgroups fit a CU
   size_t lds = g->gt_lds;
@@ -1990,9 +1812,6 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
     lds = std::min(lds, (size_t)GSPX_TILE_MAXN1 * 16 * lg + (((size_t)g->gt_entmax * sizeof(T) + 15) & ~(size_t)15) +
                             (((size_t)g->gt_entmax + 15) & ~(size_t)15) + 64);
   if (lg < 8) lds = (lds + 2047) & ~(size_t)2047;  // (graphs differ in their largest block: few distinct sizes)
-  if (br128)
-    lds = ((size_t)256 * 128 + (((size_t)g->g2_entmax * sizeof(T) + 15) & ~(size_t)15) + (((size_t)g->g2_entmax + 15) & ~(size_t)15) +
-           64 + 2047) & ~(size_t)2047;
   int per_cu = 2;
   {  // once per kernel build, device and LDS size (a driver call per launch would cost microseconds each)
     struct Known { size_t attr = 0; std::map<size_t, int> fit; };
@@ -2017,16 +1836,15 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   t.rowptr = g->rptr.as<int>();
   t.col = g->rcol.as<int>();
   t.val = vals ? vals : g->fval.as<T>();  // any values array on the internal pattern
-  t.hdr = br128 ? g->g2_hdr.as<int>() : g->gt_hdr.as<int>();
-  if (br128) t.s1rows = g->g2_s1rows.as<int>();
-  else if (!t.s1rows) t.s1rows = g->gt_s1rows.as<int>();  // (the caller may pass the lists in its panel's row order)
-  t.lidx = br128 ? g->g2_lidx.as<unsigned char>() : g->gt_lidx.as<unsigned char>();
+  t.hdr = g->gt_hdr.as<int>();
+  if (!t.s1rows) t.s1rows = g->gt_s1rows.as<int>();  // (the caller may pass the lists in its panel's row order)
+  t.lidx = g->gt_lidx.as<unsigned char>();
   t.N = (int)g->N;
   t.ld = ld;
   t.panel_bytes = (unsigned)((size_t)g->N * ld * sizeof(T));
   t.val_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
   t.lidx_bytes = (unsigned)((size_t)g->nnz_int);
-  t.nb = br128 ? g->g2_nb : g->gt_nb;
+  t.nb = g->gt_nb;
   t.ncol = ncol;
   t.per_xcd = (t.nb + 7) / 8;
   t.lds_bytes = (int)lds;
@@ -2053,9 +1871,6 @@ static int prepare_coff(gspx_graph* g, const Shape& shape, unsigned ld, hipStrea
   return GSPX_OK;
 }
 
-#ifdef GSPX_EXPERIMENTAL
-#include "experimental/gspx_pairsmall.hip.h"
-#endif
 
 template <typename T>
 static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp, const T* x,
@@ -2066,11 +1881,6 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   hipStream_t st = ctx->stream;
   const int N = (int)g->N;
   const int K = M - 1;
-#ifdef GSPX_EXPERIMENTAL
-  // the latency case (one or two signals on a cache-resident graph): two orders per launch (opt-in, slower)
-  if (pair_small_usable<T>(g, opt, nf, M, ld, deferred, acc_existing, final_to_y))
-    return run_pair_small<T>(g, M, cp, x, ldx, y, ldy, ld, ev_idx);
-#endif
   // Rows that are not made of 16-byte pieces (or a y the final flush cannot store such pieces into): the work
   // panels get padded rows of pitch ldw, so that the tile kernels take them all the same - zero columns cost
   // little next to kernels that are several times faster - and the result leaves through a copy.
@@ -2592,21 +2402,6 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   a.wts = ctx->ws_w.as<T>();
   a.old = X;
 
-  int s_first_pair = K;  // steps >= this index run as fused pairs (experimental build, graph with two-level tiles)
-  (void)s_first_pair;
-#ifdef GSPX_EXPERIMENTAL
-  // fused two-step kernel: needs tiles, 16-byte lanes on every panel it touches, and an LDS
-  // footprint (h tile on S2 + g tile on S1, 256-byte row chunks) the CU can hold
-  constexpr int PVEC = 16 / (int)sizeof(T);
-  // (two workgroups per CU when the tiles fit 80 KB; what the tiles leave free holds the staged
-  // matrix entries, block by block)
-  const size_t pair_lds = g->tile_lds;
-  const bool pair_ok = opt.newton_pair && g->tile_rows == 32 && K >= 2 && (ld % PVEC) == 0 &&
-                       (ldy % PVEC) == 0 && (((uintptr_t)y / sizeof(T)) % PVEC) == 0 &&
-                       pair_lds <= 160 * 1024 && (size_t)N * ld * sizeof(T) < ((size_t)1 << 31) &&
-                       (size_t)g->nnz_int * sizeof(T) < ((size_t)1 << 31) &&
-                       g->t_lidx2.bytes < ((size_t)1 << 31);
-#endif
   auto step_params = [&](int s, T& sc, T& be, T& ga) {
     const int j = K - 1 - s;
     if (s == 0) {
@@ -2619,70 +2414,8 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
       ga = (T)dc[j];
     }
   };
-#ifdef GSPX_EXPERIMENTAL
-  const int pair_ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
-  // (one chunk: straight-line build; more: the runtime-count build, which measured faster than an
-  // unrolled two-chunk build - that one spills)
-  void (*pair_kernel)(const PairArgs<T>) = pair_ncol == 1 ? k_newton_pair<T, 1> : k_newton_pair<T, 0>;
-  if (pair_ok) s_first_pair = K & 1;
-  int pair_cur = (pair_ok && (K & 1)) ? 0 : -1;  // panel holding h before the next pair (-1 = X)
-  if (pair_ok) {
-    HIPCHK(hipFuncSetAttribute((const void*)pair_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_newton_pair_g<T>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
-  }
-#endif
   const bool tile_ok = tile_usable<T>(g, opt, ld, y, ldy);
   for (int s = 0; s < K; ++s) {
-#ifdef GSPX_EXPERIMENTAL
-    if (s >= s_first_pair) {
-      PairArgs<T> p{};
-      p.rowptr = g->rptr.as<int>();
-      p.fval = g->fval.as<T>();
-      p.hdr = g->t_hdr.as<int>();
-      p.hdr_s = g->t_hdr_s.as<int>();
-      p.desc = g->t_desc.as<int4>();
-      p.s2rows = g->t_s2rows.as<int>();
-      p.lidx1 = g->t_lidx1.as<unsigned short>();
-      p.lidx2 = g->t_lidx2.as<unsigned short>();
-      // the pair reads h on other blocks' rows too, so it never writes the panel it reads
-      const int out_buf = (pair_cur == 0) ? 1 : 0;
-      p.h_in = (pair_cur < 0) ? X : H[pair_cur];
-      p.x = X;
-      p.h_out = H[out_buf];
-      pair_cur = out_buf;
-      p.N = N;
-      p.ld = ld;
-      p.lds_bytes = 80 * 1024;
-      p.top_bytes = (int)g->tile_top;
-      p.panel_bytes = (unsigned)((size_t)N * ld * sizeof(T));
-      p.fval_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
-      p.lidx1_bytes = (unsigned)((size_t)g->nnz_int * 2);
-      p.lidx2_bytes = (unsigned)g->t_lidx2.bytes;
-      step_params(s, p.sA, p.bA, p.gA);
-      step_params(s + 1, p.sB, p.bB, p.gB);
-      p.final = (s + 1 == K - 1) ? 1 : 0;
-      p.y = y;
-      p.ldy = ldy;
-      p.perm = perm;
-      p.nb = g->tile_nb;
-      p.ncol = (int)(((size_t)ld * sizeof(T) + 255) / 256);
-      p.nsb = p.nb - g->tile_nfb;
-      p.per_xcd = (p.nsb + 7) / 8;
-      // persistent workgroups: two per CU (LDS), a multiple of 8 so every XCD gets the same count
-      unsigned nwg = (unsigned)std::max<int64_t>(8, (2 * (int64_t)ctx->cu_count) / 8 * 8);
-      if (opt.pair_workgroups > 0)
-        nwg = (unsigned)std::max<int64_t>(8, std::min<int64_t>(opt.pair_workgroups, 1 << 20) / 8 * 8);
-      if (p.nsb > 0)
-        hipLaunchKernelGGL(pair_kernel, dim3(nwg, 1, 1), dim3(512), 80 * 1024, st, p);
-      if (g->tile_nfb > 0)
-        hipLaunchKernelGGL((k_newton_pair_g<T>), dim3((unsigned)g->tile_nfb * p.ncol, 1, 1), dim3(512),
-                           pair_lds, st, p, g->t_fb.as<int>());
-      ++s;  // two steps done
-      continue;
-    }
-#endif
     const int j = K - 1 - s;
     if (tile_ok) {
       TileArgs<T> t{};
@@ -3220,10 +2953,30 @@ extern "C" int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double*
   return GSPX_OK;
 }
 
+// Calibration: the call gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x, y, analysis) would make - the same
+// plan, the same K launches over the same buffers with the same flushes, sweeps and cache bits - with the row products
+// removed from every wide k_step_tile launch (mode 1; mode 2: the two barriers of a pass too).  y receives numbers
+// without meaning.  Times through gspx_last_timing like any filter call.  The mix ceiling of bench.py's roofline.
+extern "C" int gspx_bench_step_mix(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig,
+                                   const void* x_dev, void* y_dev, int mode) {
+  if (!g || !g->ctx) return set_err(GSPX_ERR_INVALID, "gspx_bench_step_mix: null graph");
+  if (mode != 1 && mode != 2) return set_err(GSPX_ERR_INVALID, "gspx_bench_step_mix: mode must be 1 or 2");
+  gspx_ctx* ctx = g->ctx;
+  const bool wide = Nsig > 0 && Nsig < (1 << 20) && (size_t)Nsig * elt_size(g->dtype) > 128 &&
+                    (g->dtype == GSPX_F32 ? tile_geometry<float>(g, ctx->opt, (unsigned)Nsig)
+                                          : tile_geometry<double>(g, ctx->opt, (unsigned)Nsig));
+  if (!wide)
+    return set_err(GSPX_ERR_INVALID, "gspx_bench_step_mix: this call would not run the wide LDS-staged step "
+                                     "(gather tiles, rows of more than 128 bytes made of 16-byte pieces)");
+  replay_reset(ctx);
+  ctx->opt.calib_mix = mode;
+  const int rc = gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, nullptr);
+  ctx->opt.calib_mix = 0;
+  replay_reset(ctx);
+  return rc;
+}
+
 #include "gspx_calib.hip.h"
 #include "gspx_ops.hip.h"
 #include "gspx_knn.hip.h"
 #include "gspx_setup.hip.h"
-#ifdef GSPX_EXPERIMENTAL
-#include "experimental/gspx_chebpair.hip.h"
-#endif

@@ -102,16 +102,22 @@ template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
 // with LG-lane groups a quarter to three eighths of the lanes idled through every row product.  CL == LG: as before.
 // (two resident workgroups of 320 / 384 threads are 10 / 12 waves per CU, three per SIMD: those builds may use 168
 // registers; their longer row lists per staging group - 8 / 7 instead of 5 - would spill at 128)
-// BR: rows per block (64; 128 for the round-5 experiment on 80- to 128-byte rows: twice the bytes per pass against the
-// same two barriers, row lists and entry staging, 1.6 instead of 1.9 staged rows per row; its own tile set, positions
-// still 8 bits: a staged tile holds at most 256 rows)
+// (128-row blocks for the 8-lane build - twice the bytes per pass against the same two barriers - measured
+// -3.7 ... +0.8 % in round 5, profiles/r05_narrow_rows.md; retired)
+// MIX (calibration builds, gspx_bench_step_mix - never part of a filter call): the same pass with the ARITHMETIC REMOVED -
+// same grid and walk, same LDS-DMA tile loads of the same S1 lists, same T_{k-2} / accumulator loads, same entry
+// stream into LDS, same stores with the same cache bits; the row products (the per-entry LDS gathers and FMAs) are
+// replaced by one tile read per row.  1: both barriers of a pass kept (what the memory system delivers to this
+// access mix behind this synchronisation); 2: the barriers dropped too (the access mix alone; tile rows may be read
+// while still arriving - the values mean nothing in either build).
 template <typename T, int NCOL, int LG = 16, bool OLDNAT = false, bool INS = false, int NT = 512, int CL = LG,
-          int BR = GSPX_TILE_BR>
+          int MIX = 0>
 __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   static_assert(NT == 512 || (NT == 64 * LG && NCOL == 1) || (CL < LG && NCOL == 1 && NT % 64 == 0 && NT % CL == 0),
                 "narrow builds: one row per group, one chunk per row");
+  constexpr int BR = GSPX_TILE_BR;
   static_assert(CL <= LG && (BR % (NT / CL)) == 0, "compute groups must tile the block's rows");
-  constexpr int MAXN1 = BR == GSPX_TILE_BR ? GSPX_TILE_MAXN1 : 256;
+  constexpr int MAXN1 = GSPX_TILE_MAXN1;
   constexpr bool PF = TileSchedule<T, NCOL, LG, OLDNAT>::PF;
   constexpr bool META_AFTER = TileSchedule<T, NCOL, LG, OLDNAT>::META_AFTER;
   constexpr bool TILE_LAST = TileSchedule<T, NCOL, LG, OLDNAT>::TILE_LAST;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
     } else {
       __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
     }
-    __syncthreads();  // tile and entries in place, T_{k-2} / accumulator rows in registers
+    if constexpr (MIX != 2) __syncthreads();  // tile and entries in place, T_{k-2} / accumulator rows in registers
     if constexpr (META_AFTER) {
       if (last) {  // the next block's row lists and the header after that: in flight during the row products
         M = load_meta(kn < k1 ? kn : k, Hn);
@@ -333,7 +339,10 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
     for (int t = 0; t < RPG; ++t) {
       const int s = rs[t], e = rs[t + 1];
       V acc = 0, self = 0;
-      if (fast) {
+      if (MIX && fast) {  // calibration: one tile row and one entry per row, no products over the entries
+        self = tile[(int)midx[s - rp0] * LG + lane16];
+        acc = mval[s - rp0] * self;
+      } else if (fast) {
         acc = lds_row_dot<T, V, LG, u8>(mval + (s - rp0), midx + (s - rp0), row0 + t < a.N ? e - s : 0, tile, lane16,
                                         self);
       } else if (row0 + t < a.N) {  // plain gathers from global memory (tile too large for LDS)
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
     // everybody is done with the tile (their LDS reads were consumed above).  A bare barrier: the
     // fence of __syncthreads() would also wait for the prefetches still in flight.
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-    __builtin_amdgcn_s_barrier();
+    if constexpr (MIX != 2) __builtin_amdgcn_s_barrier();
     bool more = true;
     if (last) {
       const int4 Hnn = uniform(Hv);  // youngest load so far: the row lists before it have landed too
@@ -443,10 +452,10 @@ namespace gspx {
 constexpr int GSPX_TILE_SORTCAP = 4096;  // entries of a block the LDS sort holds
 constexpr int GSPX_TILE_TMPCAP = 256;    // distinct rows kept per block (more: the block is "slow")
 
-template <int BR = GSPX_TILE_BR>
 __global__ __launch_bounds__(256) void k_tiles_unique(const int* __restrict__ rowptr,
                                                       const int* __restrict__ col, int N, int nb,
                                                       int* __restrict__ tmp, int* __restrict__ n1) {
+  constexpr int BR = GSPX_TILE_BR;
   __shared__ unsigned keys[GSPX_TILE_SORTCAP];
   __shared__ int wsum[4];
   const int b = blockIdx.x;
@@ -504,16 +513,13 @@ __global__ __launch_bounds__(256) void k_tiles_unique(const int* __restrict__ ro
   if (threadIdx.x == 0) n1[b] = base;
 }
 
-// (BR = 64: tiles of 256-byte rows, at most 160 of them; BR = 128: the 8-lane builds' 128-byte rows, at most 256)
-template <int BR = GSPX_TILE_BR>
 __global__ __launch_bounds__(256) void k_tiles_fill(const int* __restrict__ rowptr,
                                                     const int* __restrict__ col, int N, int nb,
                                                     const int* __restrict__ tmp, const int* __restrict__ n1,
                                                     const int* __restrict__ s1lo, int esz, int lds_bytes,
                                                     int* __restrict__ s1rows, u8* __restrict__ lidx,
                                                     int* __restrict__ hdr, int* __restrict__ nslow) {
-  constexpr int MAXN1 = BR == GSPX_TILE_BR ? GSPX_TILE_MAXN1 : 256;
-  constexpr int ROWB = BR == GSPX_TILE_BR ? 256 : 128;
+  constexpr int BR = GSPX_TILE_BR, MAXN1 = GSPX_TILE_MAXN1, ROWB = 256;
   const int b = blockIdx.x;
   const int r0 = b * BR, r1 = min(r0 + BR, N);
   const int e0 = rowptr[r0] & ~3, e1 = rowptr[r1] & ~3;

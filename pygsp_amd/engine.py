@@ -23,6 +23,12 @@ class Context:
         _capi.check(lib.gspx_ctx_create(int(device), ctypes.byref(h)))
         self._h = h
         self.device = int(device)
+        self._init_pool()
+
+    def _init_pool(self):
+        """The recycled-buffer pool and its lock (also called by host-only tests that build a Context without a
+        device)."""
+        self._pool, self._pooled, self._pool_lock = {}, 0, threading.RLock()
 
     def close(self):
         """Explicit teardown.  (No __del__: graphs and buffers hold a pointer to their context, so
@@ -83,13 +89,7 @@ class Context:
     POOL_BYTES = 8 << 30
 
     def _pool_state(self):
-        d = self.__dict__
-        if "_pool_lock" not in d:
-            with _default_lock:
-                d.setdefault("_pool", {})
-                d.setdefault("_pooled", 0)
-                d.setdefault("_pool_lock", threading.RLock())
-        return d["_pool_lock"]
+        return self._pool_lock
 
     def pooled_bytes(self):
         with self._pool_state():
@@ -121,11 +121,14 @@ class Context:
 
     def call(self, fn, *args):
         """rc = fn(*args) for a libgspx entry point that may allocate device memory (buffers, workspaces, graph
-        builds), mapped to the reference's exception types.  A HIP failure while the pool holds recycled buffers
-        empties the pool and runs the call once more: memory kept for reuse must never be the reason a call fails
-        that would have succeeded without the pool."""
+        builds), mapped to the reference's exception types.  An ALLOCATION failure (GSPX_ERR_OOM: nothing has been
+        launched or written by then - every entry point allocates its workspaces before its first kernel) while the
+        pool holds recycled buffers empties the pool and runs the call once more: memory kept for reuse must never be
+        the reason a call fails that would have succeeded without the pool.  Any other failure surfaces at
+        once: a call that failed midway is never repeated on inputs it may have overwritten (workspaces
+        are grow-only and sized by a call's first batch, so an allocation can only fail before the first kernel)."""
         rc = fn(*args)
-        if rc == _capi.ERR_HIP and self.pooled_bytes() > 0:
+        if rc == _capi.ERR_OOM and self.pooled_bytes() > 0:
             self.clear_pool()
             rc = fn(*args)
         _capi.check(rc)
@@ -872,6 +875,16 @@ class DeviceGraph:
         return ms.value
 
 
+    def bench_step_mix(self, coeffs, x_ptr, y_ptr, nsig, lmax, mode=1):
+        """CALIBRATION, not a filter: the launches cheby_filter_dev(coeffs, ...) would make with the row products
+        removed from every wide k_step_tile launch (gspx_bench_step_mix; mode 2: the barriers of a pass too).  y
+        receives numbers without meaning.  Returns ctx.last_timing() of that call."""
+        c = np.ascontiguousarray(np.asarray(coeffs, dtype=np.float64).ravel())
+        self.ctx.call(_capi.load().gspx_bench_step_mix, self._h, float(lmax), int(c.size), _capi.ptr(c), int(nsig),
+                      ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), int(mode))
+        return self.ctx.last_timing()
+
+
 def _newton_methods():
     def newton_filter(self, nodes, dcoef, x, lmax):
         """Newton-form evaluation (single filter): host arrays in/out, x (N, Nsig) -> (N, Nsig)."""
@@ -912,7 +925,7 @@ def _newton_methods():
         filtering stages the gathered panel in LDS.  Returns tile statistics."""
         from . import tiling
         rp, col = self.download_internal()
-        t = tiling.build_tiles(rp, col, self.N, 64, levels=1)
+        t = tiling.build_tiles(rp, col, self.N, 64)
         lidx = t["lidx1"].copy()
         lidx[lidx == tiling.PAD] = 0  # pads carry the value 0: any valid position will do
         c = np.ascontiguousarray

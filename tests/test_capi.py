@@ -13,17 +13,12 @@ from oracle import cheby_oracle as orc
 from pygsp_amd import _capi, engine
 
 
-_EXP_BLOCK = re.compile(r"#ifdef GSPX_EXPERIMENTAL\n(.*?)#endif /\* GSPX_EXPERIMENTAL \*/", re.S)
-
-
-def header_functions(names=("gspx.h", "gspx_ext.h"), experimental=False):
+def header_functions(names=("gspx.h", "gspx_ext.h")):
     """Functions declared in include/: gspx.h is the drop-in boundary of the path, gspx_ext.h the entry
-    points beside it (opt-in evaluation, calibration).  experimental=True: only what sits under
-    `#ifdef GSPX_EXPERIMENTAL` (the experimental build's extra entry points); False: everything outside it."""
+    points beside it (opt-in evaluation, calibration)."""
     found = set()
     for name in names:
         src = open(os.path.join(ROOT, "include", name)).read()
-        src = "\n".join(_EXP_BLOCK.findall(src)) if experimental else _EXP_BLOCK.sub("", src)
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         found.update(re.findall(r"\b(gspx_[a-z0-9_]+)\s*\(", src))
     return sorted(found)
@@ -51,18 +46,16 @@ def test_library_exports_every_declared_symbol():
     assert len(open(os.path.join(ROOT, "include", "gspx.h")).read().splitlines()) <= 220
 
 
-def test_default_library_exports_no_experimental_entry_point():
-    """VERDICT r4 "Next 2": the kernels that are slower or not cleared to run at size (two orders per launch, the fused
-    Newton pair, the small pair kernel) are compiled only with -DGSPX_EXPERIMENTAL.  The default libgspx.so exports
-    exactly the default section of the headers - none of theirs - and the experimental build (when it has been built)
-    exactly both sections."""
+def test_library_exports_exactly_the_headers():
+    """One library, one header pair without feature macros (the experimental build was retired in round 6): what
+    libgspx.so exports is exactly what include/*.h declares, and none of the retired kernels' entry points."""
     default_lib = os.path.join(ROOT, "pygsp_amd", "_lib", "libgspx.so")
-    exp_names = header_functions(experimental=True)
-    assert sorted(_capi.SIGNATURES_EXPERIMENTAL) == exp_names
-    assert {"gspx_cheby_pair_filter_dev", "gspx_graph_set_cheb_pair_tiles", "gspx_graph_set_tiles"} <= set(exp_names)
-    assert exported(default_lib) == header_functions()
-    if os.path.exists(_capi.EXP_LIB_PATH):
-        assert exported(_capi.EXP_LIB_PATH) == sorted(set(header_functions()) | set(exp_names))
+    names = exported(default_lib)
+    assert names == header_functions()
+    assert not [n for n in names if "pair" in n or n in ("gspx_graph_set_tiles", "gspx_graph_tile_stats")]
+    for h in ("gspx.h", "gspx_ext.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        assert "#ifdef GSPX_" not in src and "#if defined(GSPX_" not in src
 
 
 def test_version_and_error_string():

@@ -623,11 +623,9 @@ def test_plugin_estimate_lmax_seam(ctx):
     assert RefGraph.estimate_lmax is original
 
 
-def test_default_library_has_no_experimental_options(ctx):
-    """The default build neither exports the experimental kernels' entry points (tests/test_capi.py) nor knows their
-    context options: a caller cannot switch a slower / uncleared kernel on by accident."""
-    if _capi.experimental:
-        pytest.skip("the experimental build is loaded (GSPX_LIB_PATH)")
+def test_library_has_no_retired_options(ctx):
+    """The library neither exports the retired kernels' entry points (tests/test_capi.py) nor knows their context
+    options (two orders per launch, fused Newton pair, small pair kernel, 128-row blocks: retired in round 6)."""
     for key in ("pair_small", "pair_small_mb", "newton_pair", "pair_workgroups", "pair_workgroups_per_cu", "pair_kernel",
                 "tile_br128"):
         with pytest.raises(ValueError, match="unknown option"):

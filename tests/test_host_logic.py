@@ -456,6 +456,7 @@ def test_device_array_pool_is_locked_and_gives_way_to_allocations():
     from pygsp_amd import _capi, engine
     ctx = engine.Context.__new__(engine.Context)  # no device: only the pool is exercised
     ctx._h = None
+    ctx._init_pool()
 
     class Buf:
         def __init__(self, n):
@@ -478,14 +479,21 @@ def test_device_array_pool_is_locked_and_gives_way_to_allocations():
 
     def alloc(*args):
         calls.append(args)
-        return _capi.ERR_HIP if len(calls) == 1 else _capi.OK
+        return _capi.ERR_OOM if len(calls) == 1 else _capi.OK
     ctx.call(alloc, 1, 2)
     assert calls == [(1, 2), (1, 2)] and ctx.pooled_bytes() == 0 and all(k.freed for k in kept)
     # nothing in the pool: no second attempt, the failure surfaces as the library's exception
     calls.clear()
     with pytest.raises(_capi.GspxError):
-        ctx.call(lambda *a: calls.append(a) or _capi.ERR_HIP)
+        ctx.call(lambda *a: calls.append(a) or _capi.ERR_OOM)
     assert len(calls) == 1
+    # a HIP failure that is not an allocation failure is never retried (the call may have written already: ADVICE r5)
+    ctx.give(Buf(8))
+    calls.clear()
+    with pytest.raises(_capi.GspxError):
+        ctx.call(lambda *a: calls.append(a) or _capi.ERR_HIP)
+    assert len(calls) == 1 and ctx.pooled_bytes() == 8
+    ctx.clear_pool()
     # argument errors are never retried
     ctx.give(Buf(8))
     calls.clear()

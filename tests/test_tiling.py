@@ -1,5 +1,5 @@
-"""Two-level tiles of the fused Newton-pair kernel: structure invariants and a numpy emulation of
-the kernel's three phases against two explicit sparse products.  CPU only."""
+"""Row tiles of the LDS-staged recurrence step: structure invariants and a numpy emulation of the kernel's
+fast path against the explicit sparse product.  CPU only."""
 import numpy as np
 import pytest
 from scipy import sparse
@@ -36,59 +36,40 @@ def host_internal_csr(L, perm):
 
 
 @pytest.mark.parametrize("block_rows", [8, 32, 64])
-def test_tiles_reproduce_two_steps(block_rows):
+def test_tile_structure_invariants(block_rows):
+    """S1 of a block is ascending, contains the block's own rows, and every entry's position points back at its
+    column; pads carry PAD; entry 0 of a row is its diagonal slot."""
     W, coords = graphs.sensor_weights(700, k=6, seed=4)
     L = orc.laplacian(W)
     N = L.shape[0]
     perm = engine.locality_order(W, coords).astype(np.int64)
     rptr, rcol, rval = host_internal_csr(L, perm)
-    lmax = 2 * float(np.ravel(W.sum(0)).max())
-    a1 = a2 = lmax / 2
-    fval = np.where(rcol == np.repeat(np.arange(N), np.diff(rptr)), rval - a2, rval) * (2 / a1)
-    fval[rcol == N] = 0.0
     t = tiling.build_tiles(rptr, rcol, N, block_rows)
     nb = t["nb"]
     assert nb == (N + block_rows - 1) // block_rows
-    # invariants: S1 contains the block's own rows, S2 contains S1, local indices point back
     for b in (0, nb // 2, nb - 1):
         s1 = t["s1rows"][t["s1ptr"][b]:t["s1ptr"][b + 1]]
-        s2 = t["s2rows"][t["s2ptr"][b]:t["s2ptr"][b + 1]]
         own = np.arange(b * block_rows, min((b + 1) * block_rows, N))
-        assert np.all(np.diff(s1) > 0) and np.all(np.diff(s2) > 0)
-        assert np.isin(own, s1).all() and np.isin(s1, s2).all()
+        assert np.all(np.diff(s1) > 0)
+        assert np.isin(own, s1).all()
         for i in own:
             e = np.arange(rptr[i], rptr[i + 1])
             real = rcol[e] < N
             assert np.array_equal(s1[t["lidx1"][e][real]], rcol[e][real])
             assert np.all(t["lidx1"][e][~real] == tiling.PAD)
             assert s1[t["lidx1"][e[0]]] == i  # entry 0 is the diagonal slot
-    assert t["max_n1"] <= t["max_n2"] < tiling.PAD
-    # the emulated kernel == two explicit steps
-    F = sparse.csr_matrix((fval, rcol.clip(max=N - 1), rptr), shape=(N, N))
-    rng = np.random.default_rng(0)
-    h = rng.standard_normal((N, 3))
-    x = rng.standard_normal((N, 3))
-    A, B = (0.5, -0.3, 1.7), (0.5, 0.9, -0.4)
-    g = A[0] * F.dot(h) + A[1] * h + A[2] * x
-    ref = B[0] * F.dot(g) + B[1] * g + B[2] * x
-    out = tiling.emulate_pair(t, rptr, rcol, fval, N, h, x, A, B)
-    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
+    assert 0 < t["max_n1"] < tiling.PAD and t["mean_n1"] <= t["max_n1"]
 
 
-def test_gather_tiles_level1_reproduce_one_step():
-    """levels=1 (the LDS-staged recurrence step): a numpy model of k_step_tile's fast path - stage the
-    S1 rows, gather by 16-bit position - equals the sparse product; level-1 arrays equal the
-    two-level build's."""
+def test_gather_tiles_reproduce_one_step():
+    """A numpy model of k_step_tile's fast path - stage the S1 rows, gather by position - equals the sparse
+    product."""
     W, coords = graphs.sensor_weights(900, k=7, seed=6)
     L = orc.laplacian(W)
     N = L.shape[0]
     perm = engine.locality_order(W, coords)
     rptr, rcol, rval = host_internal_csr(L, perm)
-    t1 = tiling.build_tiles(rptr, rcol, N, 64, levels=1)
-    t2 = tiling.build_tiles(rptr, rcol, N, 64)
-    for key in ("s1ptr", "s1rows", "lidx1"):
-        np.testing.assert_array_equal(t1[key], t2[key])
-    assert t1["max_n1"] == t2["max_n1"] and "s2rows" not in t1
+    t1 = tiling.build_tiles(rptr, rcol, N, 64)
     x = np.random.default_rng(0).standard_normal((N, 3))
     xi = x[perm]
     out = np.zeros_like(xi)
