@@ -69,6 +69,7 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
+    p.add_argument("--no-mix", action="store_true", help="skip the mix-ceiling calibration (gspx_bench_step_mix)")
     p.add_argument("--no-e2e", action="store_true", help="skip the numpy-in/numpy-out leg (profiling passes)")
     p.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     p.add_argument("--no-f32", action="store_true", help="skip the float32 run of the headline workload")
@@ -100,6 +101,31 @@ def parse():
     return p.parse_args()
 
 
+def smi_sample():
+    """What rocm-smi says about device 0 right now (called from a thread while the recurrence runs): HBM and junction
+    temperatures, clocks, package power.  The memory temperature is the one quantity that moved with the step's
+    speed over successive runs on one GPU in round 6 (68 C: 0.612 of 8 TB/s ... 72 C: 0.598, the mix ceiling falling
+    with it - profiles/r06_box_probe.md).  {} when rocm-smi is missing or fails."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        txt = subprocess.run([exe, "-d", "0", "--showtemp", "--showclocks", "--showpower"], capture_output=True, text=True,
+                             timeout=30).stdout
+    except Exception:
+        return {}
+    out = {}
+    for key, pat in (("hbm_temperature_C", r"Sensor memory\) \(C\):\s*([0-9.]+)"),
+                     ("junction_temperature_C", r"Sensor junction\) \(C\):\s*([0-9.]+)"),
+                     ("sclk_MHz", r"sclk clock level:[^(]*\((\d+)Mhz\)"), ("mclk_MHz", r"mclk clock level:[^(]*\((\d+)Mhz\)"),
+                     ("fclk_MHz", r"fclk clock level:[^(]*\((\d+)Mhz\)"), ("power_W", r"Power \(W\):\s*([0-9.]+)")):
+        m = re.search(pat, txt)
+        if m:
+            out[key] = float(m.group(1))
+    return out
+
+
 # ---- HBM bytes per launch, measured in THIS run ---------------------------------------------------
 def live_traffic(dtype_flag, timeout_s=150):
     """roofline.traffic measured now, on this box: one call of the headline workload re-run under
@@ -116,7 +142,8 @@ def live_traffic(dtype_flag, timeout_s=150):
     if not os.path.exists(prof):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--dtype", dtype_flag,
-             "--no-cpu", "--no-newton", "--no-e2e", "--no-configs", "--no-live-traffic", "--no-f32", "--calibrate-copy"]
+             "--no-cpu", "--no-newton", "--no-mix", "--no-e2e", "--no-configs", "--no-live-traffic", "--no-f32",
+             "--calibrate-copy"]
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="gspx_pmc_", dir="/tmp")
@@ -478,6 +505,36 @@ def headline_other_dtype(a, ctx, G, c, x, lmax, dtype, oracle=True):
         ctx.sync()
         elapsed = time.perf_counter() - t0
         y = by.download(xs.shape, dtype)[:, :2]
+        # the same call as evaluation='auto' would run it (Newton form when the guard clears it), and the mix ceiling
+        from pygsp_amd import filters
+        newton_ms = y_newton = None
+        auto = filters.choose_evaluation("auto", np.atleast_2d(c[0]), dtype, N, nsig)
+        if auto == "newton" and not a.no_newton:
+            nodes, dcoef = filters.cheb_to_newton(c[0])
+            dev.newton_filter_dev(nodes, dcoef, bx.ptr, by.ptr, nsig, lmax)
+            n_ms = 0.0
+            for _ in range(max(3, a.steps // 2)):
+                dev.newton_filter_dev(nodes, dcoef, bx.ptr, by.ptr, nsig, lmax)
+                n_ms += ctx.last_timing()["steps_ms"]
+            newton_ms = n_ms / (max(3, a.steps // 2) * K)
+            y_newton = by.download(xs.shape, dtype)[:, :2]
+        mix = None
+        if not a.no_mix and nsig * elt > 128 and G.tile_stats and G.tile_stats.get("enabled"):
+            try:
+                acc = {"real": [0.0, 0], 1: [0.0, 0], 2: [0.0, 0]}
+                for rep in range(6):
+                    for which in ("real", 1, 2):
+                        if which == "real":
+                            dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, lmax)
+                            t = ctx.last_timing()
+                        else:
+                            t = dev.bench_step_mix(c[0], bx.ptr, by.ptr, nsig, lmax, which)
+                        if rep:
+                            acc[which][0] += t["steps_ms"]
+                            acc[which][1] += t["step_launches"]
+                mix = {k_: v[0] / max(v[1], 1) for k_, v in acc.items()}
+            except Exception as e:
+                mix = {"error": repr(e)}
     finally:
         bx.free()
         by.free()
@@ -492,11 +549,25 @@ def headline_other_dtype(a, ctx, G, c, x, lmax, dtype, oracle=True):
                         "avg_launch_ms": avg, "launches_timed": launches, "traffic": None},
            "note": "same graph, coefficients and signals as the headline, computed in this dtype (its own device "
                    "Laplacian and tiles); roofline from the HIP-event time of the recurrence launches"}
+    res["auto_evaluation"] = auto
+    if newton_ms is not None:
+        res["newton_form"] = {"ms_per_order": newton_ms, "frac_of_8TBps": b_launch / (newton_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "guard": filters.newton_guard(c[0], dtype)[1]}
+    if mix is not None and "error" not in mix:
+        res["roofline"].update(mix_launch_ms=mix[1], mix_nobarrier_launch_ms=mix[2], step_launch_ms_beside_mix=mix["real"],
+                               frac_of_mix_ceiling=mix[1] / mix["real"],
+                               mix_ceiling_frac=b_launch / (mix[1] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    elif mix is not None:
+        res["roofline"]["mix_error"] = mix["error"]
     if oracle:
         from oracle import cheby_oracle as orc
         ref = orc.cheby_op(G.L.astype(np.float64), lmax, c[0], x[:, :2].astype(np.float64))
         res["parity_vs_oracle"] = {"max_rel_err": float(np.max(np.abs(y - ref)) / np.max(np.abs(ref))), "columns": 2,
                                    "tolerance": 1e-3 if elt == 4 else 1e-5}
+        if y_newton is not None:
+            res["newton_form"]["parity_vs_oracle"] = {
+                "max_rel_err": float(np.max(np.abs(y_newton - ref)) / np.max(np.abs(ref))), "columns": 2,
+                "tolerance": 1e-3 if elt == 4 else 1e-5}
     for dt, g_ in list(G._dev.items()):  # the extra device graph goes; the headline's stays
         if dt == np.dtype(dtype) and dt != G.compute_dtype:
             g_.destroy()
@@ -1026,10 +1097,44 @@ def main():
             n_elapsed = gdist.max_over_ranks(n_elapsed, rdev)
         return n_elapsed, n_ms
 
-    newton = None
+    newton = y_newton = None
     if a.evaluation == "recurrence" and not a.no_newton:
         newton = time_newton()
-    if newton is not None:
+        if torch is None and not a.no_cpu:  # its result, for the parity leg below (the recurrence overwrites y next)
+            y_newton = by.download((1, N, nsig), dtype)[0][:, :min(a.cpu_cols, nsig)].copy()
+    # ---- the mix ceiling of the recurrence step on THIS box (VERDICT r5 "Next 1"): the same call with the row
+    # products removed from every launch (gspx_bench_step_mix: same grid, LDS-DMA tile loads, T_{k-2} / accumulator
+    # loads, entry stream, stores, flushes and cache bits), mode 1 with the pass barriers, mode 2 without; real calls
+    # alternate with the calibration calls so that all three see the same minutes of the same box
+    mix = None
+    tiled_now = bool(G.tile_stats and G.tile_stats.get("enabled"))
+    if (a.evaluation == "recurrence" and not a.no_mix and world == 1 and tiled_now and nsig * elt > 128
+            and (nsig * elt) % 16 == 0):
+        try:
+            import threading
+            smi = {}
+            th = threading.Thread(target=lambda: smi.update(smi_sample()), daemon=True)
+            th.start()  # rocm-smi reads its sensors while the loop below keeps the GPU at the recurrence
+            acc = {"real": [0.0, 0], 1: [0.0, 0], 2: [0.0, 0]}
+            rep, t_mix0 = 0, time.perf_counter()
+            while rep < 1 + max(3, min(a.steps, 10)) or (th.is_alive() and time.perf_counter() - t_mix0 < 5.0):
+                for which in ("real", 1, 2):
+                    if which == "real":
+                        step_recurrence()
+                        t = ctx.last_timing()
+                    else:
+                        t = dev.bench_step_mix(c[0], bx.ptr, y_ptr, nsig, lmax, which)
+                    if rep:  # rep 0: warm-up
+                        acc[which][0] += t["steps_ms"]
+                        acc[which][1] += t["step_launches"]
+                rep += 1
+            th.join(10.0)
+            mix = {k_: v[0] / max(v[1], 1) for k_, v in acc.items()}
+            mix["smi"] = dict(smi)
+            mix["read_GBps"] = ctx.bench_read(1 << 30, 5)
+        except Exception as e:  # a calibration: never a reason to lose the measurement
+            mix = {"error": repr(e)}
+    if newton is not None or mix is not None:
         step_recurrence()  # leave the headline result in y for the parity check / the gather below
         fence()
 
@@ -1134,8 +1239,12 @@ def main():
 
     def newton_report(r):
         ms_order = r[1] / (K * a.steps)
-        out = {"note": ("same interpolating polynomial in Newton form (two-term Horner recurrence, no "
-                        "accumulator): opt-in evaluation='newton'; parity-tested against the reference"),
+        guard_ok, guard = filters.newton_guard(c[0], dtype)
+        out = {"note": ("same interpolating polynomial in Newton form (two-term Horner recurrence, no accumulator): "
+                        "evaluation='newton', and what evaluation='auto' runs for this call when the host-side "
+                        "guard clears the polynomial (filters.newton_guard); parity_vs_oracle below is of THIS run"),
+               "guard_ok": guard_ok, "guard": guard,
+               "auto_picks": filters.choose_evaluation("auto", np.atleast_2d(c[0]), dtype, N, nsig),
                "value": world * N * nsig * K * a.steps / r[0], "ms_per_step": r[0] / a.steps * 1e3,
                "ms_per_order": ms_order,
                "achieved_GBps_alg": b_alg_launch / (ms_order * 1e-3) / 1e9,
@@ -1338,6 +1447,10 @@ def main():
                                           "columns": cols, "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
         out["parity_vs_oracle"] = {"max_rel_err": err, "columns": cols,
                                    "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
+        if y_newton is not None and out.get("newton_form"):  # the Newton evaluation of the same call, same oracle columns
+            out["newton_form"]["parity_vs_oracle"] = {
+                "max_rel_err": float(np.max(np.abs(y_newton[:, :cols] - ref)) / np.max(np.abs(ref))), "columns": cols,
+                "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
     # ---- the other BASELINE configs (N=1 only), appended after the headline keys ---------------------
     if rank == 0 and world == 1 and not a.no_configs:
         bx.free()
@@ -1365,7 +1478,37 @@ def main():
         rf["f32_frac"] = (f32.get("roofline") or {}).get("frac")
         rf["f32_frac_whole_call"] = f32.get("frac_whole_call")
         rf["f32_parity_max_rel_err"] = (f32.get("parity_vs_oracle") or {}).get("max_rel_err")
-        rf["newton_frac"] = (out.get("newton_form") or {}).get("frac_of_8TBps")
+        rf["f32_frac_of_mix_ceiling"] = (f32.get("roofline") or {}).get("frac_of_mix_ceiling")
+        rf["f32_mix_ceiling_frac"] = (f32.get("roofline") or {}).get("mix_ceiling_frac")
+        rf["f32_auto_evaluation"] = f32.get("auto_evaluation")
+        rf["f32_auto_frac"] = ((f32.get("newton_form") or {}).get("frac_of_8TBps") if f32.get("auto_evaluation") == "newton"
+                               else rf["f32_frac"])
+        rf["f32_newton_parity_max_rel_err"] = ((f32.get("newton_form") or {}).get("parity_vs_oracle") or {}).get("max_rel_err")
+        nf_ = out.get("newton_form") or {}
+        rf["newton_frac"] = nf_.get("frac_of_8TBps")
+        rf["newton_parity_max_rel_err"] = (nf_.get("parity_vs_oracle") or {}).get("max_rel_err")
+        # what evaluation='auto' (plugin.install(evaluation='auto') / Filter.filter(..., evaluation='auto')) runs for this
+        # very call, and the fraction it reaches: the Newton form when the guard clears it, else the recurrence
+        rf["auto_evaluation"] = nf_.get("auto_picks")
+        rf["auto_frac"] = rf["newton_frac"] if nf_.get("auto_picks") == "newton" else (rf["frac"] if nf_ else None)
+        # the mix ceiling: what THIS box's memory system delivers to the step's own access mix with the arithmetic
+        # removed (same launches, same bytes).  frac_of_mix_ceiling = mix time / step time of calls alternating in the
+        # same minute (1.0: the step is bound by the memory system serving this mix, not by its row products);
+        # mix_ceiling_GBps = the step's measured HBM bytes per launch over the mix time; mix_ceiling_frac = `frac` if
+        # the step ran at the mix kernel's speed; the *_nobarrier figures drop the two workgroup barriers of a pass too
+        if mix is not None and "error" not in mix:
+            rf["read_GBps_this_run"] = mix["read_GBps"]
+            rf["mix_launch_ms"], rf["mix_nobarrier_launch_ms"] = mix[1], mix[2]
+            rf["step_launch_ms_beside_mix"] = mix["real"]
+            rf["frac_of_mix_ceiling"] = mix[1] / mix["real"]
+            rf["frac_of_mix_ceiling_nobarrier"] = mix[2] / mix["real"]
+            rf["mix_ceiling_GBps"] = (traffic / (mix[1] * 1e-3) / 1e9) if traffic else None
+            rf["step_traffic_GBps"] = (traffic / (mix["real"] * 1e-3) / 1e9) if traffic else None
+            rf["mix_ceiling_frac"] = b_alg_launch / (mix[1] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            rf["mix_nobarrier_ceiling_frac"] = b_alg_launch / (mix[2] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            rf["smi_under_load"] = mix.get("smi") or None
+        elif mix is not None:
+            rf["mix_error"] = mix["error"]
         cfgs = out.get("configs")
         if isinstance(cfgs, list):
             rf["configs_frac"] = {"{}_{}".format(c_.get("key", i), c_.get("dtype", "")): (c_.get("roofline") or {}).get("frac")

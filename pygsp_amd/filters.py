@@ -68,16 +68,21 @@ def _quadrature_tables(m, points):
 
 # How a SINGLE filter's polynomial is evaluated on the device (filterbanks and synthesis always
 # use the three-term recurrence):
-#   'recurrence' - the reference's three-term Chebyshev recurrence (approximations.py:99-112);
+#   'recurrence' - the reference's three-term Chebyshev recurrence (approximations.py:99-112); the default;
 #   'newton'     - the identical polynomial in Newton form on Leja-ordered Chebyshev nodes, by
-#                  Horner: a two-term recurrence, 3 instead of 3 2/3 panel passes per order.
+#                  Horner: a two-term recurrence, 3 instead of 3 2/3 panel passes per order;
+#   'auto'       - 'newton' for the calls where it is the faster evaluation AND newton_guard() clears the
+#                  polynomial for the compute dtype (one filter, analysis, one device, a panel beyond the
+#                  launch-bound sizes that replay as one hipGraph); the recurrence for everything else.
+EVALUATIONS = ("recurrence", "newton", "auto")
 EVALUATION = "recurrence"
+AUTO_MIN_PANEL_BYTES = 32 << 20  # below: the recurrence replays as one hipGraph (gspx option graph_launch = 2)
 
 
 def set_evaluation(mode):
     global EVALUATION
-    if mode not in ("recurrence", "newton"):
-        raise ValueError("evaluation must be 'recurrence' or 'newton'")
+    if mode not in EVALUATIONS:
+        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
     EVALUATION = mode
 
 
@@ -107,14 +112,20 @@ def _leja_order(points):
 _newton_cache = {}
 
 
-def cheb_to_newton(c):
+def cheb_to_newton(c, ordering="leja"):
     """Chebyshev coefficients c_0..c_K of p(t) = c_0/2 + sum_k c_k T_k(t) (as compute_cheby_coeff
     returns them) -> (nodes r_0..r_{K-1}, divided differences d_0..d_K) of the SAME polynomial,
     p(t) = sum_j d_j prod_{i<j} (t - r_i).  Computed in 80+4K-digit decimal arithmetic from the
-    float64 inputs, so the only rounding is the final conversion of d_j to float64."""
+    float64 inputs, so the only rounding is the final conversion of d_j to float64.
+    `ordering`: 'leja' (what the engine uses: bounded partial products, a stable Horner evaluation) or 'sorted'
+    (the nodes in decreasing order: the textbook ill-conditioned Newton form, for the guard's tests)."""
     import decimal
     c = np.asarray(c, dtype=np.float64).ravel()
-    key = c.tobytes()
+    if not np.all(np.isfinite(c)):
+        raise ValueError("the Chebyshev coefficients must be finite")
+    if ordering not in ("leja", "sorted"):
+        raise ValueError("ordering must be 'leja' or 'sorted'")
+    key = c.tobytes() + ordering.encode()
     hit = _newton_cache.get(key)
     if hit is not None:
         return hit
@@ -124,7 +135,9 @@ def cheb_to_newton(c):
     D = decimal.Decimal
     with decimal.localcontext() as ctx:
         ctx.prec = 80 + 4 * K
-        nodes = _leja_order(np.cos(np.pi * (np.arange(K) + 0.5) / K))
+        nodes = np.cos(np.pi * (np.arange(K) + 0.5) / K)
+        if ordering == "leja":
+            nodes = _leja_order(nodes)
         extra = 0.0 if np.all(np.abs(nodes) > 1e-3) else 0.987654321
         r = [D(float(v)) for v in nodes] + [D(extra)]
         cd = [D(float(v)) for v in c]
@@ -146,6 +159,116 @@ def cheb_to_newton(c):
         _newton_cache.clear()
     _newton_cache[key] = out
     return out
+
+
+# Host-side stability guard of the Newton evaluation (VERDICT r5 "Next 2c").  Every eigencomponent of a signal goes
+# through the SCALAR Horner recurrence h_j = (t - r_j) h_{j+1} + d_j at its own t in [-1, 1], so the scalar
+# polynomial tells what the device will do:
+#   grid_err       both forms evaluated on a grid over [-1, 1] (the Chebyshev sum in extended precision, the Horner
+#                  form in the COMPUTE dtype with the rounded r_j, d_j the kernels receive): max |difference| / max |p|;
+#   amplification  the running error bound of the Horner form: a rounding error made at stage j is carried to the
+#                  result through prod_{i<j} (t - r_i), so  A = sum_j max_t |prod_{i<j}(t - r_i)| max_t |h_j(t)| / max |p|
+#                  and eps A (times a small factor for the row products) bounds the relative error of the result;
+#   finite         every d_j, r_j and intermediate representable in the compute dtype (fp32: orders beyond ~120
+#                  overflow d_j ~ 2^j).
+# On Leja-ordered Chebyshev nodes A stays below ~150 for the Heat / Mexican-hat kernels at orders 30-200
+# (profiles/r06_newton_guard.md); the guard is what notices anything else.
+NEWTON_GUARD = {
+    # compute dtype: (largest grid_err, largest eps * A * 8)
+    np.dtype(np.float64): (1e-12, 1e-10),
+    np.dtype(np.float32): (2e-5, 2.5e-4),
+}
+_guard_cache = {}
+
+
+def newton_stability(c, dtype=np.float64, nodes=None, dcoef=None):
+    """The guard's measurements for the polynomial with Chebyshev coefficients `c` evaluated in `dtype` through
+    the Newton form (`nodes`, `dcoef`; default: cheb_to_newton(c)).  Returns a dict: K, grid_err, amplification,
+    eps_amplification, finite, d_max, p_max."""
+    c = np.asarray(c, dtype=np.float64).ravel()
+    dt = np.dtype(dtype)
+    if nodes is None or dcoef is None:
+        nodes, dcoef = cheb_to_newton(c)
+    nodes, dcoef = np.asarray(nodes, dtype=np.float64), np.asarray(dcoef, dtype=np.float64)
+    K = nodes.size
+    grid = np.unique(np.concatenate([np.cos(np.linspace(0.0, np.pi, 8 * K + 9)), nodes, [-1.0, 1.0]]))
+    # the Chebyshev sum, extended precision (approximations.py:99-112 on a scalar)
+    tl, cl = grid.astype(np.longdouble), c.astype(np.longdouble)
+    t_old, t_cur = np.ones_like(tl), tl.copy()
+    p = cl[0] / 2 + cl[1] * t_cur
+    for k in range(2, K + 1):
+        t_old, t_cur = t_cur, 2 * tl * t_cur - t_old
+        p = p + cl[k] * t_cur
+    p_max = float(np.max(np.abs(p)))
+    with np.errstate(all="ignore"):
+        g, dd, rr = grid.astype(dt), dcoef.astype(dt), nodes.astype(dt)
+        h = np.full_like(g, dd[K])
+        h_max = [float(np.max(np.abs(h)))]
+        for j in range(K - 1, -1, -1):
+            h = (g - rr[j]) * h + dd[j]
+            h_max.append(float(np.max(np.abs(h))))
+        h_max.reverse()  # h_max[j]: the Horner intermediate whose leading coefficient is d_j
+        finite = bool(np.all(np.isfinite(dd)) and np.all(np.isfinite(h_max)))
+        part, part_max = np.ones_like(grid), [1.0]
+        for j in range(K):
+            part = part * (grid - nodes[j])
+            part_max.append(float(np.max(np.abs(part))))
+        scale = p_max if p_max > 0 else 1.0
+        grid_err = float(np.max(np.abs(h.astype(np.longdouble) - p))) / scale if finite else float("inf")
+        amp = float(sum(a * b for a, b in zip(part_max, h_max))) / scale if finite else float("inf")
+    return {"K": int(K), "dtype": dt.name, "grid_err": grid_err, "amplification": amp,
+            "eps_amplification": float(np.finfo(dt).eps) * amp, "finite": finite,
+            "d_max": float(np.max(np.abs(dcoef))), "p_max": p_max}
+
+
+def newton_guard(c, dtype=np.float64):
+    """(ok, measurements): may the polynomial with Chebyshev coefficients `c` be evaluated in Newton form in
+    `dtype`?  ok is False when the two forms of the scalar polynomial disagree on the grid beyond the dtype's
+    threshold, when the running error bound exceeds it, or when a coefficient or intermediate is not representable
+    (NEWTON_GUARD); evaluation='auto' then keeps the three-term recurrence."""
+    c = np.asarray(c, dtype=np.float64).ravel()
+    dt = np.dtype(dtype)
+    key = (c.tobytes(), dt.str)
+    hit = _guard_cache.get(key)
+    if hit is not None:
+        return hit
+    if dt not in NEWTON_GUARD or c.size < 2 or not np.all(np.isfinite(c)):
+        out = (False, {"K": int(c.size - 1), "dtype": dt.name, "finite": False, "reason": "coefficients"})
+    else:
+        m = newton_stability(c, dt)
+        lim_grid, lim_amp = NEWTON_GUARD[dt]
+        why = ("overflow" if not m["finite"] else "grid" if not m["grid_err"] <= lim_grid
+               else "amplification" if not 8 * m["eps_amplification"] <= lim_amp else None)
+        m["reason"] = why
+        out = (why is None, m)
+    if len(_guard_cache) > 256:
+        _guard_cache.clear()
+    _guard_cache[key] = out
+    return out
+
+
+def choose_evaluation(evaluation, coeffs, dtype, n_vertices, n_signals, split=False):
+    """'recurrence' or 'newton' for one analysis call.  'newton' is the caller's explicit choice (a polynomial that
+    does not fit the compute dtype is an error then, not a silent fallback); 'auto' takes Newton only where it is
+    both faster and cleared by newton_guard()."""
+    if evaluation not in EVALUATIONS:
+        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
+    if evaluation == "recurrence" or coeffs.shape[0] != 1:
+        return "recurrence"
+    if evaluation == "newton":
+        if split:
+            # (the column split runs the three-term recurrence on every GPU: the same call must not return
+            # different bits with and without a device list)
+            raise ValueError("evaluation='newton' is a single-device evaluation; it cannot be combined with a device "
+                             "list (devices=[...] / plugin.install(devices=[...]))")
+        ok, m = newton_guard(coeffs[0], dtype)
+        if not m.get("finite", False):
+            raise ValueError("evaluation='newton': the Newton coefficients of this order-{} polynomial are not "
+                             "representable in {} - use the recurrence (or evaluation='auto')".format(m["K"], m["dtype"]))
+        return "newton"
+    if split or n_vertices * n_signals * np.dtype(dtype).itemsize < AUTO_MIN_PANEL_BYTES:
+        return "recurrence"
+    return "newton" if newton_guard(coeffs[0], dtype)[0] else "recurrence"
 
 
 def _as_coeff_matrix(c):
@@ -173,24 +296,26 @@ def cheby_op(G, c, signal, **kwargs):
                          "G.N = {}, got {}.".format(G.N, panel.shape))
     vector_in = panel.ndim == 1
     x = panel[:, np.newaxis] if vector_in else panel
-    evaluation = kwargs.get("evaluation") or EVALUATION
-    if evaluation not in ("recurrence", "newton"):
-        raise ValueError("evaluation must be 'recurrence' or 'newton'")
     devices = _device_list(G, kwargs.get("devices"))
-    if devices is not None and evaluation == "newton":
-        # (the column split runs the three-term recurrence on every GPU: the same call must not return
-        # different bits with and without a device list)
-        raise ValueError("evaluation='newton' is a single-device evaluation; it cannot be combined with a device "
-                         "list (devices=[...] / plugin.install(devices=[...]))")
+    evaluation = kwargs.get("evaluation") or _configured_evaluation(G)
+    if evaluation not in EVALUATIONS:
+        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
     if devices is not None and x.shape[1] > 0:
+        choose_evaluation(evaluation, coeffs, np.float64, G.N, x.shape[1], split=True)  # ('newton' + a split: an error)
         # signal-parallel: the graph replicated per GPU, the columns split, one RCCL gather
         from . import multi
         y, ms = multi.filter_columns(G, coeffs, x, devices, _capi.ANALYSIS)
-    elif evaluation == "newton" and coeffs.shape[0] == 1:
-        y, ms = _device_graph_of(G).newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
+        how = "recurrence"
     else:
-        y, ms = _device_graph_of(G).cheby_filter(coeffs, x, G.lmax, _capi.ANALYSIS)
-    _record_timing(G, ms)
+        dev = _device_graph_of(G)
+        how = "recurrence"
+        if evaluation != "recurrence":  # (the default never looks at the device graph's dtype or the guard)
+            how = choose_evaluation(evaluation, coeffs, dev.dtype, G.N, x.shape[1])
+        if how == "newton":
+            y, ms = dev.newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
+        else:
+            y, ms = dev.cheby_filter(coeffs, x, G.lmax, _capi.ANALYSIS)
+    _record_timing(G, ms, how)
     stacked = np.asarray(y, dtype=np.float64).reshape(coeffs.shape[0] * G.N, x.shape[1])
     return stacked[:, 0] if vector_in else stacked
 
@@ -260,11 +385,21 @@ def _device_list(G, devices):
     return devices if len(devices) > 1 else None
 
 
-def _record_timing(G, ms):
+def _record_timing(G, ms, evaluation="recurrence"):
     try:
         G._gspx_last_kernel_ms = ms
+        G._gspx_last_evaluation = evaluation
     except Exception:
         pass
+
+
+def _configured_evaluation(G):
+    """The evaluation of a call that names none: plugin.install(evaluation=...) for a reference graph, the module
+    default (set_evaluation) for the mirror classes."""
+    if not hasattr(G, "device_graph"):
+        from . import plugin
+        return plugin._config.get("evaluation") or EVALUATION
+    return EVALUATION
 
 
 def _shape_of(s):
@@ -293,7 +428,7 @@ def _cube_shape(G, Nf, shape):
     return shape
 
 
-def filter_signals(bank, s, method="chebyshev", order=30, devices=None, coefficients=None):
+def filter_signals(bank, s, method="chebyshev", order=30, devices=None, coefficients=None, evaluation=None):
     """``Filter.filter`` (filter.py:146-328) for any object with the reference's Filter attributes (``G``, ``Nf``,
     what `coefficients` reads): the mirror class below and - through plugin.install(wrap_filter=True) - the real
     pygsp.filters.Filter.  `coefficients(bank, m=order)`: compute_cheby_coeff of whichever package `bank`
@@ -302,7 +437,8 @@ def filter_signals(bank, s, method="chebyshev", order=30, devices=None, coeffici
     analysis:  one device call, output planes [filter][vertex][signal] viewed as (vertex, signal, filter);
     synthesis: ONE device call (vector-coefficient Clenshaw: K products) where the reference loops over the
                filters (filter.py:318-321: Nf x cheby_op = K Nf products and Nf host round trips);
-    a DeviceArray in gives a DeviceArray out (nothing crosses PCIe)."""
+    a DeviceArray in gives a DeviceArray out (nothing crosses PCIe).
+    `evaluation` (analysis with one filter only): 'recurrence' | 'newton' | 'auto', default the configured one."""
     from . import engine
     coefficients = coefficients or compute_cheby_coeff
     on_device = isinstance(s, engine.DeviceArray)
@@ -320,11 +456,11 @@ def filter_signals(bank, s, method="chebyshev", order=30, devices=None, coeffici
         raise ValueError("Unknown method {}.".format(method))
     coeffs = coefficients(bank, m=order)
     if on_device:
-        return _filter_device_array(bank, s, cube_shape, _as_coeff_matrix(coeffs), devices)
+        return _filter_device_array(bank, s, cube_shape, _as_coeff_matrix(coeffs), devices, evaluation)
     cube = s.reshape(cube_shape)
     if not synthesis:
         # device buffer [filter][vertex][signal] -> (vertex, signal, filter), as filter.py:310-311
-        flat = cheby_op(bank.G, coeffs, cube[:, :, 0], devices=devices)
+        flat = cheby_op(bank.G, coeffs, cube[:, :, 0], devices=devices, evaluation=evaluation)
         out = np.moveaxis(flat.reshape(bank.Nf, bank.G.N, cube.shape[1]), 0, 2)
     else:
         # out = sum_f p_f(L) s[:, :, f]  (filter.py:313-322), one device call
@@ -343,7 +479,7 @@ def filter_signals(bank, s, method="chebyshev", order=30, devices=None, coeffici
     return np.squeeze(out)
 
 
-def _filter_device_array(bank, s, cube_shape, coeffs, devices):
+def _filter_device_array(bank, s, cube_shape, coeffs, devices, evaluation=None):
     """The device-resident form of filter_signals: `s` (engine.DeviceArray) is read as `cube_shape`, filtered
     where it lies and returned as a new DeviceArray whose `shape` is what the reference would have returned."""
     from . import engine
@@ -358,12 +494,16 @@ def _filter_device_array(bank, s, cube_shape, coeffs, devices):
     synthesis = nfeat != 1
     x_ptr, keep = s.planes(nsig, nfeat)
     out = engine.DeviceArray.empty(dev.ctx, (N, nsig, 1 if synthesis else bank.Nf), dev.dtype)
-    ms = 0.0
-    if N * nsig:
+    ms, how = 0.0, "recurrence"
+    if not synthesis:
+        how = choose_evaluation(evaluation or _configured_evaluation(bank.G), coeffs, dev.dtype, N, nsig)
+    if N * nsig and how == "newton":
+        ms = dev.newton_filter_dev(*cheb_to_newton(coeffs[0]), x_ptr, out.ptr, nsig, bank.G.lmax)
+    elif N * nsig:
         ms = dev.cheby_filter_dev(coeffs, x_ptr, out.ptr, nsig, bank.G.lmax,
                                   _capi.SYNTHESIS if synthesis else _capi.ANALYSIS)
     del keep
-    _record_timing(bank.G, ms)
+    _record_timing(bank.G, ms, how)
     return out
 
 
@@ -415,15 +555,17 @@ class Filter:
         at = np.asanyarray(x)
         return np.stack([np.broadcast_to(g(at), at.shape) for g in self._kernels]).astype(np.float64)
 
-    def filter(self, s, method="chebyshev", order=30, devices=None):
+    def filter(self, s, method="chebyshev", order=30, devices=None, evaluation=None):
         """Filter signals (analysis or synthesis), filter.py:146-328.
 
         Shapes follow the reference exactly: `s` is (N,), (N, Nsig) or (N, Nsig, Nfeat) with
         Nfeat in {1, Nf}; a trailing dimension equal to Nf means synthesis.  The result is
         squeezed.  This engine's additions: `devices`, a list of GPU ids to split the signal columns over;
-        `s` may be an engine.DeviceArray (G.to_device(x)), and then so is the result (see filter_signals).
+        `s` may be an engine.DeviceArray (G.to_device(x)), and then so is the result (see filter_signals);
+        `evaluation` ('recurrence' | 'newton' | 'auto'): how a single filter's polynomial is evaluated in an
+        analysis call (default: filters.EVALUATION, see set_evaluation and newton_guard).
         """
-        return filter_signals(self, s, method, order, devices)
+        return filter_signals(self, s, method, order, devices, evaluation=evaluation)
 
     def analyze(self, s, method="chebyshev", order=30, devices=None):
         shape = _shape_of(s)

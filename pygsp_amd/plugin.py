@@ -22,7 +22,7 @@ import threading
 _SAVED = "_gspx_saved"
 _installed = {}  # id(module) -> module, in installation order (uninstall() without an argument: the last one)
 _config = {"laplacian": "device", "dtype": np.float64, "device": 0, "reorder": "auto", "tiles": "auto",
-           "devices": None}
+           "devices": None, "evaluation": None}
 _cache_lock = threading.RLock()
 
 
@@ -166,7 +166,7 @@ def _filters_logger(bank):
 
 
 def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, reorder="auto",
-            tiles="auto", devices=None, lmax="reference", wrap_filter=True):
+            tiles="auto", devices=None, lmax="reference", wrap_filter=True, evaluation=None):
     """Patch the real pygsp in place.  `laplacian`: 'device' (L assembled by HIP kernels from
     G.W) or 'host' (upload the reference's G.L).  `devices` (a list of GPU ids, optional): every
     ``Filter.filter(method='chebyshev')`` splits its signal columns over these GPUs - the graph is replicated
@@ -175,7 +175,14 @@ def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, r
     (the step right before the path); 'reference' (default) leaves ARPACK in place.
     `wrap_filter` (default True; the secondary seam of SURVEY 8(b)): also replace ``Filter.filter`` and
     ``Filter.compute_frame`` (filter.py:146, 506) - fused synthesis, device-built identity panels,
-    device-resident arrays; False patches ``cheby_op`` alone, and the reference's own loops call it."""
+    device-resident arrays; False patches ``cheby_op`` alone, and the reference's own loops call it.
+    `evaluation`: how the polynomial of a SINGLE filter is evaluated in analysis calls - 'recurrence' (the
+    reference's three-term recurrence, approximations.py:99-112), 'newton' (the same polynomial in Newton form:
+    fewer panel passes per order) or 'auto' (Newton where it is faster and filters.newton_guard() clears the
+    polynomial for the compute dtype, the recurrence otherwise); None (default): pygsp_amd.filters.EVALUATION,
+    which is 'recurrence' unless filters.set_evaluation() changed it."""
+    if evaluation is not None and evaluation not in _filters.EVALUATIONS:
+        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
     if laplacian not in ("device", "host"):
         raise ValueError("laplacian must be 'device' or 'host'")
     if lmax not in ("device", "reference"):
@@ -188,7 +195,7 @@ def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, r
             raise ValueError("devices must name at least one GPU")
         device = devices[0]
     _config.update(laplacian=laplacian, dtype=np.dtype(dtype), device=int(device), reorder=reorder,
-                   tiles=tiles, devices=devices)
+                   tiles=tiles, devices=devices, evaluation=evaluation)
     approx = pygsp_module.filters.approximations
     if _SAVED not in approx.__dict__:
         setattr(approx, _SAVED, {"cheby_op": approx.cheby_op, "alias": getattr(pygsp_module.filters, "cheby_op", None)})
@@ -238,6 +245,8 @@ def uninstall(pygsp_module=None):
             except ImportError:
                 return
     _installed.pop(id(pygsp_module), None)
+    if not _installed:
+        _config["evaluation"] = None
     approx = pygsp_module.filters.approximations
     saved = _restore(approx, ("cheby_op",))
     if saved is None:

@@ -631,3 +631,35 @@ def test_library_has_no_retired_options(ctx):
         with pytest.raises(ValueError, match="unknown option"):
             ctx.set_option(key, 1)
     assert not hasattr(engine.DeviceGraph, "cheby_pair_filter_dev")
+
+
+@pytest.mark.parametrize("dtype,nsig", [(np.float64, 64), (np.float64, 32), (np.float32, 64), (np.float64, 96)])
+def test_mix_ceiling_calibration_runs_beside_the_filter(ctx, dtype, nsig):
+    """gspx_bench_step_mix (VERDICT r5 "Next 1"): the filter's launches with the row products removed - a calibration
+    whose output means nothing.  It must time the same number of launches, leave the context and the graph usable (the
+    next real call is right to rounding, eager and replayed), refuse calls that would not run the wide LDS-staged
+    step, and never be reachable through an option."""
+    G = graphs.Sensor(20000, seed=3, tiles=True, reorder="morton", compute_dtype=dtype, ctx=ctx)
+    G.estimate_lmax("bounds")
+    dev = G.device_graph(dtype)
+    x = np.random.default_rng(2).standard_normal((G.N, nsig)).astype(dtype)
+    c = orc.compute_cheby_coeff(orc.heat_kernel(10, G.lmax), G.lmax, 30)
+    ref = orc.cheby_op(orc.laplacian(G.W), G.lmax, c, x.astype(np.float64))
+    bx, by = ctx.upload(x), ctx.alloc(x.nbytes)
+    dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, G.lmax)
+    real = ctx.last_timing()
+    for mode in (1, 2):
+        t = dev.bench_step_mix(c, bx.ptr, by.ptr, nsig, G.lmax, mode)
+        assert t["step_launches"] == real["step_launches"] == 30 and t["steps_ms"] > 0
+    for _ in range(3):  # eager, recorded, replayed
+        dev.cheby_filter_dev(c, bx.ptr, by.ptr, nsig, G.lmax)
+        assert rel_err(by.download((G.N, nsig), dtype), ref) < TOL[np.dtype(dtype)]
+    assert np.array_equal(bx.download((G.N, nsig), dtype), x)  # the input is never written
+    with pytest.raises(ValueError, match="mode"):
+        dev.bench_step_mix(c, bx.ptr, by.ptr, nsig, G.lmax, 3)
+    with pytest.raises(ValueError, match="wide"):
+        dev.bench_step_mix(c, bx.ptr, by.ptr, 128 // np.dtype(dtype).itemsize, G.lmax, 1)  # 128-byte rows: narrow build
+    with pytest.raises(ValueError, match="unknown option"):
+        ctx.set_option("calib_mix", 1)
+    bx.free()
+    by.free()

@@ -528,3 +528,97 @@ def test_device_array_pool_is_locked_and_gives_way_to_allocations():
         assert ctx._pooled == 16 * sum(len(v) for v in ctx._pool.values())
     ctx.clear_pool()
     assert ctx.pooled_bytes() == 0
+
+
+def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
+    """VERDICT r5 "Next 2c/2d": the host-side guard of the Newton evaluation and evaluation='auto'.  The guard clears
+    the Heat / Mexican-hat polynomials on Leja-ordered nodes, trips on overflow (fp32 at order 200: d_j ~ 2^j) and on
+    a constructed ill-conditioned Newton form (the same nodes in sorted order - the textbook unstable case -, where
+    the Horner evaluation really is wrong by orders of magnitude more than the threshold); 'auto' takes Newton only
+    for one filter, analysis, one device, a panel beyond the launch-bound sizes, and a cleared polynomial."""
+    lmax = 22.1
+    for kern in [orc.heat_kernel(50, lmax), orc.heat_kernel(10, lmax)] + orc.mexican_hat_kernels(lmax, 6):
+        for order in (30, 50, 100, 200):
+            c = orc.compute_cheby_coeff(kern, lmax, order)
+            ok64, m64 = filters.newton_guard(c, np.float64)
+            assert ok64 and m64["grid_err"] < 1e-14 and m64["amplification"] < 200, m64
+            ok32, m32 = filters.newton_guard(c, np.float32)
+            if order <= 100:
+                assert ok32 and m32["grid_err"] < 5e-6, m32
+            else:
+                assert not ok32 and m32["reason"] == "overflow", m32
+    # the constructed ill-conditioned case: Newton form on SORTED Chebyshev nodes
+    c = orc.compute_cheby_coeff(orc.heat_kernel(50, lmax), lmax, 60)
+    nodes, d = filters.cheb_to_newton(c, ordering="sorted")
+    bad = filters.newton_stability(c, np.float64, nodes, d)
+    assert bad["finite"] and bad["grid_err"] > 1e-8 and bad["eps_amplification"] > 1e-6, bad
+    good = filters.newton_stability(c, np.float64)
+    assert good["grid_err"] < 1e-14 and good["eps_amplification"] < 1e-13, good
+    # ... and the guard's verdict on it, through the same thresholds newton_guard applies
+    lim_grid, lim_amp = filters.NEWTON_GUARD[np.dtype(np.float64)]
+    assert bad["grid_err"] > lim_grid and 8 * bad["eps_amplification"] > lim_amp
+    monkeypatch.setattr(filters, "cheb_to_newton", lambda cc, ordering="leja": (nodes, d))
+    filters._guard_cache.clear()
+    ok, m = filters.newton_guard(c, np.float64)
+    assert not ok and m["reason"] in ("grid", "amplification")
+    monkeypatch.undo()
+    filters._guard_cache.clear()
+    assert not filters.newton_guard(np.array([1.0, np.nan, 0.5]), np.float64)[0]
+    # choose_evaluation
+    c1, c6 = np.atleast_2d(c), np.tile(c, (6, 1))
+    big = (1000000, 64)
+    assert filters.choose_evaluation("auto", c1, np.float64, *big) == "newton"
+    assert filters.choose_evaluation("auto", c6, np.float64, *big) == "recurrence"          # a bank
+    assert filters.choose_evaluation("auto", c1, np.float64, 100000, 1) == "recurrence"     # launch-bound: hipGraph replay
+    assert filters.choose_evaluation("auto", c1, np.float64, *big, split=True) == "recurrence"
+    assert filters.choose_evaluation("recurrence", c1, np.float64, *big) == "recurrence"
+    assert filters.choose_evaluation("newton", c1, np.float64, 100, 1) == "newton"           # explicit: always
+    c200 = np.atleast_2d(orc.compute_cheby_coeff(orc.heat_kernel(50, lmax), lmax, 200))
+    assert filters.choose_evaluation("auto", c200, np.float32, *big) == "recurrence"       # guard: overflow
+    assert filters.choose_evaluation("auto", c200, np.float64, *big) == "newton"
+    with pytest.raises(ValueError, match="not representable"):
+        filters.choose_evaluation("newton", c200, np.float32, *big)
+    with pytest.raises(ValueError, match="single-device"):
+        filters.choose_evaluation("newton", c1, np.float64, *big, split=True)
+    with pytest.raises(ValueError, match="evaluation must be"):
+        filters.choose_evaluation("horner", c1, np.float64, *big)
+    # through Filter.filter with a stubbed device: 'auto' reaches newton_filter only when the rule says so
+    g = golden_sensor123
+    L, lm = csr_from(g, "Lcomb"), float(g["lmax"])
+    G = StubGraph(L, lm)
+    calls = []
+
+    class StubDev:
+        dtype = np.dtype(np.float64)
+
+        def cheby_filter(self, cc, x, lmx, mode=0):
+            calls.append("recurrence")
+            return orc.cheby_op(L, lmx, cc, x).reshape(cc.shape[0], G.N, -1), 0.0
+
+        def newton_filter(self, nd, dc, x, lmx):
+            calls.append("newton")
+            t = (2.0 / lmx) * L - sparse.identity(G.N)
+            h = dc[-1] * x
+            for j in range(len(nd) - 1, -1, -1):
+                h = t.dot(h) - nd[j] * h + dc[j] * x
+            return h, 0.0
+
+    monkeypatch.setattr(filters, "_device_graph_of", lambda G_: StubDev())
+    heat = filters.Heat(G, scale=10)
+    y = heat.filter(g["signals5"], order=30, evaluation="auto")  # 123 x 5: launch-bound -> recurrence
+    assert calls == ["recurrence"] and rel_err(y, g["heat10_y5"]) < 1e-13
+    monkeypatch.setattr(filters, "AUTO_MIN_PANEL_BYTES", 0)
+    y = heat.filter(g["signals5"], order=30, evaluation="auto")
+    assert calls[-1] == "newton" and rel_err(y, g["heat10_y5"]) < 1e-13 and G._gspx_last_evaluation == "newton"
+    filters.MexicanHat(G, Nf=6).filter(g["signals5"], order=40, evaluation="auto")
+    assert calls[-1] == "recurrence"
+    try:
+        filters.set_evaluation("auto")
+        heat.filter(g["signal"], order=30)
+        assert calls[-1] == "newton"
+    finally:
+        filters.set_evaluation("recurrence")
+    heat.filter(g["signal"], order=30)
+    assert calls[-1] == "recurrence"
+    with pytest.raises(ValueError):
+        filters.set_evaluation("horner")

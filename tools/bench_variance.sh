@@ -1,4 +1,4 @@
-q() { timeout 300 python bench.py --no-cpu --no-configs --no-newton --no-e2e --no-f32 --steps 10 --warmup 3 | python -c "import sys,json; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=b['roofline']; print('$1', round(r['frac'],4), round(r['avg_launch_ms'],4), 'copy', round(r['copy_GBps_this_run'],0))"; }
+q() { timeout 300 python bench.py --no-cpu --no-configs --no-newton --no-mix --no-e2e --no-f32 --steps 10 --warmup 3 | python -c "import sys,json; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=b['roofline']; print('$1', round(r['frac'],4), round(r['avg_launch_ms'],4), 'copy', round(r['copy_GBps_this_run'],0))"; }
 mkdir -p gpurun_out
 {
 q fresh1; q fresh2

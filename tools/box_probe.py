@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """One fresh box: the headline call (Sensor 1M, k = 8, 64 fp64 signals, Heat order 30, device resident) in a loop for a
 few seconds while rocm-smi is sampled UNDER LOAD - clocks, power, temperatures - next to the measured ms per call.
-Looking for what separates the 0.556 boxes from the 0.618 ones (profiles/r05_bench_variance.log).  GPU box only."""
+Looking for what separates the 0.556 boxes from the 0.618 ones (profiles/r05_bench_variance.log).  Round 6: the MIX
+CEILING beside it - the same call with the row products removed from every launch (gspx_bench_step_mix, mode 1 with the
+pass barriers, mode 2 without), real and calibration calls alternating - plus the read-only and copy rates of the box:
+is a slow box slow for the access mix itself (frac_of_mix_ceiling ~ 1 on both kinds of box) or for the kernel?
+GPU box only.  Appends one line to $BOX_PROBE_LOG when set."""
 import json
 import os
 import subprocess
@@ -46,5 +50,27 @@ elt = 8
 U = G.N * 64 * elt
 b_alg = 30 * (dev.nnz_l * 12 + 4 * (G.N + 1) + 3 * U) + U
 med = float(np.median(ms[5:]))
-print(json.dumps({"ms_per_call": med, "frac_whole_call": b_alg / (med * 1e-3) / 8e12, "calls": len(ms),
-                  "first_calls_ms": ms[:3], "last_calls_ms": ms[-3:], "smi_under_load": samples}))
+# the mix ceiling: real / mode 1 / mode 2 calls alternating (per-launch times from the library's HIP events)
+acc = {"real": [], 1: [], 2: []}
+for rep in range(9):
+    for which in ("real", 1, 2):
+        if which == "real":
+            dev.cheby_filter_dev(c, bx.ptr, by.ptr, 64, float(G.lmax))
+            t = ctx.last_timing()
+        else:
+            t = dev.bench_step_mix(c[0], bx.ptr, by.ptr, 64, float(G.lmax), which)
+        if rep:
+            acc[which].append(t["steps_ms"] / t["step_launches"])
+mixr = {str(k): float(np.median(v)) for k, v in acc.items()}
+b_launch = b_alg / 30
+rates = {"read_GBps": ctx.bench_read(1 << 30, 5), "copy_GBps": ctx.bench_copy(1 << 30, 5)}
+rec = {"ms_per_call": med, "frac_whole_call": b_alg / (med * 1e-3) / 8e12, "calls": len(ms),
+       "step_launch_ms": mixr["real"], "mix_launch_ms": mixr["1"], "mix_nobarrier_launch_ms": mixr["2"],
+       "frac": b_launch / (mixr["real"] * 1e-3) / 8e12, "mix_ceiling_frac": b_launch / (mixr["1"] * 1e-3) / 8e12,
+       "mix_nobarrier_ceiling_frac": b_launch / (mixr["2"] * 1e-3) / 8e12,
+       "frac_of_mix_ceiling": mixr["1"] / mixr["real"], "frac_of_mix_ceiling_nobarrier": mixr["2"] / mixr["real"],
+       **rates, "first_calls_ms": ms[:3], "last_calls_ms": ms[-3:], "smi_under_load": samples}
+print(json.dumps(rec))
+if os.environ.get("BOX_PROBE_LOG"):
+    with open(os.environ["BOX_PROBE_LOG"], "a") as f:
+        f.write(json.dumps(rec) + "\n")

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd /tmp
 OUT=$R/gpurun_out/prof_setup
 mkdir -p $OUT
-ARGS="--steps 2 --warmup 1 --no-cpu --no-newton --no-configs --no-f32 --no-chain --no-live-traffic"
+ARGS="--steps 2 --warmup 1 --no-cpu --no-newton --no-mix --no-configs --no-f32 --no-chain --no-live-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $R/bench.py $ARGS > $OUT/stats_bench.json 2> $OUT/stats.err
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
