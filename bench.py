@@ -438,17 +438,37 @@ def run_batch_config(local, rank, world, ctx, gdist, rdev, fence, comm):
             "parity_vs_oracle": {"max_rel_err": err, "columns": 1, "tolerance": 1e-5}}
 
 
+def kernel_sources_sha():
+    """sha256 (16 hex digits) over the HIP sources: what a recorded PMC measurement is stamped with, so that a record
+    taken on other kernels is recognised as stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pygsp_amd", "csrc", "*.hip*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def config_traffic(key, dtype):
-    """Measured HBM traffic of a config's recurrence step from the committed PMC passes (profiles/traffic_configs.json,
-    tools/config_traffic.py: separate rocprofv3 --pmc runs of `bench.py --no-headline --only-config <key>`; counters
-    cannot be read from inside this process): traffic per step launch and its ratio to the algorithmic bytes."""
+    """RECORDED fabric traffic of a config's recurrence step: the committed PMC passes of an earlier run
+    (profiles/traffic_configs.json, tools/config_traffic.py: separate rocprofv3 --pmc runs of `bench.py --no-headline
+    --only-config <key>`; counters cannot be read from inside this process).  Not measured by this run, hence the
+    `traffic_recorded*` names beside the live `achieved` / `frac`, the stamp of the run they come from, and
+    `traffic_recorded_stale` when the HIP sources have changed since; `traffic` itself stays null.
+    The x2 on FETCH_SIZE was calibrated on gathers of unique rows in round 6: every row of <= 128 bytes costs one
+    128-byte request, counted as 64 (profiles/r06_gather_calibration.md)."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs.json")))["{}_{}".format(key, dtype)]
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs.json")))
+        t = rec["{}_{}".format(key, dtype)]
     except Exception:
         return {"traffic": None}
-    return {"traffic": t["hbm_bytes_per_step_launch"], "traffic_over_algorithmic": t["traffic_over_algorithmic"],
-            "traffic_TBps_in_the_counted_run": t["hbm_TBps"], "tcc_hit_rate": t["tcc_hit_rate"],
-            "traffic_source": "profiles/traffic_configs.json: " + t["method"]}
+    meta = rec.get("_meta") or {}
+    return {"traffic": None, "traffic_recorded": t["hbm_bytes_per_step_launch"],
+            "traffic_recorded_over_algorithmic": t["traffic_over_algorithmic"],
+            "traffic_recorded_TBps": t["hbm_TBps"], "tcc_hit_rate_recorded": t["tcc_hit_rate"],
+            "traffic_recorded_stamp": meta or None,
+            "traffic_recorded_stale": (meta.get("kernel_sources_sha") != kernel_sources_sha()) if meta else None,
+            "traffic_source": "profiles/traffic_configs.json (recorded, not of this run): " + t["method"]}
 
 
 def reference_cpu_baseline(W, lmax, scale, K, xs):

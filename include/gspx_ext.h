@@ -255,7 +255,10 @@ int gspx_bench_step_mix(gspx_graph* g, double lmax, int M, const double* coeffs,
  * indices, in_flight (2 / 4 / 8 / 16) independent gathers per lane before the first use; no matrix values, no
  * FMA, no panel writes.  blocks == 1: indices uniform over the panel (ER); blocks > 1: the panel is cut into
  * that many row ranges and a gather lands in the range of the row it is issued "from" with probability p_intra
- * (SBM), each XCD walking a contiguous eighth of the stream.  ms: per launch; gbps: row bytes per second. */
+ * (SBM), each XCD walking a contiguous eighth of the stream; blocks == 0: UNIQUE rows - panel_rows a power of two,
+ * n_gathers <= panel_rows, every row fetched at most once per launch in a scattered order (known bytes and no reuse:
+ * the calibration of the fabric counters on gathers, tools/gather_calibration.py).  ms: per launch; gbps: row bytes
+ * per second. */
 int gspx_bench_gather(gspx_ctx* ctx, int64_t panel_rows, int row_bytes, int64_t n_gathers, int in_flight,
                       int blocks, double p_intra, int workgroups_per_cu, int iters, double* ms, double* gbps);
 

@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void k_bench_gather_idx(unsigned* __restrict__
   if (i >= n) return;
   const unsigned long long u = calib_mix(seed ^ ((unsigned long long)i * 0x100000001b3ull));
   unsigned r;
-  if (blocks > 1) {
+  if (blocks == 0) {
+    // UNIQUE rows (counter calibration): an odd multiplier modulo a power of two is a bijection, so the first
+    // panel_rows gathers touch every row exactly once, in a scattered order - known bytes, no reuse anywhere
+    r = (unsigned)(((unsigned long long)i * 2654435761ull) & (unsigned long long)(panel_rows - 1));
+  } else if (blocks > 1) {
     const unsigned bs = panel_rows / (unsigned)blocks;
     const unsigned from = (unsigned)(((unsigned __int128)(unsigned long long)i * panel_rows) / (unsigned long long)n);
     const unsigned blk = min(from / bs, (unsigned)blocks - 1);
@@ -99,9 +103,11 @@ static void launch_bench_gather(int in_flight, dim3 grid, hipStream_t st, const 
 
 extern "C" int gspx_bench_gather(gspx_ctx* ctx, int64_t panel_rows, int row_bytes, int64_t n_gathers, int in_flight,
                                  int blocks, double p_intra, int workgroups_per_cu, int iters, double* ms, double* gbps) {
-  if (!ctx || panel_rows < 1 || panel_rows >= ((int64_t)1 << 32) || n_gathers < 1 || iters < 1 || blocks < 1 ||
+  if (!ctx || panel_rows < 1 || panel_rows >= ((int64_t)1 << 32) || n_gathers < 1 || iters < 1 || blocks < 0 ||
       blocks > panel_rows || !(p_intra >= 0.0 && p_intra <= 1.0))
     return set_err(GSPX_ERR_INVALID, "gspx_bench_gather: bad argument");
+  if (blocks == 0 && ((panel_rows & (panel_rows - 1)) != 0 || n_gathers > panel_rows))
+    return set_err(GSPX_ERR_INVALID, "gspx_bench_gather: unique rows (blocks == 0) need a power-of-two panel_rows >= n_gathers");
   if (!(row_bytes == 64 || row_bytes == 128 || row_bytes == 256 || row_bytes == 512))
     return set_err(GSPX_ERR_INVALID, "gspx_bench_gather: row_bytes must be 64, 128, 256 or 512");
   if (!(in_flight == 2 || in_flight == 4 || in_flight == 8 || in_flight == 16))

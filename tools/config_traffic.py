@@ -2,7 +2,10 @@
 """HBM traffic per recurrence-step launch of BASELINE configs 2 / 3 from the rocprofv3 --pmc passes of
 tools/gpu_prof_configs.sh (gpurun_out/prof_c2, prof_c3): (2 x FETCH_SIZE + WRITE_SIZE) KiB per k_step_* dispatch -
 FETCH_SIZE counts 64 bytes per 128-byte request on gfx950 (MI355X_MICROARCH.md; calibrated on the copy kernel of the
-same run) - per compute dtype, next to the algorithmic bytes of a step.  Writes profiles/traffic_configs.json, which
+same run AND, in round 6, on gathers of unique rows: a row of 64 or 128 bytes costs exactly one 128-byte request -
+TCC_EA0_RDREQ_128B = 1.03 per row, four 32-byte DRAM sectors -, a 256-byte row two: profiles/r06_gather_calibration.md,
+so the x2 holds for the gather-dominated steps of these configs at every row width) - per compute dtype, next to the
+algorithmic bytes of a step.  The figure is FABRIC traffic (L2 misses): Infinity-Cache hits are in it.  Writes profiles/traffic_configs.json, which
 bench.py reads into configs[].roofline (PMC counters cannot be read from inside the benchmarked process).
 usage: tools/config_traffic.py gpurun_out/prof_c2 gpurun_out/prof_c3"""
 import csv
@@ -44,5 +47,17 @@ for d in sys.argv[1:]:
             "hbm_TBps": hbm / (c["avg_step_ms"] * 1e-3) / 1e12,
             "method": "(2*FETCH_SIZE + WRITE_SIZE) KiB per k_step_* dispatch, separate rocprofv3 --pmc passes of "
                       "`bench.py --no-headline --only-config {}` (tools/gpu_prof_configs.sh)".format(c["key"])}
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_sources_sha: the stamp bench.py compares against)
+import datetime
+import socket
+import subprocess
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
+out["_meta"] = {"kernel_sources_sha": bench.kernel_sources_sha(), "git_commit_where_summarised": commit,
+                "date": datetime.datetime.utcnow().strftime("%Y-%m-%d"), "host": socket.gethostname(),
+                "counter_calibration": "profiles/r06_gather_calibration.md"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_configs.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
