@@ -40,6 +40,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# What cannot be shown on the driver's GPU box, said in the line itself (VERDICT r5 "Next 7"): /root/reference does not
+# travel, so `kind` is "port" there; the reference itself was timed beside the port on a builder box in round 5.
+CPU_BASELINE_NOTE = ("kind 'port' = the oracle's restatement of the reference's algorithm (the reference cannot travel to "
+                     "this box); the reference itself, pygsp 0.6.1, measured on a builder MI355X box in round 5: "
+                     "39.4-41.4 M/s on one core, results identical to the port to 0.0 (profiles/r05_real_pygsp_bench.json)")
+REAL_PYGSP_RECORD = ("profiles/r05_real_pygsp_gpu.log: pygsp 0.6.1 and a real MI355X in one process - its own "
+                     "pygsp/tests/test_filters.py 25/25 through plugin.install(pygsp), 86 Filter.filter and 38 "
+                     "compute_frame calls through the seam (builder box; the reference cannot travel to the driver's)")
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0       # measured float4-copy ceiling on this chip (same guide)
 
@@ -101,8 +109,8 @@ def parse():
     return p.parse_args()
 
 
-def smi_sample():
-    """What rocm-smi says about device 0 right now (called from a thread while the recurrence runs): HBM and junction
+def smi_sample(device=0):
+    """What rocm-smi says about a device right now (called from a thread while the recurrence runs): HBM and junction
     temperatures, clocks, package power.  The memory temperature is the one quantity that moved with the step's
     speed over successive runs on one GPU in round 6 (68 C: 0.612 of 8 TB/s ... 72 C: 0.598, the mix ceiling falling
     with it - profiles/r06_box_probe.md).  {} when rocm-smi is missing or fails."""
@@ -111,7 +119,7 @@ def smi_sample():
     import subprocess
     exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     try:
-        txt = subprocess.run([exe, "-d", "0", "--showtemp", "--showclocks", "--showpower"], capture_output=True, text=True,
+        txt = subprocess.run([exe, "-d", str(int(device)), "--showtemp", "--showclocks", "--showpower"], capture_output=True, text=True,
                              timeout=30).stdout
     except Exception:
         return {}
@@ -127,7 +135,7 @@ def smi_sample():
 
 
 # ---- HBM bytes per launch, measured in THIS run ---------------------------------------------------
-def live_traffic(dtype_flag, timeout_s=150):
+def live_traffic(dtype_flag, timeout_s=150, device=0):
     """roofline.traffic measured now, on this box: one call of the headline workload re-run under
     `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes, no trace domain - the
     HBM section of MI355X_MICROARCH.md: FETCH_SIZE costs 3 of the 4 TCC slots and counts half the bytes of
@@ -144,12 +152,21 @@ def live_traffic(dtype_flag, timeout_s=150):
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--dtype", dtype_flag,
              "--no-cpu", "--no-newton", "--no-mix", "--no-e2e", "--no-configs", "--no-live-traffic", "--no-f32",
              "--calibrate-copy"]
+    # a single-process child on ONE GPU (this rank's), whatever launched the parent
+    child_env = {k: v for k, v in os.environ.items()
+                 if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                              "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    child_env["TMPDIR"] = "/tmp"
+    if device:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        ids = vis.split(",") if vis else None
+        child_env["HIP_VISIBLE_DEVICES"] = ids[device] if ids and device < len(ids) else str(device)
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="gspx_pmc_", dir="/tmp")
         try:
             subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child,
-                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           cwd="/tmp", env=child_env, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             step, copy = [], []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -927,6 +944,67 @@ def main_threads(a):
         errs = [r.parity(2) for r in ranks]
         parity = {"max_rel_err": max(errs), "columns": 2, "ranks": n, "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
 
+    # ---- per-device calibration, all GPUs at once like the timed region: copy rate, and the step beside its mix
+    # ceiling (gspx_bench_step_mix: the same launches with the row products removed), real and calibration calls
+    # alternating
+    def calibrate(i, ctx):
+        r = ranks[i]
+        res = {"copy_GBps": None, "mix_launch_ms": None, "frac_of_mix_ceiling": None}
+        try:
+            res["copy_GBps"] = ctx.bench_copy(1 << 30, 5)
+            tiled_i = bool(r.G.tile_stats and r.G.tile_stats.get("enabled"))
+            if not a.no_mix and tiled_i and nsig * elt > 128 and (nsig * elt) % 16 == 0:
+                acc = {"real": [0.0, 0], 1: [0.0, 0]}
+                for rep in range(5):
+                    for which in ("real", 1):
+                        if which == "real":
+                            r.step()
+                            t = ctx.last_timing()
+                        else:
+                            t = r.dev.bench_step_mix(r.c[0], r.bx.ptr, r.by.ptr, nsig, r.lmax, 1)
+                        if rep:
+                            acc[which][0] += t["steps_ms"]
+                            acc[which][1] += t["step_launches"]
+                real_ms, mix_ms = (acc[k_][0] / max(acc[k_][1], 1) for k_ in ("real", 1))
+                res.update(mix_launch_ms=mix_ms, step_launch_ms_beside_mix=real_ms, frac_of_mix_ceiling=mix_ms / real_ms)
+                r.step()  # the real result back in the output buffer
+                ctx.sync()
+        except Exception as e:
+            res["error"] = repr(e)
+        return res
+
+    calib = group.run(calibrate)
+    # ---- HBM traffic of the step (rocprofv3 child passes on the first GPU) and the CPU baseline, as at N = 1 ----
+    traffic = traffic_source = None
+    default_workload = (N, nsig, K, a.knn, a.tiles) == (1000000, 64, 30, 8, "auto")
+    if default_workload and not a.no_live_traffic:
+        group.ctxs[0].sync()
+        live = live_traffic(a.dtype, device=devices[0])
+        if live is not None:
+            traffic = live[0]
+            traffic_source = {"how": "measured in this run on GPU {}: the N = 1 call under rocprofv3 --pmc FETCH_SIZE and "
+                                     "--pmc WRITE_SIZE (two child runs), (2*FETCH_SIZE + WRITE_SIZE) per k_step_tile "
+                                     "launch".format(devices[0]), "launches": live[1], "calibration": live[2]}
+    cpu_baseline = None
+    if not a.no_cpu:
+        from oracle import cheby_oracle as orc
+        r0_ = ranks[0]
+        cols = min(a.cpu_cols, nsig)
+        Lh = r0_.G.L.astype(np.float64)
+        xs = r0_.x[:, :cols].astype(np.float64)
+        orc.cheby_op(Lh, r0_.lmax, r0_.c[0], xs[:, :1])
+        tc = time.perf_counter()
+        ref = orc.cheby_op(Lh, r0_.lmax, r0_.c[0], xs)
+        t_cpu = time.perf_counter() - tc
+        y0 = r0_.by.download(r0_.x.shape, dtype)[:, :cols]
+        cpu_baseline = {"value": N * cols * K / t_cpu, "unit": "vertex*signal*order/s", "cores": 1, "kind": "port",
+                        "sample": "oracle port of the reference (scipy csr_matvecs, single-threaded like the reference): "
+                                  "the first GPU's graph / coefficients, first {} of {} signal columns, order {}, float64 "
+                                  "({} host cores present), {:.1f} s".format(cols, nsig, K, os.cpu_count(), t_cpu),
+                        "note": CPU_BASELINE_NOTE,
+                        "parity_of_the_sample": float(np.max(np.abs(y0 - ref)) / np.max(np.abs(ref)))}
+        del Lh, xs, ref, y0
+
     from pygsp_amd import engine
     seen = engine.comm_info()  # after the gather: the device set ncclCommInitAll built, as RCCL reports it
     r0 = ranks[0]
@@ -949,20 +1027,33 @@ def main_threads(a):
             "parallelism": "graph-parallel x{} (independent graphs, no data-path collective; one final gather)".format(n),
             "evaluation": "recurrence", "engine_options": a.opt, "gather_tiles": r0.G.tile_stats,
             "gather_impl": gather["gather_impl"] if gather else None, "rccl_version": seen["rccl_version"],
-            "rccl_nranks_seen": seen["nranks"], "distinct_devices": group.n_distinct},
+            "rccl_nranks_seen": seen["nranks"], "distinct_devices": group.n_distinct,
+            "real_pygsp_on_device": REAL_PYGSP_RECORD},
         "launcher": "one process, one driver thread + one libgspx context per GPU (no torch)",
         "devices": devices,
         "driver_thread_cores": [len(p) if p else None for p in group.pinned],  # NUMA pinning (multi.pin_thread_near)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_over_algorithmic": (traffic / b_alg_launch) if traffic else None,
                      "kernel": "k_step_tile" if tiled else "k_step_panel / k_step_lds",
                      "algorithmic_bytes_per_launch": b_alg_launch, "avg_launch_ms": avg_launch_ms,
-                     "launches_timed": launches, "note": "average over the launches of all GPUs"},
+                     "launches_timed": launches, "note": "average over the launches of all GPUs",
+                     # the same bytes over the whole job's wall time per step (launch gaps, host, the slowest GPU)
+                     "frac_whole_call": n * K * b_alg_launch / (elapsed / a.steps) / 1e9 / (n * HBM_PEAK_GBS),
+                     "copy_GBps_this_run": calib[0].get("copy_GBps"),
+                     "copy_GBps_per_device": [c_.get("copy_GBps") for c_ in calib],
+                     "frac_of_mix_ceiling": calib[0].get("frac_of_mix_ceiling"),
+                     "frac_of_mix_ceiling_per_device": [c_.get("frac_of_mix_ceiling") for c_ in calib],
+                     "mix_launch_ms_per_device": [c_.get("mix_launch_ms") for c_ in calib],
+                     "parity_max_rel_err": parity["max_rel_err"] if parity else None,
+                     "parity_tolerance": parity["tolerance"] if parity else None},
         "per_device": [{"device": devices[i], "ms_per_step": (spans[i][1] - spans[i][0]) / a.steps * 1e3,
                         "device_ms_per_step": r.dev_ms / a.steps, "avg_launch_ms": r.steps_ms / max(r.launches, 1),
-                        "frac": b_alg_launch / (r.steps_ms / max(r.launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        "frac": b_alg_launch / (r.steps_ms / max(r.launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        **calib[i]}
                        for i, r in enumerate(ranks)],
         "parity_vs_oracle": parity,
+        "cpu_baseline": cpu_baseline,
     }
     if gather:
         out.update(gather)
@@ -1075,6 +1166,12 @@ def main():
 
     step = step_newton if a.evaluation == "newton" else step_recurrence
 
+    def download_y():  # this rank's output block as a host array (N, nsig)
+        if torch is not None:
+            torch.cuda.synchronize(tdev)
+            return ty.cpu().numpy()[0]
+        return by.download((1, N, nsig), dtype)[0]
+
     def fence():
         ctx.sync()
         if torch is not None:
@@ -1120,20 +1217,20 @@ def main():
     newton = y_newton = None
     if a.evaluation == "recurrence" and not a.no_newton:
         newton = time_newton()
-        if torch is None and not a.no_cpu:  # its result, for the parity leg below (the recurrence overwrites y next)
-            y_newton = by.download((1, N, nsig), dtype)[0][:, :min(a.cpu_cols, nsig)].copy()
+        if rank == 0 and not a.no_cpu:  # its result, for the parity leg below (the recurrence overwrites y next)
+            y_newton = download_y()[:, :min(a.cpu_cols, nsig)].copy()
     # ---- the mix ceiling of the recurrence step on THIS box (VERDICT r5 "Next 1"): the same call with the row
     # products removed from every launch (gspx_bench_step_mix: same grid, LDS-DMA tile loads, T_{k-2} / accumulator
     # loads, entry stream, stores, flushes and cache bits), mode 1 with the pass barriers, mode 2 without; real calls
     # alternate with the calibration calls so that all three see the same minutes of the same box
     mix = None
     tiled_now = bool(G.tile_stats and G.tile_stats.get("enabled"))
-    if (a.evaluation == "recurrence" and not a.no_mix and world == 1 and tiled_now and nsig * elt > 128
+    if (a.evaluation == "recurrence" and not a.no_mix and tiled_now and nsig * elt > 128
             and (nsig * elt) % 16 == 0):
         try:
             import threading
             smi = {}
-            th = threading.Thread(target=lambda: smi.update(smi_sample()), daemon=True)
+            th = threading.Thread(target=lambda: smi.update(smi_sample(local)), daemon=True)
             th.start()  # rocm-smi reads its sensors while the loop below keeps the GPU at the recurrence
             acc = {"real": [0.0, 0], 1: [0.0, 0], 2: [0.0, 0]}
             rep, t_mix0 = 0, time.perf_counter()
@@ -1278,6 +1375,18 @@ def main():
         copy_now = ctx.bench_copy(1 << 30, 5)
     except Exception:
         pass
+    # N > 1: the slowest and the fastest GPU of the job, for the copy rate, the step and its mix ceiling (every rank
+    # measures its own; rank 0's own values are the plain keys)
+    spread = None
+    if torch is not None:
+        def lo_hi(v):
+            v = float(v or 0.0)
+            return [-gdist.max_over_ranks(-v, rdev), gdist.max_over_ranks(v, rdev)]
+        mix_ok = mix is not None and "error" not in mix
+        spread = {"copy_GBps_min_max_over_ranks": lo_hi(copy_now),
+                  "avg_launch_ms_min_max_over_ranks": lo_hi(steps_ms / max(launches, 1)),
+                  "frac_of_mix_ceiling_min_max_over_ranks": lo_hi(mix[1] / mix["real"] if mix_ok else 0.0),
+                  "mix_launch_ms_min_max_over_ranks": lo_hi(mix[1] if mix_ok else 0.0)}
 
     # ---- roofline of the dominant kernel (the recurrence step) ---------------------------------
     nnz_l = dev.nnz_l
@@ -1293,9 +1402,11 @@ def main():
     default_workload = (N, nsig, K, a.knn, a.evaluation, a.tiles) == (1000000, 64, 30, 8, "recurrence", "auto")
     traffic_source = None
     live = None
-    if default_workload and rank == 0 and world == 1 and not a.no_live_traffic:
+    if default_workload and rank == 0 and not a.no_live_traffic:
+        # (N > 1: the child pass runs on this rank's GPU while the other ranks wait at the next collective - the
+        # timed region and the gather are over)
         ctx.sync()
-        live = live_traffic(a.dtype)
+        live = live_traffic(a.dtype, device=local)
     if live is not None:
         traffic = live[0]
         traffic_source = {"how": "measured in this run: the same call under rocprofv3 --pmc FETCH_SIZE and --pmc "
@@ -1341,6 +1452,7 @@ def main():
                 # itself reports must equal n_gpus)
                 "gather_impl": gather_impl, "rccl_version": (comm_seen or engine.comm_info())["rccl_version"],
                 "rccl_nranks_seen": comm_seen["nranks"] if comm_seen else 0, "launcher_world_size": world,
+                "real_pygsp_on_device": REAL_PYGSP_RECORD,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1433,7 +1545,7 @@ def main():
         fence()
 
     # ---- CPU baseline beside it (rank 0, N=1 only): the oracle on a bounded column sample --------
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if rank == 0 and not a.no_cpu:
         from oracle import cheby_oracle as orc
         cols = min(a.cpu_cols, nsig)
         L = G.L.astype(np.float64)
@@ -1442,7 +1554,7 @@ def main():
         tc = time.perf_counter()
         ref = orc.cheby_op(L, lmax, c[0], xs)
         t_cpu = time.perf_counter() - tc
-        y = (by.download((1, N, nsig), dtype))[0]
+        y = download_y()
         err = float(np.max(np.abs(y[:, :cols] - ref)) / np.max(np.abs(ref)))
         out["cpu_baseline"] = {
             "value": N * cols * K / t_cpu, "unit": "vertex*signal*order/s", "cores": 1,
@@ -1450,6 +1562,7 @@ def main():
             "sample": "oracle port of the reference (scipy csr_matvecs, single-threaded like the reference): same "
                       "graph/coefficients, first {} of {} signal columns, order {}, float64 ({} host cores "
                       "present), {:.1f} s".format(cols, nsig, K, os.cpu_count(), t_cpu),
+            "note": CPU_BASELINE_NOTE,
             "multi_core": cpu_all,
         }
         # the reference ITSELF beside it whenever a real pygsp can be imported on this box (installed,
@@ -1529,6 +1642,8 @@ def main():
             rf["smi_under_load"] = mix.get("smi") or None
         elif mix is not None:
             rf["mix_error"] = mix["error"]
+        if spread is not None:
+            rf.update(spread)
         cfgs = out.get("configs")
         if isinstance(cfgs, list):
             rf["configs_frac"] = {"{}_{}".format(c_.get("key", i), c_.get("dtype", "")): (c_.get("roofline") or {}).get("frac")

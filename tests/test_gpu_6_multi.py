@@ -181,6 +181,35 @@ def test_two_ranks_on_this_gpu_through_bench():
     b5 = out["batch_config4"]  # BASELINE configs[4]: 8 graphs sharded 4 + 4
     assert b5["n_gpus"] == 2 and b5["n_graphs"] == 8 and b5["value"] > 0 and "4/4" in b5["workload"]
     assert b5["parity_vs_oracle"]["max_rel_err"] < 1e-11
+    # VERDICT r5 "Next 5": the N > 1 line is as checkable as the N = 1 line - the same keys
+    check_multi_line_keys(out, wide=False)
+
+
+def check_multi_line_keys(out, wide):
+    """What BENCH_rNN's `parsed` holds at N = 1 is in the N > 1 line too: whole-call fraction, traffic (null away from
+    the headline workload), this run's copy rate, the mix ceiling (wide panels), a CPU baseline with its cores."""
+    rf = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_whole_call", "copy_GBps_this_run",
+                "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_timed", "parity_max_rel_err"):
+        assert key in rf, key
+    assert 0 < rf["frac_whole_call"] <= rf["frac"] * 1.05 and rf["copy_GBps_this_run"] > 1000
+    if wide:
+        assert 0.5 < rf["frac_of_mix_ceiling"] < 1.3
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "reference itself" in cb["note"]
+    assert "real_pygsp_on_device" in out["config"]
+
+
+def test_multi_gpu_lines_carry_the_single_gpu_keys():
+    """The same check on a wide panel (64 fp64 signals: the wide LDS-staged step, so the mix ceiling is measured) for
+    the launcher-free form, per device."""
+    res = _run_bench(["--gpus", "2", "--devices", "0,0", "--steps", "2", "--warmup", "1", "--vertices", "100000",
+                      "--nsig", "64", "--no-configs", "--cpu-cols", "4"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    check_multi_line_keys(out, wide=True)
+    assert len(out["roofline"]["copy_GBps_per_device"]) == 2 and len(out["roofline"]["frac_of_mix_ceiling_per_device"]) == 2
+    assert all(0.5 < p["frac_of_mix_ceiling"] < 1.3 and p["copy_GBps"] > 1000 for p in out["per_device"])
 
 
 # ---- one process, several contexts / GPUs: bench.py --gpus N without a launcher, signal-parallel filtering ----
@@ -218,6 +247,7 @@ def test_bench_threads_two_contexts_on_this_gpu():
     sp = out["signal_parallel"]  # one graph, its 16 signals split 8 / 8 over the two contexts
     assert sp["n_gpus"] == 2 and "8/8" in sp["workload"] and sp["value"] > 0 and sp["gather_ms"] > 0
     assert sp["parity_vs_oracle"]["max_rel_err"] < 1e-11
+    check_multi_line_keys(out, wide=False)
 
 
 def test_bench_threads_eight_contexts_on_this_gpu():
