@@ -442,7 +442,9 @@ class Graph:
                 candidates.append(on_device[3])  # (NaN with isolated vertices: never the minimum, as in the reference)
                 return float(min(candidates))
         W, deg = self._symmetric_w(), np.asarray(self.dw, dtype=np.float64)
-        candidates = [self.n_vertices * W.max(), 2 * deg.max()]
+        # (the first candidate on W AS STORED, graph.py:941 - for a directed graph max W_ij, not max (W + W.T) / 2,
+        # which would give a smaller bound than the reference's where this candidate is the minimum: ADVICE r5)
+        candidates = [self.n_vertices * self.W.max(), 2 * deg.max()]
         if self.n_edges:
             ends = self.W.tocoo()  # max over edges: both triangles give the same maximum
             candidates.append((deg[ends.row] + deg[ends.col]).max())

@@ -216,6 +216,34 @@ def ops_directed():
     np.savez_compressed(os.path.join(OUT, "ops_directed.npz"), **out)
 
 
+def lmax_directed():
+    """Graph._get_upper_bound (graph.py:933-960) on DIRECTED graphs: the 60-vertex directed fixture of ops_directed()
+    and a small dense directed graph on which the FIRST candidate, N * max(W) of the unsymmetrised W (graph.py:941), is
+    the minimum of the four - the case where symmetrising first would return a smaller bound than the reference."""
+    from scipy import sparse
+    out = {}
+    A = sparse.random(60, 60, 0.08, random_state=5, format="lil")
+    A.setdiag(0)
+    A[3, 3], A[17, 17] = 0.8, 1.7
+    Wd = sparse.csr_matrix(A)
+    Wd.eliminate_zeros()
+    rng = np.random.default_rng(3)
+    D = rng.uniform(0.9, 1.0, (6, 6))
+    np.fill_diagonal(D, 0.0)
+    D[0, 1], D[1, 0] = 1.0, 0.2  # the largest entry has a small mirror: max(W) > max((W + W.T) / 2)
+    Wdense = sparse.csr_matrix(D)
+    for name, W in (("sparse60", Wd), ("dense6", Wdense)):
+        G = graphs.Graph(W)
+        assert G.is_directed()
+        out.update(csr_parts(W, "W_" + name))
+        out["bound_" + name] = np.float64(G._get_upper_bound())
+        G.estimate_lmax("bounds")
+        out["lmax_bounds_" + name] = np.float64(G.lmax)
+    G = graphs.Graph(Wdense)
+    assert out["bound_dense6"] == G.n_vertices * np.max(G.W)  # the first candidate is the minimum here
+    np.savez_compressed(os.path.join(OUT, "lmax_directed.npz"), **out)
+
+
 def knn():
     """NNGraph (nngraph.py:113-297) on small point clouds, Sensor variants."""
     out = {}
@@ -315,6 +343,7 @@ if __name__ == "__main__":
     laplacians4()
     ops_sensor123()
     ops_directed()
+    lmax_directed()
     knn()
     knn_highdim()
     for f in sorted(os.listdir(OUT)):

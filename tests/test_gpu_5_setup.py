@@ -324,6 +324,23 @@ def test_directed_adjacency_is_symmetrised_on_the_device(ctx, golden_lap4, lap_t
     assert rel_err(y, ref) < (1e-5 if wdtype == np.float32 else 1e-11)
 
 
+def test_directed_lmax_bounds_equal_the_reference(ctx):
+    """Graph._get_upper_bound of a DIRECTED graph takes its first candidate from W as stored (graph.py:941),
+    not from (W + W.T) / 2 - on a small dense directed graph that candidate is the minimum of the four, and
+    symmetrising first returned a smaller bound than the reference.  Goldens generated from the real reference
+    (tests/golden/gen_golden.py lmax_directed)."""
+    from conftest import load_golden
+    g = load_golden("lmax_directed.npz")
+    for name in ("sparse60", "dense6"):
+        G = graphs.Graph(csr_from(g, "W_" + name))
+        assert G.is_directed()
+        assert abs(G._get_upper_bound() - float(g["bound_" + name])) <= 1e-14 * float(g["bound_" + name])
+        G.estimate_lmax("bounds")
+        assert abs(G.lmax - float(g["lmax_bounds_" + name])) <= 1e-14 * float(g["lmax_bounds_" + name])
+    Wd = csr_from(g, "W_dense6")
+    assert float(g["bound_dense6"]) == 6 * Wd.max() > 6 * ((Wd + Wd.T) / 2).max()
+
+
 def test_directed_graph_of_a_million_vertices_in_one_device_call(ctx):
     """A directed 1M-vertex graph (8 out-neighbours per vertex, a third of them reciprocated): set up in one device
     call, L and dw equal the oracle's on (W + W.T) / 2."""
