@@ -124,6 +124,16 @@ def smi_sample(device=0):
     except Exception:
         return {}
     out = {}
+    try:  # which card this is (the population of cards differs: memory vendor, VBIOS; profiles/r06_box_probe.md)
+        ident = subprocess.run([exe, "-d", str(int(device)), "--showuniqueid", "--showmemvendor", "--showvbios"],
+                               capture_output=True, text=True, timeout=30).stdout
+        for key, pat in (("gpu_unique_id", r"Unique ID:\s*(\S+)"), ("memory_vendor", r"memory vendor:\s*(\S+)"),
+                         ("vbios", r"VBIOS version:\s*(\S+)")):
+            m = re.search(pat, ident)
+            if m:
+                out[key] = m.group(1)
+    except Exception:
+        pass
     for key, pat in (("hbm_temperature_C", r"Sensor memory\) \(C\):\s*([0-9.]+)"),
                      ("junction_temperature_C", r"Sensor junction\) \(C\):\s*([0-9.]+)"),
                      ("sclk_MHz", r"sclk clock level:[^(]*\((\d+)Mhz\)"), ("mclk_MHz", r"mclk clock level:[^(]*\((\d+)Mhz\)"),

@@ -235,6 +235,22 @@ int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);
 /* Calibration: read-only GB/s of a `bytes`-sized buffer streamed `passes` times in one launch. */
 int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
 
+/* Placement tuning of a context's streamed workspaces for single-filter calls of Nsig signals on graph g: `candidates`
+ * (1-32) fresh physical backings are drawn - the previous ones held meanwhile, so every draw gets other pages -, a short
+ * filter call on scratch panels times each, the fastest stays in the context and the others are released.  Why: on
+ * MI355X the recurrence on panels beyond the Infinity Cache runs 0.54-0.60 of 8 TB/s depending on which physical pages
+ * back its workspaces, and a fresh process draws the same pages every time (profiles/r06_placement.md).  out[i]: ms per
+ * recurrence launch with candidate i (0: the backing the context already had, if any); out[candidates]: index kept.
+ * Costs candidates x (one workspace allocation + ~5 ms of kernels); the graph's factor values for its last lmax are
+ * reused.  Results of later calls are bit-identical whichever backing was kept. */
+int gspx_ctx_tune_placement(gspx_graph* g, int64_t Nsig, int candidates, double* out);
+
+/* Calibration: total GB/s of n_read (0-4) read streams and n_write (0-2) write streams of bytes_per_stream each, walked
+ * together by workgroups_per_cu persistent workgroups per CU, 16 bytes per lane (nt: bit 0 non-temporal loads, bit 1
+ * non-temporal stores) - what the memory system delivers to a read : write ratio with nothing else in the way. */
+int gspx_bench_streams(gspx_ctx* ctx, int64_t bytes_per_stream, int n_read, int n_write, int nt, int workgroups_per_cu,
+                       int iters, double* gbps);
+
 /* Calibration, the MIX CEILING of the LDS-staged recurrence step: exactly the call
  * gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, NULL) would make - the same plan, the
  * same M-1 k_step_tile launches on the same grid over the same buffers, the same LDS-DMA tile loads of the same row

@@ -88,7 +88,92 @@ __global__ __launch_bounds__(256) void k_bench_gather(const uint4* __restrict__ 
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = acc.x;  // keeps the loads alive
 }
 
+// Stream mix (round 6): NR read streams and NW write streams of `n4` 16-byte pieces each, walked together by a
+// persistent grid - what the memory system delivers to a given read : write ratio with nothing else in the way.  The
+// recurrence step is such a mix (T_{k-1} tiles, T_{k-2}, accumulator and entries in; T_k and the accumulator out: 3.6 : 1
+// on a plain step, 2.3 : 1 on a flush step), and boxes that agree on a read-only stream and on a 1 : 1 copy differ by
+// 10 % on it (profiles/r06_box_probe.md).  nt: bit 0 non-temporal loads, bit 1 non-temporal stores.
+template <int NR, int NW>
+__global__ __launch_bounds__(256) void k_bench_streams(const u32x4* __restrict__ rd, u32x4* __restrict__ wr, size_t n4,
+                                                       int nt, unsigned* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    u32x4 v[NR > 0 ? NR : 1];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const u32x4* src = rd + (size_t)r * n4 + i;
+      v[r] = (nt & 1) ? __builtin_nontemporal_load(src) : *src;
+    }
+    u32x4 o = {(unsigned)i, 1u, 2u, 3u};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      o.x ^= v[r].x;
+      o.y += v[r].y;
+      o.z ^= v[r].z;
+      o.w += v[r].w;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      u32x4* dst = wr + (size_t)w * n4 + i;
+      if (nt & 2) __builtin_nontemporal_store(o, dst);
+      else *dst = o;
+    }
+    if (NW == 0) {
+      acc.x ^= o.x;
+      acc.y += o.y;
+    }
+  }
+  if (NW == 0 && (acc.x ^ acc.y) == 0x9e3779b9u) sink[0] = acc.x;  // keeps the loads alive
+}
+
 }  // namespace gspx
+
+template <int NR>
+static void launch_bench_streams(int nw, dim3 grid, hipStream_t st, const gspx::u32x4* rd, gspx::u32x4* wr, size_t n4, int nt,
+                                 unsigned* sink) {
+  switch (nw) {
+    case 0: hipLaunchKernelGGL((gspx::k_bench_streams<NR, 0>), grid, dim3(256), 0, st, rd, wr, n4, nt, sink); break;
+    case 1: hipLaunchKernelGGL((gspx::k_bench_streams<NR, 1>), grid, dim3(256), 0, st, rd, wr, n4, nt, sink); break;
+    default: hipLaunchKernelGGL((gspx::k_bench_streams<NR, 2>), grid, dim3(256), 0, st, rd, wr, n4, nt, sink); break;
+  }
+}
+
+extern "C" int gspx_bench_streams(gspx_ctx* ctx, int64_t bytes_per_stream, int n_read, int n_write, int nt,
+                                  int workgroups_per_cu, int iters, double* gbps) {
+  if (!ctx || !gbps || bytes_per_stream < 4096 || n_read < 0 || n_read > 4 || n_write < 0 || n_write > 2 ||
+      n_read + n_write < 1 || iters < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 16 || nt < 0 || nt > 3)
+    return set_err(GSPX_ERR_INVALID, "gspx_bench_streams: bad argument (0-4 read streams, 0-2 write streams)");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t n4 = (size_t)bytes_per_stream / 16;
+  DevMem rd, wr, sink;
+  CHK(rd.alloc(std::max<size_t>(n4 * 16 * (size_t)n_read, 64)));
+  CHK(wr.alloc(std::max<size_t>(n4 * 16 * (size_t)n_write, 64)));
+  CHK(sink.alloc(64));
+  if (n_read)
+    hipLaunchKernelGGL((k_fill<float>), dim3(4096), dim3(256), 0, st, rd.as<float>(), n4 * 4 * (size_t)n_read, 1.0f);
+  const dim3 grid((unsigned)(ctx->cu_count * workgroups_per_cu));
+  auto launch = [&]() {
+    switch (n_read) {
+      case 0: launch_bench_streams<0>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
+      case 1: launch_bench_streams<1>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
+      case 2: launch_bench_streams<2>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
+      case 3: launch_bench_streams<3>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
+      default: launch_bench_streams<4>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
+    }
+  };
+  launch();  // warm-up
+  HIPCHK(hipEventRecord(ctx->ev[2], st));
+  for (int i = 0; i < iters; ++i) launch();
+  HIPCHK(hipEventRecord(ctx->ev[3], st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  float t = 0;
+  HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3]));
+  *gbps = (double)n4 * 16.0 * (n_read + n_write) * iters / ((double)t * 1e-3) / 1e9;
+  return GSPX_OK;
+}
 
 template <int LPR>
 static void launch_bench_gather(int in_flight, dim3 grid, hipStream_t st, const uint4* panel, const unsigned* idx,

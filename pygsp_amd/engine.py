@@ -145,6 +145,13 @@ class Context:
         _capi.check(_capi.load().gspx_bench_read(self._h, int(nbytes), int(passes), ctypes.byref(v)))
         return v.value
 
+    def bench_streams(self, bytes_per_stream, n_read, n_write, nt=0, workgroups_per_cu=8, iters=5):
+        """Total GB/s of n_read read streams + n_write write streams walked together (gspx_bench_streams)."""
+        v = ctypes.c_double(0)
+        _capi.check(_capi.load().gspx_bench_streams(self._h, int(bytes_per_stream), int(n_read), int(n_write), int(nt),
+                                                    int(workgroups_per_cu), int(iters), ctypes.byref(v)))
+        return v.value
+
     def bench_gather(self, panel_rows, row_bytes, n_gathers, in_flight=8, blocks=1, p_intra=0.0, workgroups_per_cu=8,
                      iters=5):
         """Rate of random row gathers on this device (gspx_bench_gather): (ms per launch, GB/s of row bytes)."""
@@ -874,6 +881,15 @@ class DeviceGraph:
             ctypes.c_void_p(y_ptr), mode, ctypes.byref(ms))
         return ms.value
 
+
+    def tune_placement(self, nsig, candidates=6):
+        """Draw `candidates` physical backings for the context's streamed workspaces and keep the one on which a short
+        single-filter call of `nsig` signals on this graph runs fastest (gspx_ctx_tune_placement; on MI355X the same
+        call runs 0.54-0.60 of 8 TB/s depending on which pages back the work panels).  Returns
+        {"launch_ms": [per candidate], "kept": index}.  Later results are bit-identical whichever backing was kept."""
+        out = np.zeros(int(candidates) + 1)
+        self.ctx.call(_capi.load().gspx_ctx_tune_placement, self._h, int(nsig), int(candidates), _capi.ptr(out))
+        return {"launch_ms": [float(v) for v in out[:-1]], "kept": int(out[-1])}
 
     def bench_step_mix(self, coeffs, x_ptr, y_ptr, nsig, lmax, mode=1):
         """CALIBRATION, not a filter: the launches cheby_filter_dev(coeffs, ...) would make with the row products

@@ -12,6 +12,7 @@ import pytest
 
 from oracle import cheby_oracle as orc
 from pygsp_amd import engine, graphs
+from conftest import rel_err
 from gpu_helpers import upper_lmax
 
 pytestmark = pytest.mark.gpu
@@ -215,5 +216,42 @@ def test_staged_copies_of_large_buffers():
             rates[mode] = (x.nbytes / (t1 - t0) / 1e9, x.nbytes / (t2 - t1) / 1e9)
             buf.free()
         print("GB/s (upload, download): staged {} plain {}".format(rates[2], rates[0]))
+    finally:
+        ctx.close()
+
+
+def test_placement_tuning_keeps_the_fastest_backing_and_the_same_bits():
+    """gspx_ctx_tune_placement (round 6): several physical backings of the streamed workspaces are drawn, timed with a
+    short call and the fastest kept.  The result of a filter call is bit-identical before and after (only WHERE the
+    work panels lie changes), the reported candidate kept is the fastest, the context stays usable (growth, other
+    widths, another tuning), and bad arguments are refused."""
+    ctx = engine.Context(0)
+    try:
+        G = graphs.Sensor(200000, k=8, seed=5, ctx=ctx)
+        G.estimate_lmax("bounds")
+        dev = G.device_graph()
+        x = np.random.default_rng(3).standard_normal((G.N, 64))
+        c = orc.compute_cheby_coeff(orc.heat_kernel(20, G.lmax), G.lmax, 30)
+        y0, _ = dev.cheby_filter(c, x, G.lmax)
+        rep = dev.tune_placement(64, candidates=5)
+        assert len(rep["launch_ms"]) == 5 and all(v > 0 for v in rep["launch_ms"])
+        assert rep["launch_ms"][rep["kept"]] == min(rep["launch_ms"])
+        y1, _ = dev.cheby_filter(c, x, G.lmax)
+        assert np.array_equal(y0, y1)
+        ref = orc.cheby_op(orc.laplacian(G.W), G.lmax, c, x[:, :2])
+        assert rel_err(y1[0][:, :2], ref) < 1e-11
+        # wider than tuned for (the workspaces grow), narrower, a bank, then tuning again for another width
+        x2 = np.random.default_rng(4).standard_normal((G.N, 96))
+        y2, _ = dev.cheby_filter(c, x2, G.lmax)
+        assert rel_err(y2[0][:, :2], orc.cheby_op(orc.laplacian(G.W), G.lmax, c, x2[:, :2])) < 1e-11
+        rep2 = dev.tune_placement(32, candidates=2)
+        assert rep2["kept"] in (0, 1)
+        y3, _ = dev.cheby_filter(c, x, G.lmax)
+        assert np.array_equal(y0, y3)
+        with pytest.raises(ValueError):
+            dev.tune_placement(64, candidates=0)
+        with pytest.raises(ValueError):
+            dev.tune_placement(0, candidates=2)
+        dev.destroy()
     finally:
         ctx.close()

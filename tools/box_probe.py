@@ -64,6 +64,21 @@ for rep in range(9):
 mixr = {str(k): float(np.median(v)) for k, v in acc.items()}
 b_launch = b_alg / 30
 rates = {"read_GBps": ctx.bench_read(1 << 30, 5), "copy_GBps": ctx.bench_copy(1 << 30, 5)}
+# what the memory system gives plain stream mixes: reads : writes, 256 MB per stream (gspx_bench_streams)
+streams = {}
+for nr, nw, nt in ((1, 0, 0), (3, 0, 0), (4, 0, 0), (0, 1, 0), (1, 1, 0), (2, 1, 0), (3, 1, 0), (4, 1, 0), (3, 2, 0),
+                   (4, 2, 0), (3, 1, 1), (3, 1, 2), (3, 1, 3)):
+    for wg in (8, 2):
+        streams["r{}w{}nt{}wg{}".format(nr, nw, nt, wg)] = round(ctx.bench_streams(256 << 20, nr, nw, nt, wg, 4), 1)
+rates["streams_GBps"] = streams
+try:
+    uid = subprocess.run(["rocm-smi", "--showuniqueid", "--showmemvendor", "--showvbios", "--showproductname"],
+                         capture_output=True, text=True).stdout
+    for key, tag in (("gpu_unique_id", "Unique ID"), ("memory_vendor", "memory vendor"), ("vbios", "VBIOS version"),
+                     ("node_id", "Node ID")):
+        rates[key] = [ln.split(":")[-1].strip() for ln in uid.splitlines() if ln.startswith("GPU[") and tag in ln][:1]
+except Exception:
+    pass
 rec = {"ms_per_call": med, "frac_whole_call": b_alg / (med * 1e-3) / 8e12, "calls": len(ms),
        "step_launch_ms": mixr["real"], "mix_launch_ms": mixr["1"], "mix_nobarrier_launch_ms": mixr["2"],
        "frac": b_launch / (mixr["real"] * 1e-3) / 8e12, "mix_ceiling_frac": b_launch / (mixr["1"] * 1e-3) / 8e12,
