@@ -78,6 +78,9 @@ def parse():
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
     p.add_argument("--no-mix", action="store_true", help="skip the mix-ceiling calibration (gspx_bench_step_mix)")
+    p.add_argument("--tune-candidates", type=int, default=6,
+                   help="set-up: physical backings of the streamed workspaces drawn by DeviceGraph.tune_placement, the "
+                        "fastest kept (0: none; profiles/r06_placement.md)")
     p.add_argument("--no-e2e", action="store_true", help="skip the numpy-in/numpy-out leg (profiling passes)")
     p.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     p.add_argument("--no-f32", action="store_true", help="skip the float32 run of the headline workload")
@@ -161,7 +164,7 @@ def live_traffic(dtype_flag, timeout_s=150, device=0):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--dtype", dtype_flag,
              "--no-cpu", "--no-newton", "--no-mix", "--no-e2e", "--no-configs", "--no-live-traffic", "--no-f32",
-             "--calibrate-copy"]
+             "--calibrate-copy", "--tune-candidates", "0"]
     # a single-process child on ONE GPU (this rank's), whatever launched the parent
     child_env = {k: v for k, v in os.environ.items()
                  if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
@@ -702,6 +705,32 @@ class RankWork:
         self.nsig = nsig
         self.dev_ms = self.steps_ms = 0.0
         self.launches = 0
+        self.tuning = None
+
+    def tune(self, candidates, y_ptr=None):
+        """Set-up, outside every timed region: draw `candidates` physical backings for the context's streamed
+        workspaces, run this rank's own call on each and keep the fastest (DeviceGraph.tune_placement;
+        profiles/r06_placement.md).  No-op for the plain kernels' graphs and for candidates < 2."""
+        tiled = bool(self.G.tile_stats and self.G.tile_stats.get("enabled"))
+        if candidates < 2 or not tiled or (y_ptr is None and self.by is None):
+            return None
+        t0 = time.perf_counter()
+        try:
+            rep = self.dev.tune_placement(self.c[0], self.bx.ptr, y_ptr or self.by.ptr, self.nsig, self.lmax, candidates)
+        except Exception as e:  # a tuning step: never a reason to lose the measurement
+            self.tuning = {"error": repr(e)}
+            return self.tuning
+        N, elt = self.x.shape[0], self.x.dtype.itemsize
+        U = N * self.nsig * elt
+        K = self.c.shape[1] - 1
+        b_launch = self.dev.nnz_l * (elt + 4) + 4 * (N + 1) + 3 * U + U / K
+        self.tuning = {"seconds": time.perf_counter() - t0, "candidates": candidates, "kept": rep["kept"],
+                       "candidates_launch_ms": rep["launch_ms"],
+                       "candidates_frac": [b_launch / (v * 1e-3) / 1e9 / HBM_PEAK_GBS for v in rep["launch_ms"]],
+                       "what": "DeviceGraph.tune_placement: physical backings of the streamed workspaces drawn in the "
+                               "set-up, this call run on each, the fastest kept (bit-identical results; candidate 0 = "
+                               "the first draw, what a run without tuning would have used)"}
+        return self.tuning
 
     def step(self, y_ptr=None):
         return self.dev.cheby_filter_dev(self.c, self.bx.ptr, y_ptr or self.by.ptr, self.nsig, self.lmax)
@@ -915,6 +944,7 @@ def main_threads(a):
             k, v = kv.split("=")
             ctx.set_option(k, int(v))
         ranks[i] = RankWork(a, ctx, i, dtype)
+        ranks[i].tune(a.tune_candidates)
         for _ in range(a.warmup):
             ranks[i].step()
         ctx.sync()
@@ -1064,6 +1094,7 @@ def main_threads(a):
                        for i, r in enumerate(ranks)],
         "parity_vs_oracle": parity,
         "cpu_baseline": cpu_baseline,
+        "setup_s": {"placement_tuning": [r.tuning for r in ranks]},
     }
     if gather:
         out.update(gather)
@@ -1190,6 +1221,8 @@ def main():
 
     if a.calibrate_copy:  # k_permute_in as a pure copy of 2 x 512 MiB: known bytes for the PMC passes
         ctx.bench_copy(1 << 29, 2)
+    if a.evaluation == "recurrence":
+        rw.tune(a.tune_candidates, y_ptr)  # set-up: the workspaces' physical backing (setup_s.placement_tuning)
     for _ in range(a.warmup):
         step()
     fence()
@@ -1259,6 +1292,10 @@ def main():
             mix = {k_: v[0] / max(v[1], 1) for k_, v in acc.items()}
             mix["smi"] = dict(smi)
             mix["read_GBps"] = ctx.bench_read(1 << 30, 5)
+            # plain stream mixes, 256 MB per stream (gspx_bench_streams): reads : writes 1:0, 1:1, 3:1 - the 1:1 pair is
+            # what tells slow cards from fast ones where read-only and copy rates do not (profiles/r06_placement.md)
+            mix["streams"] = {"r{}w{}".format(nr, nw): ctx.bench_streams(256 << 20, nr, nw, 0, 8, 3)
+                              for nr, nw in ((1, 0), (1, 1), (3, 1))}
         except Exception as e:  # a calibration: never a reason to lose the measurement
             mix = {"error": repr(e)}
     if newton is not None or mix is not None:
@@ -1484,7 +1521,7 @@ def main():
                         "graph_object_incl_device_laplacian": t_graph,
                         "device_laplacian_build_ms": dev.build_ms,
                         "estimate_lmax_bounds": rw.t_lmax_bounds, "estimate_lmax_lanczos_device": t_lanczos,
-                        "lanczos_ritz_over_bound": lanczos_ratio},
+                        "lanczos_ritz_over_bound": lanczos_ratio, "placement_tuning": rw.tuning},
         }
 
     # ---- end to end through the mirrored API: numpy in -> Filter.filter -> numpy out (PCIe both ways,
@@ -1650,6 +1687,9 @@ def main():
             rf["mix_ceiling_frac"] = b_alg_launch / (mix[1] * 1e-3) / 1e9 / HBM_PEAK_GBS
             rf["mix_nobarrier_ceiling_frac"] = b_alg_launch / (mix[2] * 1e-3) / 1e9 / HBM_PEAK_GBS
             rf["smi_under_load"] = mix.get("smi") or None
+            rf["stream_mix_GBps"] = mix.get("streams")
+            tun = (out.get("setup_s") or {}).get("placement_tuning") or {}
+            rf["placement_candidates_frac"] = tun.get("candidates_frac")
         elif mix is not None:
             rf["mix_error"] = mix["error"]
         if spread is not None:

@@ -235,15 +235,16 @@ int gspx_bench_copy(gspx_ctx* ctx, int64_t bytes, int iters, double* gbps);
 /* Calibration: read-only GB/s of a `bytes`-sized buffer streamed `passes` times in one launch. */
 int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
 
-/* Placement tuning of a context's streamed workspaces for single-filter calls of Nsig signals on graph g: `candidates`
- * (1-32) fresh physical backings are drawn - the previous ones held meanwhile, so every draw gets other pages -, a short
- * filter call on scratch panels times each, the fastest stays in the context and the others are released.  Why: on
- * MI355X the recurrence on panels beyond the Infinity Cache runs 0.54-0.60 of 8 TB/s depending on which physical pages
- * back its workspaces, and a fresh process draws the same pages every time (profiles/r06_placement.md).  out[i]: ms per
- * recurrence launch with candidate i (0: the backing the context already had, if any); out[candidates]: index kept.
- * Costs candidates x (one workspace allocation + ~5 ms of kernels); the graph's factor values for its last lmax are
- * reused.  Results of later calls are bit-identical whichever backing was kept. */
-int gspx_ctx_tune_placement(gspx_graph* g, int64_t Nsig, int candidates, double* out);
+/* Placement tuning of a context's streamed workspaces for one single-filter analysis call (the arguments of
+ * gspx_cheby_filter_dev with Nf = 1): `candidates` (1-32) physical backings are drawn - the previous ones held meanwhile,
+ * so every draw gets other pages -, the call itself runs three times on each, the fastest stays in the context and
+ * the others are released.  Why: on MI355X the recurrence on panels beyond the Infinity Cache runs 0.54-0.60 of 8 TB/s
+ * depending on which physical pages back its work panels, and what a process draws first it keeps
+ * (profiles/r06_placement.md).  out[i]: ms per recurrence launch with candidate i (0: the backing the context already
+ * had, if any); out[candidates]: index kept.  y_dev holds the call's result afterwards; results are bit-identical
+ * whichever backing is kept. */
+int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig, const void* x_dev,
+                            void* y_dev, int candidates, double* out);
 
 /* Calibration: total GB/s of n_read (0-4) read streams and n_write (0-2) write streams of bytes_per_stream each, walked
  * together by workgroups_per_cu persistent workgroups per CU, 16 bytes per lane (nt: bit 0 non-temporal loads, bit 1

@@ -95,8 +95,6 @@ struct DevMem {
   void* p = nullptr;
   size_t bytes = 0;     // usable bytes
   bool streamed = false;  // eligible for the chunked mapping (set once by the owner)
-  size_t chunk_want = (size_t)2 << 20;  // physical chunk size of the mapping (options streamed_chunk_mb; 0: one piece)
-  bool scramble = true;   // chunks mapped in a scrambled order (option streamed_scramble)
   // chunked mapping
   size_t va_size = 0;   // > 0: p is a reserved address range of that many bytes
   size_t mapped = 0;    // bytes mapped from its start (a multiple of chunk)
@@ -138,7 +136,7 @@ struct DevMem {
     if (want <= mapped) return true;
     if (want > va_size) return false;
     const size_t base = mapped, cnt = (want - mapped) / chunk;
-    size_t mult = scramble ? 257 : 1;  // coprime with the piece count: a scrambled, fixed order that visits every slot once
+    size_t mult = 257;  // coprime with the piece count: a scrambled, fixed order that visits every slot once
     while (cnt > 1 && std::gcd(mult, cnt) != 1) mult += 2;
     const size_t first = pieces.size();
     bool ok = true;
@@ -183,7 +181,7 @@ struct DevMem {
     size_t gran = 0;
     if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran)
       return false;
-    size_t c = chunk_want ? chunk_want : std::max<size_t>(n, (size_t)2 << 20);  // (0: the whole request as one piece)
+    size_t c = (size_t)2 << 20;
     c = (c + gran - 1) / gran * gran;
     const size_t need = (n + c - 1) / c * c;
     // room to grow in place: twice the request, at least 1 GiB (address space only)
@@ -236,8 +234,6 @@ struct DevMem {
     std::swap(p, o.p);
     std::swap(bytes, o.bytes);
     std::swap(streamed, o.streamed);
-    std::swap(chunk_want, o.chunk_want);
-    std::swap(scramble, o.scramble);
     std::swap(va_size, o.va_size);
     std::swap(mapped, o.mapped);
     std::swap(chunk, o.chunk);
@@ -383,13 +379,6 @@ struct Options {
   int64_t copy_threads = 0;       // host threads of a staged copy (0: 8)
   int64_t tile_regroup = 1;     // 1: rows of 3 / 5 / 6 / 7 / 10 / 12 / 14 sixteen-byte pieces run the builds whose compute
                                 // phases regroup the lanes by pieces (k_step_tile<..., CL>); 0: the power-of-two builds
-  int64_t tile_chunk_major = 1; // 1: a single-filter analysis call on rows of exactly two 256-byte chunks (64 fp64 signals)
-                                // keeps its work panels chunk-major - two panels of whole 256-byte rows - instead of
-                                // row-major (round 6: profiles/r06_chunk_major.md); 0: row-major everywhere
-  int64_t streamed_chunk_mb = 2;  // physical chunk size of the streamed workspaces' mapping (0: one piece per request)
-  int64_t streamed_scramble = 1;  // 1: chunks mapped in a scrambled order; 0: in order
-  int64_t ws_skew = 0;          // bytes between the end of T slot 0 and the start of slot 1 (single-filter calls)
-  int64_t racc_skew = 0;        // bytes the accumulator panel is shifted inside its workspace
   int64_t tile_lg = 0;          // lanes per row of the narrow builds: 0 by row size (1 / 2 / 4 / 8); 2, 4 or 8: at least that
   int64_t edge_vertex_walk = 1; // grad / div walk the vertices in the internal order (k_grad_v / k_div_v); 0: edge order
   int64_t fuse_input = 1;       // 1: k_step_tile reads the caller's panel directly in steps 1-2 (no permute-in copy)
@@ -632,11 +621,6 @@ static int64_t* option_slot(Options& o, const char* key) {
   if (!strcmp(key, "graph_launch")) return &o.graph_launch;
   if (!strcmp(key, "tile_workgroups")) return &o.tile_workgroups;
   if (!strcmp(key, "tile_lg")) return &o.tile_lg;
-  if (!strcmp(key, "tile_chunk_major")) return &o.tile_chunk_major;
-  if (!strcmp(key, "ws_skew")) return &o.ws_skew;
-  if (!strcmp(key, "streamed_chunk_mb")) return &o.streamed_chunk_mb;
-  if (!strcmp(key, "streamed_scramble")) return &o.streamed_scramble;
-  if (!strcmp(key, "racc_skew")) return &o.racc_skew;
   if (!strcmp(key, "tile_regroup")) return &o.tile_regroup;
   if (!strcmp(key, "staged_copy")) return &o.staged_copy;
   if (!strcmp(key, "staged_copy_min_mb")) return &o.staged_copy_min_mb;
@@ -686,15 +670,6 @@ extern "C" int gspx_ctx_set_option(gspx_ctx* ctx, const char* key, int64_t value
         m->release();
       }
       m->streamed = on;
-    }
-  }
-  if (!strcmp(key, "streamed_chunk_mb") || !strcmp(key, "streamed_scramble")) {  // the next allocation uses them
-    (void)hipSetDevice(ctx->device);
-    for (DevMem* m : {&ctx->ws_t, &ctx->ws_r}) {
-      (void)hipStreamSynchronize(ctx->stream);
-      m->release();
-      m->chunk_want = (size_t)std::max<int64_t>(ctx->opt.streamed_chunk_mb, 0) << 20;
-      m->scramble = ctx->opt.streamed_scramble != 0;
     }
   }
   return GSPX_OK;
@@ -1876,16 +1851,6 @@ static int launch_step_tile(gspx_graph* g, const Options& opt, TileArgs<T> t, un
   t.N = (int)g->N;
   t.ld = ld;
   t.panel_bytes = (unsigned)((size_t)g->N * ld * sizeof(T));
-  {  // panel layouts: row-major unless the caller marked a panel chunk-major (pitch == 256 set by run_batch)
-    const unsigned rm_pitch = (unsigned)rowb, rm_cs = 16u * (unsigned)lg, cm_cs = (unsigned)((size_t)g->N * 256);
-    auto lay = [&](unsigned& pitch, unsigned& cs) {
-      if (pitch == 256 && ncol == 2) cs = cm_cs;
-      else pitch = rm_pitch, cs = rm_cs;
-    };
-    lay(t.cur_pitch, t.cur_cs);
-    lay(t.old_pitch, t.old_cs);
-    lay(t.wrk_pitch, t.wrk_cs);
-  }
   t.val_bytes = (unsigned)((size_t)g->nnz_int * sizeof(T));
   t.lidx_bytes = (unsigned)((size_t)g->nnz_int);
   t.nb = g->gt_nb;
@@ -1971,16 +1936,13 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   }
 
   const size_t nslots = deferred ? (size_t)M : 2;
-  // slot pitch: the panels of a call are walked in lockstep, row by row, so how their addresses lie relative to each
-  // other decides which memory channels the concurrent streams meet on (round 6, profiles/r06_placement.md); ws_skew /
-  // racc_skew (bytes, multiples of 256) shift slot 1 and the accumulator against slot 0
-  const size_t skew_t = deferred ? 0 : (size_t)std::max<int64_t>(opt.ws_skew, 0) / 256 * 256 / sizeof(T);
-  const size_t skew_r = deferred ? 0 : (size_t)std::max<int64_t>(opt.racc_skew, 0) / 256 * 256 / sizeof(T);
-  const size_t SU = U + skew_t;
+  // (Shifting slot 1 or the accumulator against slot 0 by 256 B ... 16 MB changes nothing: the placement effect of
+  // profiles/r06_placement.md is not stream-against-stream channel aliasing - tools/skew_sweep.py's record.)
+  const size_t SU = U;  // slot pitch
   CHK(ctx->ws_t.ensure(nslots * SU * sizeof(T) + 256));
-  if (!deferred) CHK(ctx->ws_r.ensure(((size_t)nf * U + skew_r) * sizeof(T) + 256));
+  if (!deferred) CHK(ctx->ws_r.ensure((size_t)nf * U * sizeof(T) + 256));
   T* slots = ctx->ws_t.as<T>();
-  T* racc = ctx->ws_r.as<T>() + skew_r;
+  T* racc = ctx->ws_r.as<T>();
 
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   if (!cap) {
@@ -2004,10 +1966,6 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
   const bool fuse_in = tile_direct && !deferred && opt.fuse_input && g->gt_slow == 0 && ldx == ld &&
                        ((uintptr_t)x % 16) == 0 && (xb + xbytes <= yb || yb + ybytes <= xb) &&
                        (!g->has_perm || (g->gt_ns1 > 0 && (!cap || g->gt_s1nat.p)));
-  // Chunk-major work panels: the K launches of this call are the only readers and writers of the two T slots and the
-  // accumulator (fused input: no permute-in copy; the last flush stores straight into y), so their layout is this
-  // function's own business.  Rows of exactly two 256-byte chunks only (the 2-chunk build of the kernel).
-  const bool chunk_major = fuse_in && opt.tile_chunk_major && (size_t)ldw * sizeof(T) == 512 && g->gt_slow == 0;
   if (fuse_in) {
     CHK(ensure_s1nat(g, st));
   } else if (padded) {
@@ -2054,11 +2012,6 @@ static int run_batch(gspx_graph* g, int nf, int M, const std::vector<double>& cp
           t.old = x;
           t.old_rows = perm;  // null without an internal order: plain rows
         }
-      }
-      if (chunk_major) {  // every panel of the call but the caller's x (cur of step 1, old of step 2) and y
-        t.wrk_pitch = 256;
-        t.cur_pitch = (k == 1) ? 0 : 256;
-        t.old_pitch = (k <= 2) ? 0 : 256;
       }
       t.racc = racc;
       t.y = y;
@@ -3037,31 +2990,22 @@ extern "C" int gspx_bench_step_mix(gspx_graph* g, double lmax, int M, const doub
 // Placement tuning (round 6, profiles/r06_placement.md).  On MI355X the speed of the recurrence on panels beyond the
 // Infinity Cache depends on WHICH physical pages back the streamed workspaces: the same call, in one process on one GPU,
 // runs anywhere between 0.54 and 0.60 of 8 TB/s as the allocator hands out different pages - the "slow boxes" of rounds
-// 2 to 5 were boxes whose first allocation drew badly, and a fresh process draws the same pages again.  Relative shifts
-// of the panels inside one allocation change nothing (options ws_skew / racc_skew, tools/skew_sweep.py), so this is not
+// 2 to 5 were partly boxes whose first allocation drew badly (and partly cards that are slow whatever they draw).
+// Relative shifts of the panels inside one allocation change nothing (256 B ... 16 MB, measured), so this is not
 // stream-against-stream channel aliasing that a layout rule could avoid; the remedy is to draw several times and keep
 // the best.  For `candidates` fresh backings of the two workspaces (the previous ones held meanwhile, so every draw
-// gets other pages) a short single-filter call of the given width runs on scratch panels; the fastest backing stays
-// in the context, the others are released.  out[i]: milliseconds per recurrence launch with candidate i (candidate 0
-// = the backing the context had, or its first own draw), out[candidates] = index kept.
-extern "C" int gspx_ctx_tune_placement(gspx_graph* g, int64_t Nsig, int candidates, double* out) {
+// gets other pages) the caller's OWN call runs three times (a 7-launch stand-in on scratch panels ranked the candidates
+// wrongly: its spread was 2 %, the full call's 8 %); the fastest backing stays in the context, the others are
+// released.  out[i]: milliseconds per recurrence launch with candidate i (candidate 0 = the backing the context had,
+// or its first own draw), out[candidates] = index kept.
+extern "C" int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig,
+                                       const void* x_dev, void* y_dev, int candidates, double* out) {
   if (!g || !g->ctx || !out) return set_err(GSPX_ERR_INVALID, "gspx_ctx_tune_placement: null argument");
   if (candidates < 1 || candidates > 32) return set_err(GSPX_ERR_INVALID, "gspx_ctx_tune_placement: 1 to 32 candidates");
+  CHK(check_filter_args(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS));
   gspx_ctx* ctx = g->ctx;
-  const size_t elt = elt_size(g->dtype);
-  if (Nsig < 1 || Nsig >= (1 << 20) || (size_t)g->N * (size_t)Nsig * elt >= ((size_t)1 << 31))
-    return set_err(GSPX_ERR_INVALID, "gspx_ctx_tune_placement: panel width out of range");
   HIPCHK(hipSetDevice(ctx->device));
   replay_reset(ctx);
-  const size_t bytes = (size_t)g->N * (size_t)Nsig * elt;
-  DevMem x, y;
-  CHK(x.alloc(bytes));
-  CHK(y.alloc(bytes));
-  // (any non-zero pattern: the launches' times do not depend on the values, but all-zero panels clock higher)
-  hipLaunchKernelGGL((k_fill<float>), dim3(4096), dim3(256), 0, ctx->stream, x.as<float>(), bytes / 4, 0.7183f);
-  const int M = 8;  // 7 launches, two of them flush steps: every stream of a full call is in it
-  const double coeffs[M] = {1.0, 0.5, -0.25, 0.125, -0.0625, 0.03125, -0.015625, 0.0078125};
-  const double lmax = g->fval_lmax > 0 ? g->fval_lmax : 2.0;  // (the factor values already on the device, if any)
   std::vector<std::unique_ptr<DevMem>> held;  // losing candidates stay allocated until the end: no page is drawn twice
   DevMem best_t, best_r;
   double best_ms = 0;
@@ -3069,8 +3013,8 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, int64_t Nsig, int candidat
   for (int i = 0; i < candidates; ++i) {
     if (i > 0) {  // candidate 0 is what the context has (or draws now); later ones start from empty workspaces
       DevMem t, r;
-      t.streamed = ctx->ws_t.streamed, t.chunk_want = ctx->ws_t.chunk_want, t.scramble = ctx->ws_t.scramble;
-      r.streamed = ctx->ws_r.streamed, r.chunk_want = ctx->ws_r.chunk_want, r.scramble = ctx->ws_r.scramble;
+      t.streamed = ctx->ws_t.streamed;
+      r.streamed = ctx->ws_r.streamed;
       ctx->ws_t.swap(t);
       ctx->ws_r.swap(r);
       if (best == i - 1) {  // the previous candidate is the best so far: keep it aside
@@ -3083,8 +3027,8 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, int64_t Nsig, int candidat
       held.back()->swap(r);
     }
     double ms = 0;
-    for (int rep = 0; rep < 2; ++rep) {
-      const int rc = gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x.p, y.p, GSPX_ANALYSIS, nullptr);
+    for (int rep = 0; rep < 3; ++rep) {  // the caller's own call: the first run allocates, the best of the next two counts
+      const int rc = gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, nullptr);
       if (rc != GSPX_OK) {
         if (best >= 0 && best != i) {  // put the best backing found so far in place before reporting the failure
           ctx->ws_t.swap(best_t);
@@ -3092,7 +3036,9 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, int64_t Nsig, int candidat
         }
         return rc;
       }
-      ms = ctx->timing[1] / std::max(ctx->timing[2], 1.0);
+      const double t = ctx->timing[1] / std::max(ctx->timing[2], 1.0);
+      if (rep == 1 || (rep == 2 && t < ms)) ms = t;
+      replay_reset(ctx);
     }
     out[i] = ms;
     if (best < 0 || ms < best_ms) best_ms = ms, best = i;
@@ -3102,9 +3048,8 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, int64_t Nsig, int candidat
     ctx->ws_r.swap(best_r);
   }
   out[candidates] = (double)best;
-  replay_reset(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  return GSPX_OK;  // (held, best_t / best_r - now the losers - and the scratch panels are released here)
+  return GSPX_OK;  // (held and best_t / best_r - now the losers - are released here; y holds the call's result)
 }
 
 #include "gspx_calib.hip.h"

@@ -42,12 +42,6 @@ template <typename T> struct TileArgs {
   int N;
   u32 ld, ldy;
   u32 panel_bytes, val_bytes, lidx_bytes;
-  // Where piece (row, column chunk c, lane) of a panel lies: row * pitch + c * cs + lane * 16 bytes.  Row-major panels
-  // (the caller's x and y, every panel by default): pitch = ld * sizeof(T), cs = 16 LG.  CHUNK-MAJOR work panels
-  // (round 6, rows of two 256-byte chunks: the fp64 headline): pitch = 256, cs = N * 256 - each column chunk is a
-  // panel of whole 256-byte rows of its own, so a pass touches whole contiguous rows instead of halves of 512-byte
-  // rows (profiles/r06_chunk_major.md).  cur: the gathered panel T_{k-1}; old: T_{k-2}; wrk: out and the accumulator.
-  u32 cur_pitch, cur_cs, old_pitch, old_cs, wrk_pitch, wrk_cs;
   int nb, ncol, per_xcd;
   int lds_bytes;
   T scale, gamma;
@@ -89,15 +83,11 @@ constexpr int GSPX_TILE_MAXN1 = 160;  // S1 rows a workgroup stages (5 per group
 // -0.8 ... -1.4 %: the previous build did not wait for a wave's own tile at all (see the first barrier below).
 // The OLDNAT builds (one launch per call) keep the plain order and a full wait.
 // Narrow panels (8-lane groups) issue the tile first and wait for everything: measured better there.
-#ifndef GSPX_SCHED_VARIANT
-#define GSPX_SCHED_VARIANT 0
-#endif
 template <typename T, int NCOL, int LG, bool OLDNAT> struct TileSchedule {
-  static constexpr bool ONE = NCOL == 1 && LG == 16 && !OLDNAT;  // (round-6 A/B: one-chunk wide rows, the fp32 headline)
   static constexpr bool PF = !OLDNAT;
-  static constexpr bool TILE_LAST = PF && LG == 16 && !(ONE && (GSPX_SCHED_VARIANT & 2));
+  static constexpr bool TILE_LAST = PF && LG == 16;
   static constexpr bool PF_ENTRIES = PF;  // (leaving the entries with their own pass measured 2-3 % slower)
-  static constexpr bool META_AFTER = !OLDNAT && LG == 16 && (NCOL == 0 || (ONE && (GSPX_SCHED_VARIANT & 1)));
+  static constexpr bool META_AFTER = !OLDNAT && LG == 16 && NCOL == 0;
 };
 
 // INS: the step adds extra input panels to the row (synthesis by Clenshaw, a.nin > 0) - its own build, so
@@ -163,9 +153,6 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   const rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.val, 0, a.val_bytes, 0x00020000);
   const rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)a.lidx, 0, a.lidx_bytes, 0x00020000);
   const u32 ldb = a.ld * (u32)sizeof(T);
-  // (locals, not a.*: with `a.cur_pitch` inside the LDS-DMA builtin's offset the HOST pass of hipcc silently drops the
-  // kernel's stub and handle - an undefined symbol at load time, no diagnostic; ROCm 7.2)
-  const u32 cur_pitch = a.cur_pitch, cur_cs = a.cur_cs;
 
   struct Meta { int rows[ST]; int rp[RPG + 1]; int orow[OLDNAT ? RPG : 1]; };
   // walk position -> block: the XCD's range front to back, or back to front
@@ -202,16 +189,16 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
     for (int t = 0; t < ST; ++t) {
       if (grp_d + NGD * t < n1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rcur, (lds_ptr)(gspx_smem + (wave * (64 / LG) + NGD * t) * RB), 16,
-                                                 (u32)m.rows[t] * cur_pitch + cb, 0, 0, 0);
+                                                 (u32)m.rows[t] * ldb + cb, 0, 0, 0);
     }
   };
-  auto chunk_off_d = [&](int c) {  // the staging lane's piece of column chunk c of the gathered panel
+  auto chunk_off_d = [&](int c) {  // the staging lane's piece of column chunk c
     const u32 col0 = (c * LG + lane_d) * VEC;
-    return col0 < a.ld ? (u32)c * cur_cs + (u32)lane_d * 16u : POISON;
+    return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
   };
-  auto chunk_off = [&](int c, u32 cs) {    // the compute lane's, in a panel whose chunks lie cs bytes apart
+  auto chunk_off = [&](int c) {    // the compute lane's
     const u32 col0 = (c * LG + lane16) * VEC;
-    return col0 < a.ld ? (u32)c * cs + (u32)lane16 * 16u : POISON;
+    return col0 < a.ld ? col0 * (u32)sizeof(T) : POISON;
   };
 
   // Loads that a pass consumes are issued one pass ahead, together with its tile: T_{k-2} (and the
@@ -224,13 +211,12 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
   for (int q = 0; q < NE; ++q) ev[q] = 0;
   auto prefetch_rows = [&](const Meta& m, int blk, int c) {
     const int r0 = phys(blk) * BR + grp * RPG;
-    const u32 cbo = chunk_off(c, a.old_cs), cbw = chunk_off(c, a.wrk_cs);
+    const u32 cb = chunk_off(c);
 #pragma unroll
     for (int t = 0; t < RPG; ++t) {
-      const bool live = r0 + t < a.N && cbo != POISON;
-      const u32 off = live ? (u32)(r0 + t) * a.wrk_pitch + cbw : POISON;
-      u32 oo = (live && a.gamma != T(0)) ? (u32)(r0 + t) * a.old_pitch + cbo : POISON;
-      if constexpr (OLDNAT) oo = (live && a.gamma != T(0)) ? (u32)m.orow[t] * a.old_pitch + cbo : POISON;
+      const u32 off = (r0 + t < a.N && cb != POISON) ? (u32)(r0 + t) * ldb + cb : POISON;
+      u32 oo = a.gamma != T(0) ? off : POISON;
+      if constexpr (OLDNAT) oo = (off != POISON && a.gamma != T(0)) ? (u32)m.orow[t] * ldb + cb : POISON;
       if (a.nt & 4) ov[t] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rold, oo, 0, 2));
       else ov[t] = VT<T, VEC>::bload(rold, oo);
       const u32 ro = a.flush == 2 ? off : POISON;
@@ -362,7 +348,7 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
       } else if (row0 + t < a.N) {  // plain gathers from global memory (tile too large for LDS)
         for (int j = s; j < e; ++j) {
           const int cc = a.col[j];
-          const V xv = VT<T, VEC>::bload(rcur, (cc < a.N && on) ? (u32)cc * cur_pitch + (u32)c * cur_cs + (u32)lane16 * 16u : POISON);
+          const V xv = VT<T, VEC>::bload(rcur, cc < a.N ? (u32)cc * ldb + cb : POISON);
           if (j == s) self = xv;  // entry 0 is the diagonal slot
           acc += a.val[j] * xv;
         }
@@ -400,16 +386,15 @@ __global__ __launch_bounds__(NT, 4) void k_step_tile(const TileArgs<T> a) {
           *(V*)(a.y + orow * a.ldy + col0) = nv[t];
           continue;
         }
-        const size_t woff = (size_t)row * a.wrk_pitch + (size_t)c * a.wrk_cs + (size_t)lane16 * 16u;  // bytes
-        if (a.nt & 8) __builtin_nontemporal_store(nv[t], (V*)((unsigned char*)a.out + woff));
-        else *(V*)((unsigned char*)a.out + woff) = nv[t];
+        if (a.nt & 8) __builtin_nontemporal_store(nv[t], (V*)(a.out + (size_t)row * a.ld + col0));
+        else *(V*)(a.out + (size_t)row * a.ld + col0) = nv[t];
         if (a.flush) {
           if (a.final) {
             const size_t orow = a.perm ? (size_t)a.perm[row] : (size_t)row;
             *(V*)(a.y + orow * a.ldy + col0) = res[t];
           } else {
-            if (a.nt & 2) __builtin_nontemporal_store(res[t], (V*)((unsigned char*)a.racc + woff));
-            else *(V*)((unsigned char*)a.racc + woff) = res[t];
+            if (a.nt & 2) __builtin_nontemporal_store(res[t], (V*)(a.racc + (size_t)row * a.ld + col0));
+            else *(V*)(a.racc + (size_t)row * a.ld + col0) = res[t];
           }
         }
       }

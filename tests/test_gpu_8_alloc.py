@@ -233,7 +233,9 @@ def test_placement_tuning_keeps_the_fastest_backing_and_the_same_bits():
         x = np.random.default_rng(3).standard_normal((G.N, 64))
         c = orc.compute_cheby_coeff(orc.heat_kernel(20, G.lmax), G.lmax, 30)
         y0, _ = dev.cheby_filter(c, x, G.lmax)
-        rep = dev.tune_placement(64, candidates=5)
+        bx, by = ctx.upload(x), ctx.alloc(x.nbytes)
+        rep = dev.tune_placement(c, bx.ptr, by.ptr, 64, G.lmax, candidates=5)
+        assert np.array_equal(by.download(x.shape, np.float64), y0[0])  # the tuned call's own result
         assert len(rep["launch_ms"]) == 5 and all(v > 0 for v in rep["launch_ms"])
         assert rep["launch_ms"][rep["kept"]] == min(rep["launch_ms"])
         y1, _ = dev.cheby_filter(c, x, G.lmax)
@@ -244,14 +246,16 @@ def test_placement_tuning_keeps_the_fastest_backing_and_the_same_bits():
         x2 = np.random.default_rng(4).standard_normal((G.N, 96))
         y2, _ = dev.cheby_filter(c, x2, G.lmax)
         assert rel_err(y2[0][:, :2], orc.cheby_op(orc.laplacian(G.W), G.lmax, c, x2[:, :2])) < 1e-11
-        rep2 = dev.tune_placement(32, candidates=2)
+        rep2 = dev.tune_placement(c, bx.ptr, by.ptr, 32, G.lmax, candidates=2)
         assert rep2["kept"] in (0, 1)
         y3, _ = dev.cheby_filter(c, x, G.lmax)
         assert np.array_equal(y0, y3)
         with pytest.raises(ValueError):
-            dev.tune_placement(64, candidates=0)
-        with pytest.raises(ValueError):
-            dev.tune_placement(0, candidates=2)
+            dev.tune_placement(c, bx.ptr, by.ptr, 64, G.lmax, candidates=0)
+        with pytest.raises(TypeError):
+            dev.tune_placement(c[:1], bx.ptr, by.ptr, 64, G.lmax, candidates=2)
+        bx.free()
+        by.free()
         dev.destroy()
     finally:
         ctx.close()

@@ -44,8 +44,8 @@ G, dev = make_graph()
 c = np.atleast_2d(filters.compute_cheby_coeff(filters.Heat(G, 50), m=30))
 bx, by = ctx.upload(x), ctx.alloc(U)
 out = {"start": frac(dev, G, c, bx, by)}
-rep = dev.tune_placement(64, trials)
-b7 = dev.nnz_l * 12 + 4 * (G.N + 1) + 3 * U + U / 7
+rep = dev.tune_placement(c[0], bx.ptr, by.ptr, 64, float(G.lmax), trials)
+b7 = dev.nnz_l * 12 + 4 * (G.N + 1) + 3 * U + U / 30
 out["ws"] = {"candidates_frac_short_call": [round(b7 / (v * 1e-3) / 8e12, 4) for v in rep["launch_ms"]], "kept": rep["kept"],
              "after": frac(dev, G, c, bx, by)}
 print(json.dumps(out), flush=True)
