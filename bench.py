@@ -78,9 +78,12 @@ def parse():
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
     p.add_argument("--no-mix", action="store_true", help="skip the mix-ceiling calibration (gspx_bench_step_mix)")
-    p.add_argument("--tune-candidates", type=int, default=6,
+    p.add_argument("--tune-candidates", type=int, default=14,
                    help="set-up: physical backings of the streamed workspaces drawn by DeviceGraph.tune_placement, the "
                         "fastest kept (0: none; profiles/r06_placement.md)")
+    p.add_argument("--tune-stride-mb", type=int, default=16000,
+                   help="set-up: device memory held between two draws of the placement tuning, so that the candidates "
+                        "sample the card's memory at that stride (fast and slow pages come in zones of tens of GB)")
     p.add_argument("--no-e2e", action="store_true", help="skip the numpy-in/numpy-out leg (profiling passes)")
     p.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     p.add_argument("--no-f32", action="store_true", help="skip the float32 run of the headline workload")
@@ -116,7 +119,7 @@ def smi_sample(device=0):
     """What rocm-smi says about a device right now (called from a thread while the recurrence runs): HBM and junction
     temperatures, clocks, package power.  The memory temperature is the one quantity that moved with the step's
     speed over successive runs on one GPU in round 6 (68 C: 0.612 of 8 TB/s ... 72 C: 0.598, the mix ceiling falling
-    with it - profiles/r06_box_probe.md).  {} when rocm-smi is missing or fails."""
+    with it - profiles/r06_placement.md).  {} when rocm-smi is missing or fails."""
     import re
     import shutil
     import subprocess
@@ -127,7 +130,7 @@ def smi_sample(device=0):
     except Exception:
         return {}
     out = {}
-    try:  # which card this is (the population of cards differs: memory vendor, VBIOS; profiles/r06_box_probe.md)
+    try:  # which card this is (the population of cards differs: memory vendor, VBIOS; profiles/r06_placement.md)
         ident = subprocess.run([exe, "-d", str(int(device)), "--showuniqueid", "--showmemvendor", "--showvbios"],
                                capture_output=True, text=True, timeout=30).stdout
         for key, pat in (("gpu_unique_id", r"Unique ID:\s*(\S+)"), ("memory_vendor", r"memory vendor:\s*(\S+)"),
@@ -707,16 +710,18 @@ class RankWork:
         self.launches = 0
         self.tuning = None
 
-    def tune(self, candidates, y_ptr=None):
+    def tune(self, candidates, y_ptr=None, stride_mb=0):
         """Set-up, outside every timed region: draw `candidates` physical backings for the context's streamed
         workspaces, run this rank's own call on each and keep the fastest (DeviceGraph.tune_placement;
         profiles/r06_placement.md).  No-op for the plain kernels' graphs and for candidates < 2."""
         tiled = bool(self.G.tile_stats and self.G.tile_stats.get("enabled"))
-        if candidates < 2 or not tiled or (y_ptr is None and self.by is None):
+        # (panels within the 256 MB Infinity Cache do not feel where they lie in HBM: nothing to tune)
+        if candidates < 2 or not tiled or (y_ptr is None and self.by is None) or self.x.nbytes < (192 << 20):
             return None
         t0 = time.perf_counter()
         try:
-            rep = self.dev.tune_placement(self.c[0], self.bx.ptr, y_ptr or self.by.ptr, self.nsig, self.lmax, candidates)
+            rep = self.dev.tune_placement(self.c[0], self.bx.ptr, y_ptr or self.by.ptr, self.nsig, self.lmax, candidates,
+                                          stride_mb)
         except Exception as e:  # a tuning step: never a reason to lose the measurement
             self.tuning = {"error": repr(e)}
             return self.tuning
@@ -724,12 +729,15 @@ class RankWork:
         U = N * self.nsig * elt
         K = self.c.shape[1] - 1
         b_launch = self.dev.nnz_l * (elt + 4) + 4 * (N + 1) + 3 * U + U / K
-        self.tuning = {"seconds": time.perf_counter() - t0, "candidates": candidates, "kept": rep["kept"],
-                       "candidates_launch_ms": rep["launch_ms"],
-                       "candidates_frac": [b_launch / (v * 1e-3) / 1e9 / HBM_PEAK_GBS for v in rep["launch_ms"]],
+        self.tuning = {"seconds": time.perf_counter() - t0, "candidates": candidates, "stride_mb": stride_mb,
+                       "kept": rep["kept"], "candidates_launch_ms": rep["launch_ms"],
+                       "candidates_frac": [(b_launch / (v * 1e-3) / 1e9 / HBM_PEAK_GBS) if v > 0 else None
+                                           for v in rep["launch_ms"]],
                        "what": "DeviceGraph.tune_placement: physical backings of the streamed workspaces drawn in the "
-                               "set-up, this call run on each, the fastest kept (bit-identical results; candidate 0 = "
-                               "the first draw, what a run without tuning would have used)"}
+                               "set-up - a pad of stride_mb held between two draws, so that they sample the card's memory "
+                               "zones -, this very call run on each, the fastest kept, everything else released "
+                               "(bit-identical results; candidate 0 = the first draw, what a run without tuning would "
+                               "have used; null = not drawn, memory ran out)"}
         return self.tuning
 
     def step(self, y_ptr=None):
@@ -944,7 +952,7 @@ def main_threads(a):
             k, v = kv.split("=")
             ctx.set_option(k, int(v))
         ranks[i] = RankWork(a, ctx, i, dtype)
-        ranks[i].tune(a.tune_candidates)
+        ranks[i].tune(a.tune_candidates, None, a.tune_stride_mb)
         for _ in range(a.warmup):
             ranks[i].step()
         ctx.sync()
@@ -1222,7 +1230,7 @@ def main():
     if a.calibrate_copy:  # k_permute_in as a pure copy of 2 x 512 MiB: known bytes for the PMC passes
         ctx.bench_copy(1 << 29, 2)
     if a.evaluation == "recurrence":
-        rw.tune(a.tune_candidates, y_ptr)  # set-up: the workspaces' physical backing (setup_s.placement_tuning)
+        rw.tune(a.tune_candidates, y_ptr, a.tune_stride_mb)  # set-up: the workspaces' backing (setup_s.placement_tuning)
     for _ in range(a.warmup):
         step()
     fence()
@@ -1690,6 +1698,7 @@ def main():
             rf["stream_mix_GBps"] = mix.get("streams")
             tun = (out.get("setup_s") or {}).get("placement_tuning") or {}
             rf["placement_candidates_frac"] = tun.get("candidates_frac")
+            rf["frac_untuned_first_draw"] = (tun.get("candidates_frac") or [None])[0]
         elif mix is not None:
             rf["mix_error"] = mix["error"]
         if spread is not None:

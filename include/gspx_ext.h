@@ -241,10 +241,12 @@ int gspx_bench_read(gspx_ctx* ctx, int64_t bytes, int passes, double* gbps);
  * the others are released.  Why: on MI355X the recurrence on panels beyond the Infinity Cache runs 0.54-0.60 of 8 TB/s
  * depending on which physical pages back its work panels, and what a process draws first it keeps
  * (profiles/r06_placement.md).  out[i]: ms per recurrence launch with candidate i (0: the backing the context already
- * had, if any); out[candidates]: index kept.  y_dev holds the call's result afterwards; results are bit-identical
- * whichever backing is kept. */
+ * had, if any; 0: never drawn, memory ran out); out[candidates]: index kept.  stride_mb > 0: a pad of that many MB is
+ * allocated and held before every further draw (released at the end), so that the candidates sample the card's memory at
+ * that stride - fast and slow pages come in zones of tens of GB in allocation order.  y_dev holds the call's result
+ * afterwards; results are bit-identical whichever backing is kept. */
 int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig, const void* x_dev,
-                            void* y_dev, int candidates, double* out);
+                            void* y_dev, int candidates, int64_t stride_mb, double* out);
 
 /* Calibration: total GB/s of n_read (0-4) read streams and n_write (0-2) write streams of bytes_per_stream each, walked
  * together by workgroups_per_cu persistent workgroups per CU, 16 bytes per lane (nt: bit 0 non-temporal loads, bit 1

@@ -2997,12 +2997,19 @@ extern "C" int gspx_bench_step_mix(gspx_graph* g, double lmax, int M, const doub
 // gets other pages) the caller's OWN call runs three times (a 7-launch stand-in on scratch panels ranked the candidates
 // wrongly: its spread was 2 %, the full call's 8 %); the fastest backing stays in the context, the others are
 // released.  out[i]: milliseconds per recurrence launch with candidate i (candidate 0 = the backing the context had,
-// or its first own draw), out[candidates] = index kept.
+// or its first own draw; 0 for candidates never drawn because memory ran out), out[candidates] = index kept.
+// stride_mb > 0: a pad of that size is allocated and held before every further draw, so that the candidates sample the
+// card's memory at that stride - the speed classes come in zones of tens of GB in allocation order (tools/zone_map.py:
+// 0 - 60 GB mixed, 60 - 130 GB slow, 130 - 200 GB medium, 200 - 270 GB fast on one card), and a card whose first 12 GB
+// are slow may have its fast zone 200 GB in.  The pads are released with the losing candidates.
 extern "C" int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const double* coeffs, int64_t Nsig,
-                                       const void* x_dev, void* y_dev, int candidates, double* out) {
+                                       const void* x_dev, void* y_dev, int candidates, int64_t stride_mb, double* out) {
   if (!g || !g->ctx || !out) return set_err(GSPX_ERR_INVALID, "gspx_ctx_tune_placement: null argument");
   if (candidates < 1 || candidates > 32) return set_err(GSPX_ERR_INVALID, "gspx_ctx_tune_placement: 1 to 32 candidates");
+  if (stride_mb < 0 || stride_mb > ((int64_t)1 << 20))
+    return set_err(GSPX_ERR_INVALID, "gspx_ctx_tune_placement: stride_mb out of range");
   CHK(check_filter_args(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS));
+  for (int i = 0; i <= candidates; ++i) out[i] = 0.0;
   gspx_ctx* ctx = g->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   replay_reset(ctx);
@@ -3025,14 +3032,30 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const 
       held.back()->swap(t);  // (what best_t held before, or the loser itself)
       held.emplace_back(new DevMem());
       held.back()->swap(r);
+      if (stride_mb > 0) {  // a held pad moves the next draw `stride_mb` further along the allocator's order: the speed
+        held.emplace_back(new DevMem());  // classes come in zones of tens of GB (profiles/r06_placement.md)
+        if (held.back()->alloc((size_t)stride_mb << 20) != GSPX_OK) {  // memory exhausted: the search ends here
+          held.pop_back();
+          ctx->ws_t.swap(best_t);  // (the live workspaces are empty at this point: the best so far goes back in)
+          ctx->ws_r.swap(best_r);
+          out[candidates] = (double)best;
+          replay_reset(ctx);
+          return GSPX_OK;
+        }
+      }
     }
     double ms = 0;
     for (int rep = 0; rep < 3; ++rep) {  // the caller's own call: the first run allocates, the best of the next two counts
       const int rc = gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, nullptr);
       if (rc != GSPX_OK) {
-        if (best >= 0 && best != i) {  // put the best backing found so far in place before reporting the failure
+        if (best >= 0 && best != i) {  // put the best backing found so far in place
           ctx->ws_t.swap(best_t);
           ctx->ws_r.swap(best_r);
+        }
+        if (rc == GSPX_ERR_OOM && best >= 0) {  // a deep candidate that did not fit: the search ends, not the call
+          out[candidates] = (double)best;
+          replay_reset(ctx);
+          return gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, nullptr);
         }
         return rc;
       }

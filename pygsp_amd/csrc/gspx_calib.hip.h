@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bench_gather(const uint4* __restrict__ 
 // persistent grid - what the memory system delivers to a given read : write ratio with nothing else in the way.  The
 // recurrence step is such a mix (T_{k-1} tiles, T_{k-2}, accumulator and entries in; T_k and the accumulator out: 3.6 : 1
 // on a plain step, 2.3 : 1 on a flush step), and boxes that agree on a read-only stream and on a 1 : 1 copy differ by
-// 10 % on it (profiles/r06_box_probe.md).  nt: bit 0 non-temporal loads, bit 1 non-temporal stores.
+// 10 % on it (profiles/r06_placement.md).  nt: bit 0 non-temporal loads, bit 1 non-temporal stores.
 template <int NR, int NW>
 __global__ __launch_bounds__(256) void k_bench_streams(const u32x4* __restrict__ rd, u32x4* __restrict__ wr, size_t n4,
                                                        int nt, unsigned* __restrict__ sink) {

@@ -882,15 +882,17 @@ class DeviceGraph:
         return ms.value
 
 
-    def tune_placement(self, coeffs, x_ptr, y_ptr, nsig, lmax, candidates=6):
+    def tune_placement(self, coeffs, x_ptr, y_ptr, nsig, lmax, candidates=6, stride_mb=0):
         """Draw `candidates` physical backings for the context's streamed workspaces and keep the one on which THIS call
         (the arguments of cheby_filter_dev, one filter) runs fastest (gspx_ctx_tune_placement; on MI355X the same call
         runs 0.54-0.60 of 8 TB/s depending on which pages back the work panels).  Returns {"launch_ms": [per
-        candidate], "kept": index}; y holds the call's result.  Results are bit-identical whichever backing is kept."""
+        candidate], "kept": index}; y holds the call's result.  Results are bit-identical whichever backing is kept.
+        stride_mb > 0: a pad of that size is held before every further draw, so the candidates sample the card's
+        memory at that stride (fast and slow pages come in zones of tens of GB); candidates that no longer fit read 0."""
         c = np.ascontiguousarray(np.asarray(coeffs, dtype=np.float64).ravel())
         out = np.zeros(int(candidates) + 1)
         self.ctx.call(_capi.load().gspx_ctx_tune_placement, self._h, float(lmax), int(c.size), _capi.ptr(c), int(nsig),
-                      ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), int(candidates), _capi.ptr(out))
+                      ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), int(candidates), int(stride_mb), _capi.ptr(out))
         return {"launch_ms": [float(v) for v in out[:-1]], "kept": int(out[-1])}
 
     def bench_step_mix(self, coeffs, x_ptr, y_ptr, nsig, lmax, mode=1):

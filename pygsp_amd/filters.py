@@ -580,6 +580,14 @@ class Filter:
                              "Nf = {}, got {}.".format(self.Nf, shape))
         return self.filter(s, method, order, devices=devices)
 
+    def tune_placement(self, n_signals, order=30, candidates=6, stride_mb=0):
+        """One-off set-up for a serving loop of single-filter analysis calls of `n_signals` columns at `order`: draw
+        `candidates` physical backings for the context's streamed workspaces, run that call (on scratch panels) on each
+        and keep the fastest (engine.DeviceGraph.tune_placement; on MI355X the same call runs 0.54-0.60 of 8 TB/s
+        depending on which pages back its work panels - profiles/r06_placement.md).  Results of later calls are
+        bit-identical whichever backing is kept.  Returns the report {"launch_ms": [...], "kept": index}."""
+        return tune_placement(self, n_signals, order, candidates, stride_mb=stride_mb)
+
     def localize(self, i, **kwargs):
         """The kernel(s) localised at vertex i: sqrt(N) * filter(delta_i)  (filter.py:350-391)."""
         delta = np.zeros(self.G.N)
@@ -596,6 +604,23 @@ class Filter:
         if method != "chebyshev":
             return self.filter(np.identity(self.G.N), method=method, order=order).T.reshape(-1, self.G.N)
         return frame_panels(self, order)
+
+
+def tune_placement(bank, n_signals, order=30, candidates=6, coefficients=None, stride_mb=0):
+    """Filter.tune_placement for any object with the reference's Filter attributes (the mirror class or, through
+    pygsp_amd.plugin.tune_placement, the real pygsp.filters.Filter): one filter only."""
+    from . import engine
+    if bank.Nf != 1:
+        raise ValueError("placement tuning times a single-filter analysis call (Nf = 1), got Nf = {}".format(bank.Nf))
+    coeffs = _as_coeff_matrix((coefficients or compute_cheby_coeff)(bank, m=order))
+    dev = _device_graph_of(bank.G)
+    x = engine.DeviceArray.from_host(dev.ctx, np.full((bank.G.N, int(n_signals)), 0.7183), dev.dtype)
+    y = engine.DeviceArray.empty(dev.ctx, (bank.G.N, int(n_signals), 1), dev.dtype)
+    try:
+        return dev.tune_placement(coeffs[0], x.ptr, y.ptr, int(n_signals), bank.G.lmax, candidates, stride_mb)
+    finally:
+        x.free()
+        y.free()
 
 
 def frame_panels(bank, order=30, panel=1024, coefficients=None):

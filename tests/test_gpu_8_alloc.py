@@ -248,6 +248,11 @@ def test_placement_tuning_keeps_the_fastest_backing_and_the_same_bits():
         assert rel_err(y2[0][:, :2], orc.cheby_op(orc.laplacian(G.W), G.lmax, c, x2[:, :2])) < 1e-11
         rep2 = dev.tune_placement(c, bx.ptr, by.ptr, 32, G.lmax, candidates=2)
         assert rep2["kept"] in (0, 1)
+        # a strided search: a held pad between the draws (candidates that no longer fit would read 0)
+        rep2 = dev.tune_placement(c, bx.ptr, by.ptr, 64, G.lmax, candidates=3, stride_mb=512)
+        assert rep2["kept"] in (0, 1, 2) and all(v > 0 for v in rep2["launch_ms"])
+        with pytest.raises(ValueError):
+            dev.tune_placement(c, bx.ptr, by.ptr, 64, G.lmax, candidates=2, stride_mb=-1)
         y3, _ = dev.cheby_filter(c, x, G.lmax)
         assert np.array_equal(y0, y3)
         with pytest.raises(ValueError):
@@ -256,6 +261,14 @@ def test_placement_tuning_keeps_the_fastest_backing_and_the_same_bits():
             dev.tune_placement(c[:1], bx.ptr, by.ptr, 64, G.lmax, candidates=2)
         bx.free()
         by.free()
+        # the one-liner of the drop-in layer: scratch panels, the bank's own coefficients
+        from pygsp_amd import filters
+        rep3 = filters.Heat(G, 20).tune_placement(64, order=30, candidates=2)
+        assert len(rep3["launch_ms"]) == 2 and rep3["kept"] in (0, 1)
+        with pytest.raises(ValueError, match="single-filter"):
+            filters.MexicanHat(G, Nf=3).tune_placement(64)
+        y4, _ = dev.cheby_filter(c, x, G.lmax)
+        assert np.array_equal(y0, y4)
         dev.destroy()
     finally:
         ctx.close()

@@ -38,7 +38,7 @@ def headline():
 before = headline()
 y0 = by.download(x.shape, dtype)
 t0 = time.perf_counter()
-rep = dev.tune_placement(c[0], bx.ptr, by.ptr, 64, float(G.lmax), cands)
+rep = dev.tune_placement(c[0], bx.ptr, by.ptr, 64, float(G.lmax), cands, int(os.environ.get("TUNE_STRIDE_MB", "0")))
 dt = time.perf_counter() - t0
 after = headline()
 y1 = by.download(x.shape, dtype)
