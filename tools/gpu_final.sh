@@ -11,7 +11,7 @@ timeout 1700 python -m pytest tests -m gpu -q --durations=6 > $O/pytest_gpu.log 
 SECONDS=0
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$? wall=${SECONDS}s"
 timeout 300 python tools/box_probe.py > $O/box_probe_final.json 2> $O/box_probe_final.err; echo "probe rc=$?"
-bash tools/gpu_prof.sh f64 --dtype f64 --tune-candidates 0 > $O/prof_f64.log 2>&1; grep -E "step-kernel launches|k_step_tile<double, 2, 16, false, false.*calls" $O/prof_f64.log | head -3
+bash tools/gpu_prof.sh f64 --dtype f64 > $O/prof_f64.log 2>&1; grep -E "step-kernel launches|k_step_tile<double, 2, 16, false, false.*calls" $O/prof_f64.log | head -3
 bash tools/gpu_prof_configs.sh c3 > $O/prof_c3.log 2>&1; bash tools/gpu_prof_configs.sh c2 > $O/prof_c2.log 2>&1
 python tools/config_traffic.py $O/prof_c2 $O/prof_c3 > $O/config_traffic.log 2>&1; cp profiles/traffic_configs.json $O/traffic_configs.json
 timeout 600 python bench.py --gpus 2 --devices 0,0 --steps 5 --warmup 2 > $O/bench_threads2.json 2> $O/bench_threads2.err; echo "bench threads rc=$?"

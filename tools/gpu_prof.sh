@@ -1,4 +1,7 @@
 # rocprofv3 evidence for the bench workload.  usage: bash tools/gpu_prof.sh <tag> [bench args...]
+# The kernel trace runs bench.py's default set-up INCLUDING the placement tuning (its launches are in the trace and in the
+# per-kernel average of kernel_stats.csv; the summary compares the LAST launches - the timed region - with the HIP events
+# of the same launches).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-f64}; shift
 export TMPDIR=/tmp
@@ -14,7 +17,8 @@ DEFAULT_PASSES="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;TCC_EA0_RDREQ_sum
 IFS=';' read -r -a PASSES <<< "${PROF_PASSES:-$DEFAULT_PASSES}"
 for pass in "${PASSES[@]}" ; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-newton --no-mix --no-e2e --no-configs --no-f32 --calibrate-copy "$@" > /dev/null 2> $OUT/pmc_$name.err
+  # (the counter passes skip the placement tuning of the set-up: the bytes a launch moves do not depend on where its panels lie)
+  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-newton --no-mix --no-e2e --no-configs --no-f32 --calibrate-copy --tune-candidates 0 "$@" > /dev/null 2> $OUT/pmc_$name.err
 done
 python $R/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
