@@ -3014,6 +3014,30 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const 
   HIPCHK(hipSetDevice(ctx->device));
   replay_reset(ctx);
   std::vector<std::unique_ptr<DevMem>> held;  // losing candidates stay allocated until the end: no page is drawn twice
+  struct Pads {  // physical memory held without a mapping (hipMemCreate): occupies pages, costs no page-table work
+    std::vector<hipMemGenericAllocationHandle_t> h;
+    bool hold(size_t bytes, int device) {
+      hipMemAllocationProp prop = {};
+      prop.type = hipMemAllocationTypePinned;
+      prop.location.type = hipMemLocationTypeDevice;
+      prop.location.id = device;
+      size_t gran = 0;
+      if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+        (void)hipGetLastError();
+        return false;
+      }
+      hipMemGenericAllocationHandle_t one;
+      if (hipMemCreate(&one, (bytes + gran - 1) / gran * gran, &prop, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+      }
+      h.push_back(one);
+      return true;
+    }
+    ~Pads() {
+      for (auto& one : h) (void)hipMemRelease(one);
+    }
+  } pads;
   DevMem best_t, best_r;
   double best_ms = 0;
   int best = -1;
@@ -3033,9 +3057,13 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const 
       held.emplace_back(new DevMem());
       held.back()->swap(r);
       if (stride_mb > 0) {  // a held pad moves the next draw `stride_mb` further along the allocator's order: the speed
-        held.emplace_back(new DevMem());  // classes come in zones of tens of GB (profiles/r06_placement.md)
-        if (held.back()->alloc((size_t)stride_mb << 20) != GSPX_OK) {  // memory exhausted: the search ends here
-          held.pop_back();
+        bool ok = pads.hold((size_t)stride_mb << 20, ctx->device);  // classes come in zones of tens of GB
+        if (!ok) {  // (physical memory without a mapping is all a pad needs; a plain allocation if that API refuses)
+          held.emplace_back(new DevMem());
+          ok = held.back()->alloc((size_t)stride_mb << 20) == GSPX_OK;
+          if (!ok) held.pop_back();
+        }
+        if (!ok) {  // memory exhausted: the search ends here
           ctx->ws_t.swap(best_t);  // (the live workspaces are empty at this point: the best so far goes back in)
           ctx->ws_r.swap(best_r);
           out[candidates] = (double)best;
