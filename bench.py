@@ -1300,8 +1300,9 @@ def main():
             mix = {k_: v[0] / max(v[1], 1) for k_, v in acc.items()}
             mix["smi"] = dict(smi)
             mix["read_GBps"] = ctx.bench_read(1 << 30, 5)
-            # plain stream mixes, 256 MB per stream (gspx_bench_streams): reads : writes 1:0, 1:1, 3:1 - the 1:1 pair is
-            # what tells slow cards from fast ones where read-only and copy rates do not (profiles/r06_placement.md)
+            # plain stream mixes, 256 MB per stream (gspx_bench_streams): reads : writes 1:0, 1:1, 3:1 - like the read-only
+            # and copy rates they are the same in fast and slow memory zones (profiles/r06_placement.md): the box's
+            # plain bandwidth, beside which the step's own figure is read
             mix["streams"] = {"r{}w{}".format(nr, nw): ctx.bench_streams(256 << 20, nr, nw, 0, 8, 3)
                               for nr, nw in ((1, 0), (1, 1), (3, 1))}
         except Exception as e:  # a calibration: never a reason to lose the measurement

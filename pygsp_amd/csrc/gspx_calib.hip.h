@@ -91,8 +91,9 @@ __global__ __launch_bounds__(256) void k_bench_gather(const uint4* __restrict__ 
 // Stream mix (round 6): NR read streams and NW write streams of `n4` 16-byte pieces each, walked together by a
 // persistent grid - what the memory system delivers to a given read : write ratio with nothing else in the way.  The
 // recurrence step is such a mix (T_{k-1} tiles, T_{k-2}, accumulator and entries in; T_k and the accumulator out: 3.6 : 1
-// on a plain step, 2.3 : 1 on a flush step), and boxes that agree on a read-only stream and on a 1 : 1 copy differ by
-// 10 % on it (profiles/r06_placement.md).  nt: bit 0 non-temporal loads, bit 1 non-temporal stores.
+// on a plain step, 2.3 : 1 on a flush step); these plain mixes run the same in the memory zones where the step runs
+// 10 % apart (profiles/r06_placement.md) - they give the box's plain rates.  nt: bit 0 non-temporal loads, bit 1
+// non-temporal stores.
 template <int NR, int NW>
 __global__ __launch_bounds__(256) void k_bench_streams(const u32x4* __restrict__ rd, u32x4* __restrict__ wr, size_t n4,
                                                        int nt, unsigned* __restrict__ sink) {

@@ -35,8 +35,11 @@ for r in range(rounds):
             ms.append(t["steps_ms"] / t["step_launches"])
     b_launch = dev.nnz_l * 12 + 4 * (G.N + 1) + 3 * U + U / 30
     med = float(np.median(ms))
+    # plain stream mixes on buffers allocated at the same depth (gspx_bench_streams allocates its own): do they see the zone?
+    st = {k: round(ctx.bench_streams(256 << 20, nr, nw, 0, 8, 3)) for k, (nr, nw) in
+          (("r1w1", (1, 1)), ("r3w1", (3, 1)), ("r1w0", (1, 0)), ("r0w1", (0, 1)))} if os.environ.get("ZONE_STREAMS") else {}
     print(json.dumps({"round": r, "GB_allocated_before": round(held_gb, 1), "launch_ms": round(med, 4),
-                      "frac": round(b_launch / (med * 1e-3) / 8e12, 4)}), flush=True)
+                      "frac": round(b_launch / (med * 1e-3) / 8e12, 4), **st}), flush=True)
     keep.append((ctx, G, dev))
     held_gb += 1.9
     try:
