@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_bench_gather(const uint4* __restrict__ 
 // recurrence step is such a mix (T_{k-1} tiles, T_{k-2}, accumulator and entries in; T_k and the accumulator out: 3.6 : 1
 // on a plain step, 2.3 : 1 on a flush step); these plain mixes run the same in the memory zones where the step runs
 // 10 % apart (profiles/r06_placement.md) - they give the box's plain rates.  nt: bit 0 non-temporal loads, bit 1
-// non-temporal stores.
+// non-temporal stores, bit 2 write stream w goes IN PLACE over read stream w (the recurrence's T_{k-2} -> T_k).
 template <int NR, int NW>
 __global__ __launch_bounds__(256) void k_bench_streams(const u32x4* __restrict__ rd, u32x4* __restrict__ wr, size_t n4,
                                                        int nt, unsigned* __restrict__ sink) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_bench_streams(const u32x4* __restrict__
     }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      u32x4* dst = wr + (size_t)w * n4 + i;
+      u32x4* dst = ((nt & 4) && w < NR) ? (u32x4*)rd + (size_t)w * n4 + i : wr + (size_t)w * n4 + i;  // bit 2: in place
       if (nt & 2) __builtin_nontemporal_store(o, dst);
       else *dst = o;
     }
@@ -143,7 +143,7 @@ static void launch_bench_streams(int nw, dim3 grid, hipStream_t st, const gspx::
 extern "C" int gspx_bench_streams(gspx_ctx* ctx, int64_t bytes_per_stream, int n_read, int n_write, int nt,
                                   int workgroups_per_cu, int iters, double* gbps) {
   if (!ctx || !gbps || bytes_per_stream < 4096 || n_read < 0 || n_read > 4 || n_write < 0 || n_write > 2 ||
-      n_read + n_write < 1 || iters < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 16 || nt < 0 || nt > 3)
+      n_read + n_write < 1 || iters < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 16 || nt < 0 || nt > 7)
     return set_err(GSPX_ERR_INVALID, "gspx_bench_streams: bad argument (0-4 read streams, 0-2 write streams)");
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;

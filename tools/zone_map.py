@@ -38,6 +38,10 @@ for r in range(rounds):
     # plain stream mixes on buffers allocated at the same depth (gspx_bench_streams allocates its own): do they see the zone?
     st = {k: round(ctx.bench_streams(256 << 20, nr, nw, 0, 8, 3)) for k, (nr, nw) in
           (("r1w1", (1, 1)), ("r3w1", (3, 1)), ("r1w0", (1, 0)), ("r0w1", (0, 1)))} if os.environ.get("ZONE_STREAMS") else {}
+    if os.environ.get("ZONE_STREAMS"):  # in place (the recurrence's T_{k-2} -> T_k), 512 MB streams like the headline's panels
+        st["r1w1_inplace"] = round(ctx.bench_streams(512 << 20, 1, 1, 4, 8, 3))
+        st["r2w1_inplace"] = round(ctx.bench_streams(512 << 20, 2, 1, 4, 8, 3))
+        st["r3w2_inplace"] = round(ctx.bench_streams(512 << 20, 3, 2, 4, 8, 3))
     print(json.dumps({"round": r, "GB_allocated_before": round(held_gb, 1), "launch_ms": round(med, 4),
                       "frac": round(b_launch / (med * 1e-3) / 8e12, 4), **st}), flush=True)
     keep.append((ctx, G, dev))
