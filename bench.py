@@ -78,10 +78,10 @@ def parse():
     p.add_argument("--no-gather", action="store_true")
     p.add_argument("--no-newton", action="store_true")
     p.add_argument("--no-mix", action="store_true", help="skip the mix-ceiling calibration (gspx_bench_step_mix)")
-    p.add_argument("--tune-candidates", type=int, default=24,
+    p.add_argument("--tune-candidates", type=int, default=32,
                    help="set-up: physical backings of the streamed workspaces drawn by DeviceGraph.tune_placement, the "
                         "fastest kept (0: none; profiles/r06_placement.md)")
-    p.add_argument("--tune-stride-mb", type=int, default=10000,
+    p.add_argument("--tune-stride-mb", type=int, default=8000,
                    help="set-up: device memory held between two draws of the placement tuning, so that the candidates "
                         "sample the card's memory at that stride (fast and slow pages come in zones of tens of GB)")
     p.add_argument("--no-e2e", action="store_true", help="skip the numpy-in/numpy-out leg (profiling passes)")

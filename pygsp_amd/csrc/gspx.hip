@@ -3072,6 +3072,18 @@ extern "C" int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const 
         }
       }
     }
+    {  // room for a third panel in the candidate's T workspace, drawn from the same place: the Newton evaluation of the
+       // same call (evaluation='auto') keeps three panels there and would otherwise grow the winner by one panel from
+       // wherever the allocator stands after the search
+      const size_t panel = (size_t)g->N * (size_t)Nsig * elt_size(g->dtype);
+      if (panel < ((size_t)1 << 31) && ctx->ws_t.ensure(3 * panel + 256) != GSPX_OK && best >= 0) {
+        ctx->ws_t.swap(best_t);  // memory exhausted: the search ends here with the best so far
+        ctx->ws_r.swap(best_r);
+        out[candidates] = (double)best;
+        replay_reset(ctx);
+        return gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, nullptr);
+      }
+    }
     double ms = 0;
     for (int rep = 0; rep < 3; ++rep) {  // the caller's own call: the first run allocates, the best of the next two counts
       const int rc = gspx_cheby_filter_dev(g, lmax, 1, M, coeffs, Nsig, x_dev, y_dev, GSPX_ANALYSIS, nullptr);

@@ -663,3 +663,14 @@ def test_mix_ceiling_calibration_runs_beside_the_filter(ctx, dtype, nsig):
         ctx.set_option("calib_mix", 1)
     bx.free()
     by.free()
+
+
+def test_stream_mix_calibration(ctx):
+    """gspx_bench_streams (round 6): n read + m write streams walked together, optionally non-temporal or in place - a
+    calibration whose only contract is a positive rate below the chip's peak and the refusal of bad arguments."""
+    for nr, nw, nt in ((1, 0, 0), (0, 1, 0), (1, 1, 0), (3, 1, 0), (4, 2, 3), (1, 1, 4), (3, 2, 4)):
+        v = ctx.bench_streams(64 << 20, nr, nw, nt, 8, 2)
+        assert 500 < v < 16000, (nr, nw, nt, v)
+    for bad in ((0, 0, 0), (5, 0, 0), (1, 3, 0), (1, 1, 8)):
+        with pytest.raises(ValueError):
+            ctx.bench_streams(64 << 20, *bad)
