@@ -93,13 +93,30 @@ __global__ __launch_bounds__(256) void k_bench_gather(const uint4* __restrict__ 
 // recurrence step is such a mix (T_{k-1} tiles, T_{k-2}, accumulator and entries in; T_k and the accumulator out: 3.6 : 1
 // on a plain step, 2.3 : 1 on a flush step); these plain mixes run the same in the memory zones where the step runs
 // 10 % apart (profiles/r06_placement.md) - they give the box's plain rates.  nt: bit 0 non-temporal loads, bit 1
-// non-temporal stores, bit 2 write stream w goes IN PLACE over read stream w (the recurrence's T_{k-2} -> T_k).
+// non-temporal stores, bit 2 write stream w goes IN PLACE over read stream w (the recurrence's T_{k-2} -> T_k), bit 3 the
+// step's walk (XCD-partitioned 32 KB blocks) instead of a grid-stride sweep.
 template <int NR, int NW>
 __global__ __launch_bounds__(256) void k_bench_streams(const u32x4* __restrict__ rd, u32x4* __restrict__ wr, size_t n4,
                                                        int nt, unsigned* __restrict__ sink) {
   const size_t stride = (size_t)gridDim.x * 256;
   u32x4 acc = {0u, 0u, 0u, 0u};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+  // bit 3: the WALK of the recurrence step instead of a grid-stride sweep - workgroup w belongs to "XCD" w % 8 and takes
+  // 32 KB blocks of that XCD's eighth of every stream, strided over the XCD's workgroups: hundreds of separate 32 KB
+  // regions of every stream are open at any time instead of one moving window
+  const bool walk = (nt & 8) != 0;
+  const size_t per_xcd = n4 / 8, nwx = gridDim.x >> 3, wx = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  constexpr size_t BLK = 2048;  // 16-byte pieces of a block
+  const size_t total = walk ? (per_xcd / BLK + nwx - 1) / nwx * (BLK / 256) : (n4 + stride - 1) / stride;
+  for (size_t it = 0; it < total; ++it) {
+    size_t i;
+    if (walk) {
+      const size_t blk = wx + (it / (BLK / 256)) * nwx;
+      i = xcd * per_xcd + blk * BLK + (it % (BLK / 256)) * 256 + threadIdx.x;
+      if (blk * BLK >= per_xcd) break;
+    } else {
+      i = (size_t)blockIdx.x * 256 + threadIdx.x + it * stride;
+      if (i >= n4) break;
+    }
     u32x4 v[NR > 0 ? NR : 1];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -143,7 +160,7 @@ static void launch_bench_streams(int nw, dim3 grid, hipStream_t st, const gspx::
 extern "C" int gspx_bench_streams(gspx_ctx* ctx, int64_t bytes_per_stream, int n_read, int n_write, int nt,
                                   int workgroups_per_cu, int iters, double* gbps) {
   if (!ctx || !gbps || bytes_per_stream < 4096 || n_read < 0 || n_read > 4 || n_write < 0 || n_write > 2 ||
-      n_read + n_write < 1 || iters < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 16 || nt < 0 || nt > 7)
+      n_read + n_write < 1 || iters < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 16 || nt < 0 || nt > 15)
     return set_err(GSPX_ERR_INVALID, "gspx_bench_streams: bad argument (0-4 read streams, 0-2 write streams)");
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;

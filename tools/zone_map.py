@@ -42,6 +42,13 @@ for r in range(rounds):
         st["r1w1_inplace"] = round(ctx.bench_streams(512 << 20, 1, 1, 4, 8, 3))
         st["r2w1_inplace"] = round(ctx.bench_streams(512 << 20, 2, 1, 4, 8, 3))
         st["r3w2_inplace"] = round(ctx.bench_streams(512 << 20, 3, 2, 4, 8, 3))
+        # ... and with the step's walk: 2 workgroups per CU, XCD-partitioned 32 KB blocks
+        st["r2w1_inplace_walk"] = round(ctx.bench_streams(512 << 20, 2, 1, 12, 2, 3))
+        st["r3w2_inplace_walk"] = round(ctx.bench_streams(512 << 20, 3, 2, 12, 2, 3))
+        st["r3w1_walk"] = round(ctx.bench_streams(512 << 20, 3, 1, 8, 2, 3))
+        # random gathers of 512-byte rows from a 512 MB panel allocated at this depth (gspx_bench_gather)
+        st["gather512"] = round(ctx.bench_gather(1000000, 512, 8000000, 8, 1, 0.0, 8, 3)[1])
+        st["gather256"] = round(ctx.bench_gather(2000000, 256, 16000000, 8, 1, 0.0, 8, 3)[1])
     print(json.dumps({"round": r, "GB_allocated_before": round(held_gb, 1), "launch_ms": round(med, 4),
                       "frac": round(b_launch / (med * 1e-3) / 8e12, 4), **st}), flush=True)
     keep.append((ctx, G, dev))
