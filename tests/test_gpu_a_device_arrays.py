@@ -334,3 +334,41 @@ def test_plugin_wrap_in_float32_and_with_a_device_list():
         plugin.uninstall(fake)
         plugin.install(fake)  # back to the single-device float64 configuration for whatever runs next
         plugin.uninstall(fake)
+
+
+def test_plugin_auto_evaluation_and_placement_tuning(monkeypatch):
+    """The two opt-ins of round 6 through the seam of a pygsp-shaped package: install(evaluation='auto') runs a single
+    filter's analysis in Newton form when the panel is large and the guard clears the polynomial (the recurrence
+    otherwise: banks, synthesis, small panels), to rounding of the reference's result; plugin.tune_placement draws
+    candidate backings for the work panels with the bank's own coefficients and leaves results bit-identical."""
+    from pygsp_amd import plugin
+
+    G0 = graphs.Sensor(60000, k=6, seed=9)
+    W = G0.W
+    lmax = upper_lmax(W)
+    fake = pygsp_like(W, lmax)
+    G = fake.RefGraph()
+    heat = fake.filters.Filter(G, [orc.heat_kernel(20, lmax)])
+    bank = fake.filters.Filter(G, orc.mexican_hat_kernels(lmax, 3))
+    x = np.random.default_rng(3).standard_normal((G.N, 64))
+    ref = orc.cheby_op(G.L, lmax, orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, 30), x[:, :2])
+    try:
+        plugin.install(fake, evaluation="auto")
+        monkeypatch.setattr(filters, "AUTO_MIN_PANEL_BYTES", 1 << 20)  # (60k x 64 fp64 = 30 MB: "large" for this test)
+        y_auto = heat.filter(x, order=30)
+        assert G._gspx_last_evaluation == "newton" and rel_err(y_auto[:, :2], ref) < 1e-11
+        bank.filter(x[:, :4], order=20)
+        assert G._gspx_last_evaluation == "recurrence"  # a bank keeps the reference's recurrence
+        plugin.install(fake)  # evaluation back to the default
+        y_rec = heat.filter(x, order=30)
+        assert G._gspx_last_evaluation == "recurrence" and rel_err(y_rec[:, :2], ref) < 1e-11
+        rep = plugin.tune_placement(heat, 64, order=30, candidates=3, stride_mb=256)
+        assert len(rep["launch_ms"]) == 3 and rep["kept"] in (0, 1, 2)
+        assert np.array_equal(heat.filter(x, order=30), y_rec)
+        with pytest.raises(ValueError, match="single-filter"):
+            plugin.tune_placement(bank, 64)
+        with pytest.raises(ValueError, match="evaluation must be"):
+            plugin.install(fake, evaluation="horner")
+    finally:
+        monkeypatch.undo()
+        plugin.uninstall(fake)
