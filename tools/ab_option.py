@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of ONE context option on the headline call, alternating in one process on one box:
-    python tools/ab_option.py tile_chunk_major 0 1 [f64|f32] [nsig]
+    python tools/ab_option.py alternate_sweep 0 1 [f64|f32] [nsig]
 prints per value the median step-launch time, its fraction of 8 TB/s and a checksum of the result."""
 import json
 import os
