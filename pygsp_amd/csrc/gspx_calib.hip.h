@@ -160,25 +160,33 @@ static void launch_bench_streams(int nw, dim3 grid, hipStream_t st, const gspx::
 extern "C" int gspx_bench_streams(gspx_ctx* ctx, int64_t bytes_per_stream, int n_read, int n_write, int nt,
                                   int workgroups_per_cu, int iters, double* gbps) {
   if (!ctx || !gbps || bytes_per_stream < 4096 || n_read < 0 || n_read > 4 || n_write < 0 || n_write > 2 ||
-      n_read + n_write < 1 || iters < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 16 || nt < 0 || nt > 15)
+      n_read + n_write < 1 || iters < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 16 || nt < 0 || nt > 31)
     return set_err(GSPX_ERR_INVALID, "gspx_bench_streams: bad argument (0-4 read streams, 0-2 write streams)");
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const size_t n4 = (size_t)bytes_per_stream / 16;
   DevMem rd, wr, sink;
-  CHK(rd.alloc(std::max<size_t>(n4 * 16 * (size_t)n_read, 64)));
-  CHK(wr.alloc(std::max<size_t>(n4 * 16 * (size_t)n_write, 64)));
+  const bool in_ws = (nt & 16) != 0;  // bit 4: the streams lie in the context's T workspace (whatever backs it) instead of
+  if (in_ws) {                        // fresh allocations - the memory the recurrence itself streams
+    if (!ctx->ws_t.p || ctx->ws_t.bytes < n4 * 16 * (size_t)(n_read + n_write))
+      return set_err(GSPX_ERR_INVALID, "gspx_bench_streams: the context's workspace is smaller than the streams");
+  } else {
+    CHK(rd.alloc(std::max<size_t>(n4 * 16 * (size_t)n_read, 64)));
+    CHK(wr.alloc(std::max<size_t>(n4 * 16 * (size_t)n_write, 64)));
+  }
   CHK(sink.alloc(64));
+  const gspx::u32x4* rdp = in_ws ? (const gspx::u32x4*)ctx->ws_t.p : (const gspx::u32x4*)rd.p;
+  gspx::u32x4* wrp = in_ws ? (gspx::u32x4*)ctx->ws_t.p + n4 * (size_t)n_read : (gspx::u32x4*)wr.p;
   if (n_read)
-    hipLaunchKernelGGL((k_fill<float>), dim3(4096), dim3(256), 0, st, rd.as<float>(), n4 * 4 * (size_t)n_read, 1.0f);
+    hipLaunchKernelGGL((k_fill<float>), dim3(4096), dim3(256), 0, st, (float*)rdp, n4 * 4 * (size_t)n_read, 1.0f);
   const dim3 grid((unsigned)(ctx->cu_count * workgroups_per_cu));
   auto launch = [&]() {
     switch (n_read) {
-      case 0: launch_bench_streams<0>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
-      case 1: launch_bench_streams<1>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
-      case 2: launch_bench_streams<2>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
-      case 3: launch_bench_streams<3>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
-      default: launch_bench_streams<4>(n_write, grid, st, (const gspx::u32x4*)rd.p, (gspx::u32x4*)wr.p, n4, nt, sink.as<unsigned>()); break;
+      case 0: launch_bench_streams<0>(n_write, grid, st, rdp, wrp, n4, nt & 15, sink.as<unsigned>()); break;
+      case 1: launch_bench_streams<1>(n_write, grid, st, rdp, wrp, n4, nt & 15, sink.as<unsigned>()); break;
+      case 2: launch_bench_streams<2>(n_write, grid, st, rdp, wrp, n4, nt & 15, sink.as<unsigned>()); break;
+      case 3: launch_bench_streams<3>(n_write, grid, st, rdp, wrp, n4, nt & 15, sink.as<unsigned>()); break;
+      default: launch_bench_streams<4>(n_write, grid, st, rdp, wrp, n4, nt & 15, sink.as<unsigned>()); break;
     }
   };
   launch();  // warm-up

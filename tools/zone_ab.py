@@ -68,6 +68,24 @@ def both(label, setup=None, nsig=64, mix=0):
 
 
 both("default")
+
+
+def streams_both(label, nr, nw, nt, wg=8, mb=256):
+    row = {"what": label}
+    for name, (_, r, ctx, G, dev, c) in (("fast", fast), ("slow", slow)):
+        row[name] = round(ctx.bench_streams(mb << 20, nr, nw, nt, wg, 4))
+    row["fast_over_slow"] = round(row["fast"] / row["slow"], 3)
+    print(json.dumps(row), flush=True)
+
+
+# plain streams INSIDE each context's own T workspace (gspx_bench_streams bit 4): is it the memory or the step's pattern?
+streams_both("streams in the workspace: write only (GB/s)", 0, 1, 16)
+streams_both("streams in the workspace: read only", 1, 0, 16)
+streams_both("streams in the workspace: 1 read + 1 write", 1, 1, 16)
+streams_both("streams in the workspace: 2 reads + 1 write in place", 2, 1, 16 + 4)
+streams_both("streams in the workspace: write only, the step's walk, 2 workgroups per CU", 0, 1, 16 + 8, 2)
+streams_both("streams in the workspace: 2 writes", 0, 2, 16)
+streams_both("fresh allocations: write only", 0, 1, 0)
 both("mix kernel (no row products)", mix=1)
 both("mix kernel, no barriers", mix=2)
 for nt in (0, 1, 2, 4, 8, 5, 10, 15):
