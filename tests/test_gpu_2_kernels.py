@@ -666,11 +666,18 @@ def test_mix_ceiling_calibration_runs_beside_the_filter(ctx, dtype, nsig):
 
 
 def test_stream_mix_calibration(ctx):
-    """gspx_bench_streams (round 6): n read + m write streams walked together, optionally non-temporal or in place - a
-    calibration whose only contract is a positive rate below the chip's peak and the refusal of bad arguments."""
+    """gspx_bench_streams (round 6): n read + m write streams walked together, optionally non-temporal, in place, in the
+    step's walk or inside the context's own workspace - a calibration whose only contract is a positive rate below the
+    chip's peak and the refusal of bad arguments."""
+    fresh = engine.Context(0)
+    try:  # bit 4: the streams lie in the context's T workspace - a context that has none yet refuses
+        with pytest.raises(ValueError, match="workspace"):
+            fresh.bench_streams(64 << 20, 1, 1, 16, 8, 2)
+    finally:
+        fresh.close()
     for nr, nw, nt in ((1, 0, 0), (0, 1, 0), (1, 1, 0), (3, 1, 0), (4, 2, 3), (1, 1, 4), (3, 2, 4), (2, 1, 12), (3, 1, 8)):
         v = ctx.bench_streams(64 << 20, nr, nw, nt, 8, 2)
         assert 500 < v < 16000, (nr, nw, nt, v)
-    for bad in ((0, 0, 0), (5, 0, 0), (1, 3, 0), (1, 1, 16)):
+    for bad in ((0, 0, 0), (5, 0, 0), (1, 3, 0), (1, 1, 32)):
         with pytest.raises(ValueError):
             ctx.bench_streams(64 << 20, *bad)
