@@ -562,12 +562,17 @@ def headline_other_dtype(a, ctx, G, c, x, lmax, dtype, oracle=True):
         from pygsp_amd import filters
         newton_ms = y_newton = None
         auto = filters.choose_evaluation("auto", np.atleast_2d(c[0]), dtype, N, nsig)
-        if auto == "newton" and not a.no_newton:
-            nodes, dcoef = filters.cheb_to_newton(c[0])
-            dev.newton_filter_dev(nodes, dcoef, bx.ptr, by.ptr, nsig, lmax)
+        if auto in ("newton", "product") and not a.no_newton:
+            if auto == "newton":
+                nodes, dcoef = filters.cheb_to_newton(c[0])
+                run_auto = lambda: dev.newton_filter_dev(nodes, dcoef, bx.ptr, by.ptr, nsig, lmax)  # noqa: E731
+            else:
+                program = filters.cheb_to_product(c[0], dtype)
+                run_auto = lambda: dev.program_filter_dev(program, bx.ptr, by.ptr, nsig, lmax)  # noqa: E731
+            run_auto()
             n_ms = 0.0
             for _ in range(max(3, a.steps // 2)):
-                dev.newton_filter_dev(nodes, dcoef, bx.ptr, by.ptr, nsig, lmax)
+                run_auto()
                 n_ms += ctx.last_timing()["steps_ms"]
             newton_ms = n_ms / (max(3, a.steps // 2) * K)
             y_newton = by.download(xs.shape, dtype)[:, :2]
@@ -603,9 +608,10 @@ def headline_other_dtype(a, ctx, G, c, x, lmax, dtype, oracle=True):
            "note": "same graph, coefficients and signals as the headline, computed in this dtype (its own device "
                    "Laplacian and tiles); roofline from the HIP-event time of the recurrence launches"}
     res["auto_evaluation"] = auto
-    if newton_ms is not None:
-        res["newton_form"] = {"ms_per_order": newton_ms, "frac_of_8TBps": b_launch / (newton_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "guard": filters.newton_guard(c[0], dtype)[1]}
+    if newton_ms is not None:  # (key kept from round 5: the evaluation 'auto' picked, Newton or product form)
+        res["newton_form"] = {"evaluation": auto, "ms_per_order": newton_ms,
+                              "frac_of_8TBps": b_launch / (newton_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "guard": (filters.newton_guard if auto == "newton" else filters.product_guard)(c[0], dtype)[1]}
     if mix is not None and "error" not in mix:
         res["roofline"].update(mix_launch_ms=mix[1], mix_nobarrier_launch_ms=mix[2], step_launch_ms_beside_mix=mix["real"],
                                frac_of_mix_ceiling=mix[1] / mix["real"],
@@ -1213,6 +1219,12 @@ def main():
     def step_newton():
         return dev.newton_filter_dev(nodes, dcoef, bx.ptr, y_ptr, nsig, lmax)
 
+    product_ok, product_guard = filters.product_guard(c[0], dtype)
+    program = filters.cheb_to_product(c[0], dtype) if product_guard.get("finite") else None
+
+    def step_product():
+        return dev.program_filter_dev(program, bx.ptr, y_ptr, nsig, lmax)
+
     step = step_newton if a.evaluation == "newton" else step_recurrence
 
     def download_y():  # this rank's output block as a host array (N, nsig)
@@ -1250,14 +1262,14 @@ def main():
         steps_ms_max = steps_ms
 
     # ---- same polynomial in Newton form (extra, reported separately; not the headline) ----------
-    def time_newton():
+    def time_form(step_form):
         for _ in range(a.warmup):
-            step_newton()
+            step_form()
         fence()
         tn = time.perf_counter()
         n_ms = 0.0
         for _ in range(a.steps):
-            step_newton()
+            step_form()
             n_ms += ctx.last_timing()["steps_ms"]
         fence()
         n_elapsed = time.perf_counter() - tn
@@ -1265,11 +1277,15 @@ def main():
             n_elapsed = gdist.max_over_ranks(n_elapsed, rdev)
         return n_elapsed, n_ms
 
-    newton = y_newton = None
+    newton = y_newton = product = y_product = None
     if a.evaluation == "recurrence" and not a.no_newton:
-        newton = time_newton()
+        newton = time_form(step_newton)
         if rank == 0 and not a.no_cpu:  # its result, for the parity leg below (the recurrence overwrites y next)
             y_newton = download_y()[:, :min(a.cpu_cols, nsig)].copy()
+        if program is not None:  # ... and as the product of its factors over its roots (filters.cheb_to_product)
+            product = time_form(step_product)
+            if rank == 0 and not a.no_cpu:
+                y_product = download_y()[:, :min(a.cpu_cols, nsig)].copy()
     # ---- the mix ceiling of the recurrence step on THIS box (VERDICT r5 "Next 1"): the same call with the row
     # products removed from every launch (gspx_bench_step_mix: same grid, LDS-DMA tile loads, T_{k-2} / accumulator
     # loads, entry stream, stores, flushes and cache bits), mode 1 with the pass barriers, mode 2 without; real calls
@@ -1307,7 +1323,7 @@ def main():
                               for nr, nw in ((1, 0), (1, 1), (3, 1))}
         except Exception as e:  # a calibration: never a reason to lose the measurement
             mix = {"error": repr(e)}
-    if newton is not None or mix is not None:
+    if newton is not None or product is not None or mix is not None:
         step_recurrence()  # leave the headline result in y for the parity check / the gather below
         fence()
 
@@ -1410,12 +1426,18 @@ def main():
 
     tiled = bool(G.tile_stats and G.tile_stats.get("enabled"))
 
-    def newton_report(r):
+    def form_report(r, form):
         ms_order = r[1] / (K * a.steps)
-        guard_ok, guard = filters.newton_guard(c[0], dtype)
+        guard_ok, guard = (filters.newton_guard(c[0], dtype) if form == "newton" else (product_ok, product_guard))
         out = {"note": ("same interpolating polynomial in Newton form (two-term Horner recurrence, no accumulator): "
-                        "evaluation='newton', and what evaluation='auto' runs for this call when the host-side "
-                        "guard clears the polynomial (filters.newton_guard); parity_vs_oracle below is of THIS run"),
+                        "evaluation='newton', what evaluation='auto' runs for this call when the product form is refused "
+                        "and filters.newton_guard clears the polynomial; parity_vs_oracle below is of THIS run")
+               if form == "newton" else
+                       ("same polynomial as the product of its factors over its roots (filters.cheb_to_product: a real "
+                        "root is one step - gather h, write h': two panel passes -, a conjugate pair two steps; "
+                        "guard.panel_passes_per_order against 3 2/3 of the recurrence): evaluation='product', what "
+                        "evaluation='auto' runs for this call when filters.product_guard clears the polynomial; "
+                        "ms_per_order is per order of the polynomial (K), not per launch"),
                "guard_ok": guard_ok, "guard": guard,
                "auto_picks": filters.choose_evaluation("auto", np.atleast_2d(c[0]), dtype, N, nsig),
                "value": world * N * nsig * K * a.steps / r[0], "ms_per_step": r[0] / a.steps * 1e3,
@@ -1521,7 +1543,8 @@ def main():
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "avg_launch_ms": avg_launch_ms, "launches_timed": launches,
             },
-            "newton_form": None if newton is None else newton_report(newton),
+            "newton_form": None if newton is None else form_report(newton, "newton"),
+            "product_form": None if product is None else form_report(product, "product"),
             "device_ms_per_step": dev_ms / a.steps,
             "device_ms_recurrence_per_step": steps_ms_max / a.steps,
             "gather_ms": gather_ms, "gather_impl": gather_impl,
@@ -1636,10 +1659,11 @@ def main():
                                           "columns": cols, "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
         out["parity_vs_oracle"] = {"max_rel_err": err, "columns": cols,
                                    "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
-        if y_newton is not None and out.get("newton_form"):  # the Newton evaluation of the same call, same oracle columns
-            out["newton_form"]["parity_vs_oracle"] = {
-                "max_rel_err": float(np.max(np.abs(y_newton[:, :cols] - ref)) / np.max(np.abs(ref))), "columns": cols,
-                "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
+        for key_, y_form in (("newton_form", y_newton), ("product_form", y_product)):  # the other evaluations of the
+            if y_form is not None and out.get(key_):                                  # same call, same oracle columns
+                out[key_]["parity_vs_oracle"] = {
+                    "max_rel_err": float(np.max(np.abs(y_form[:, :cols] - ref)) / np.max(np.abs(ref))), "columns": cols,
+                    "tolerance": 1e-5 if a.dtype == "f64" else 1e-3}
     # ---- the other BASELINE configs (N=1 only), appended after the headline keys ---------------------
     if rank == 0 and world == 1 and not a.no_configs:
         bx.free()
@@ -1670,16 +1694,24 @@ def main():
         rf["f32_frac_of_mix_ceiling"] = (f32.get("roofline") or {}).get("frac_of_mix_ceiling")
         rf["f32_mix_ceiling_frac"] = (f32.get("roofline") or {}).get("mix_ceiling_frac")
         rf["f32_auto_evaluation"] = f32.get("auto_evaluation")
-        rf["f32_auto_frac"] = ((f32.get("newton_form") or {}).get("frac_of_8TBps") if f32.get("auto_evaluation") == "newton"
-                               else rf["f32_frac"])
+        rf["f32_auto_frac"] = ((f32.get("newton_form") or {}).get("frac_of_8TBps")
+                               if f32.get("auto_evaluation") in ("newton", "product") else rf["f32_frac"])
         rf["f32_newton_parity_max_rel_err"] = ((f32.get("newton_form") or {}).get("parity_vs_oracle") or {}).get("max_rel_err")
         nf_ = out.get("newton_form") or {}
         rf["newton_frac"] = nf_.get("frac_of_8TBps")
         rf["newton_parity_max_rel_err"] = (nf_.get("parity_vs_oracle") or {}).get("max_rel_err")
         # what evaluation='auto' (plugin.install(evaluation='auto') / Filter.filter(..., evaluation='auto')) runs for this
         # very call, and the fraction it reaches: the Newton form when the guard clears it, else the recurrence
+        pf_ = out.get("product_form") or {}
+        rf["product_frac"] = pf_.get("frac_of_8TBps")
+        rf["product_parity_max_rel_err"] = (pf_.get("parity_vs_oracle") or {}).get("max_rel_err")
+        rf["product_panel_passes_per_order"] = (pf_.get("guard") or {}).get("panel_passes_per_order")
         rf["auto_evaluation"] = nf_.get("auto_picks")
-        rf["auto_frac"] = rf["newton_frac"] if nf_.get("auto_picks") == "newton" else (rf["frac"] if nf_ else None)
+        rf["auto_frac"] = (rf["product_frac"] if nf_.get("auto_picks") == "product" else
+                           rf["newton_frac"] if nf_.get("auto_picks") == "newton" else (rf["frac"] if nf_ else None))
+        rf["auto_parity_max_rel_err"] = (rf["product_parity_max_rel_err"] if nf_.get("auto_picks") == "product" else
+                                         rf["newton_parity_max_rel_err"] if nf_.get("auto_picks") == "newton" else
+                                         rf["parity_max_rel_err"])
         # the mix ceiling: what THIS box's memory system delivers to the step's own access mix with the arithmetic
         # removed (same launches, same bytes).  frac_of_mix_ceiling = mix time / step time of calls alternating in the
         # same minute (1.0: the step is bound by the memory system serving this mix, not by its row products);

@@ -28,6 +28,19 @@ int gspx_newton_filter_dev(gspx_graph* g, double lmax, int K, const double* node
 int gspx_newton_filter(gspx_graph* g, double lmax, int K, const double* nodes, const double* dcoef,
                        int64_t Nsig, const void* x_host, void* y_host, double* kernel_ms);
 
+/* A polynomial of the scaled operator t = (2 / lmax) L - I evaluated as a PROGRAM of S steps on N x Nsig panels:
+ *     h_0 = x;   h_{s+1} = scale_s * (2 t) h_s + beta_s * h_s + gamma_s * o_s;   y = h_S,
+ * o_s = x for every step (old_is_x != 0: the Newton form above is such a program) or o_s = h_{s-1} (old_is_x == 0, gamma_0
+ * ignored: the PRODUCT form - a real root r of the polynomial is one step with scale sigma / 2, beta -sigma r, gamma 0, which
+ * reads one panel and writes one; a conjugate pair a +- ib is two steps, the second with gamma sigma^2 b^2).  The same
+ * polynomial as approximations.py:93-112 evaluates when the program is built from its Chebyshev coefficients
+ * (pygsp_amd.filters.cheb_to_product, behind filters.product_guard): 2.2 - 2.5 panel passes per order instead of 3 2/3.
+ * Single filter, analysis.  _dev: device pointers; the other: host arrays.  S < 1 -> GSPX_ERR_COEFF. */
+int gspx_poly_program_dev(gspx_graph* g, double lmax, int S, const double* scale, const double* beta, const double* gamma,
+                          int old_is_x, int64_t Nsig, const void* x_dev, void* y_dev, double* kernel_ms);
+int gspx_poly_program(gspx_graph* g, double lmax, int S, const double* scale, const double* beta, const double* gamma,
+                      int old_is_x, int64_t Nsig, const void* x_host, void* y_host, double* kernel_ms);
+
 /* The internal padded CSR pattern (engine vertex order; rowptr low 2 bits = pad counts, pads have col == N): what
  * host-built tiles (pygsp_amd/tiling.py) are computed from. */
 int gspx_graph_download_internal(gspx_graph* g, int32_t* rowptr, int32_t* col);

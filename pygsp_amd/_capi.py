@@ -127,6 +127,10 @@ SIGNATURES = {
     "gspx_bench_gather": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_double, _c.c_int,
                                      _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "gspx_bench_copy": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.POINTER(_c.c_double)]),
+    "gspx_poly_program_dev": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int64, _P, _P,
+                                       _c.POINTER(_c.c_double)]),
+    "gspx_poly_program": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int64, _P, _P,
+                                   _c.POINTER(_c.c_double)]),
     "gspx_ctx_tune_placement": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _c.c_int64, _P, _P, _c.c_int, _c.c_int64, _P]),
     "gspx_bench_streams": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double)]),
     "gspx_bench_step_mix": (_c.c_int, [_P, _c.c_double, _c.c_int, _P, _c.c_int64, _P, _P, _c.c_int]),

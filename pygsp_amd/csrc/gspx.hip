@@ -2366,9 +2366,15 @@ static int run_batch_synthesis(gspx_graph* g, int nf, int M, const std::vector<d
 // the reference's Chebyshev coefficients (pygsp_amd/filters.py::cheb_to_newton), so the polynomial
 // is identical; results agree with the reference to ~1e-14 (fp64).
 // ------------------------------------------------------------------------------------------------
+// A polynomial PROGRAM on one batch of columns: h_0 = x (copied into the internal order), then S steps
+//     h_{s+1} = scale_s * (F h_s) + beta_s * h_s + gamma_s * o_s,
+// o_s = x for every step (old_is_x: the Newton form's Horner recurrence) or o_s = h_{s-1} (the product form's quadratic
+// factors; h_{s+1} then overwrites h_{s-1} in place, as the three-term recurrence does); the last step stores y.
+// F = (2/a1)(L - a2 I) has its spectrum in [-2, 2]: a factor (t - r) of a polynomial in t = F/2 is scale 1/2, beta -r.
+// A step whose gamma is 0 reads no third panel at all: gather h_s, write h_{s+1} - two panel passes.
 template <typename T>
-static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const double* dc, const T* x,
-                            unsigned ldx, T* y, unsigned ldy, unsigned ld, size_t& ev_idx) {
+static int run_batch_program(gspx_graph* g, int S, const double* sc, const double* be, const double* ga, bool old_is_x,
+                             const T* x, unsigned ldx, T* y, unsigned ldy, unsigned ld, size_t& ev_idx) {
   gspx_ctx* ctx = g->ctx;
   Options opt = ctx->opt;
   hipStream_t st = ctx->stream;
@@ -2380,13 +2386,14 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   const Shape shape = choose_shape(opt, sizeof(T), ld, veccap);
   const int* perm = g->has_perm ? g->perm.as<int>() : nullptr;
 
-  const T hw[3] = {T(1), T(0), T(0)};  // final step: y = 1 * h_0
+  const T hw[3] = {T(1), T(0), T(0)};  // final step of the plain kernels: y = 1 * h
   CHK(ctx->ws_w.ensure(sizeof(hw) + 64));
   HIPCHK(hipMemcpyAsync(ctx->ws_w.p, hw, sizeof(hw), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
-  CHK(ctx->ws_t.ensure(3 * U * sizeof(T) + 256));
+  // panels: X (h_0; kept for the whole call when every step reads it) and one or two more
+  CHK(ctx->ws_t.ensure((old_is_x ? 3 : 2) * U * sizeof(T) + 256));
   T* X = ctx->ws_t.as<T>();
-  T* H[2] = {X + U, X + 2 * U};
+  T* H[2] = {X + U, old_is_x ? X + 2 * U : X};  // product form: ping-pong between the second panel and X itself
 
   hipEvent_t e0 = pool_event(ctx, ++ev_idx), e1 = pool_event(ctx, ++ev_idx),
              e2 = pool_event(ctx, ++ev_idx), e3 = pool_event(ctx, ++ev_idx);
@@ -2411,52 +2418,40 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
   a.ldy = ldy;
   a.perm = perm;
   a.wts = ctx->ws_w.as<T>();
-  a.old = X;
-
-  auto step_params = [&](int s, T& sc, T& be, T& ga) {
-    const int j = K - 1 - s;
-    if (s == 0) {
-      sc = (T)(0.5 * dc[K]);
-      be = T(0);
-      ga = (T)(dc[j] - dc[K] * nodes[j]);
-    } else {
-      sc = T(0.5);
-      be = (T)(-nodes[j]);
-      ga = (T)dc[j];
-    }
-  };
   const bool tile_ok = tile_usable<T>(g, opt, ld, y, ldy);
-  for (int s = 0; s < K; ++s) {
-    const int j = K - 1 - s;
+  for (int s = 0; s < S; ++s) {
+    const bool last = s == S - 1;
+    const T* cur = (s == 0) ? X : H[(s - 1) & 1];
+    T* out = H[s & 1];
+    // o_s: x, or h_{s-1} - which lives in the panel this step writes (s >= 1: H[(s - 2) & 1] == H[s & 1]; s == 0 has none)
+    const T* old = old_is_x ? X : (const T*)out;
+    const double gam = (!old_is_x && s == 0) ? 0.0 : ga[s];
     if (tile_ok) {
       TileArgs<T> t{};
-      t.cur = (s == 0) ? X : H[(s - 1) & 1];
-      t.old = X;
-      t.out = H[s & 1];
+      t.cur = cur;
+      t.old = gam == 0.0 ? cur : old;
+      t.out = out;
       t.racc = H[0];  // never read or written (flush == 0)
       t.y = y;
       t.ldy = ldy;
       t.perm = perm;
-      step_params(s, t.scale, t.beta, t.gamma);
+      t.scale = (T)sc[s];
+      t.beta = (T)be[s];
+      t.gamma = (T)gam;
       t.flush = 0;
-      t.final = (j == 0) ? 1 : 0;
-      t.reverse = (opt.alternate_sweep && (j & 1)) ? 1 : 0;
+      t.final = last ? 1 : 0;
+      t.reverse = (opt.alternate_sweep && (s & 1)) ? 1 : 0;
       CHK(launch_step_tile<T>(g, opt, t, ld, st));
       continue;
     }
-    a.cur = (s == 0) ? X : H[(s - 1) & 1];
-    a.out = H[s & 1];
-    if (s == 0) {
-      a.scale = (T)(0.5 * dc[K]);
-      a.beta = T(0);
-      a.gamma = (T)(dc[j] - dc[K] * nodes[j]);
-    } else {
-      a.scale = T(0.5);
-      a.beta = (T)(-nodes[j]);
-      a.gamma = (T)dc[j];
-    }
-    a.flush = (j == 0) ? 1 : 0;
-    a.final = (j == 0) ? 1 : 0;
+    a.cur = cur;
+    a.old = gam == 0.0 ? cur : old;
+    a.out = out;
+    a.scale = (T)sc[s];
+    a.beta = (T)be[s];
+    a.gamma = (T)gam;
+    a.flush = last ? 1 : 0;
+    a.final = last ? 1 : 0;
     a.reverse = (opt.alternate_sweep && (s & 1)) ? 1 : 0;
     launch_step<T>(a, shape, opt, st, g->coff.as<unsigned>());
   }
@@ -2467,8 +2462,8 @@ static int run_batch_newton(gspx_graph* g, int K, const double* nodes, const dou
 }
 
 template <typename T>
-static int newton_dev_t(gspx_graph* g, double lmax, int K, const double* nodes, const double* dc,
-                        int64_t Nsig, const T* x, T* y) {
+static int program_dev_t(gspx_graph* g, double lmax, int S, const double* sc, const double* be, const double* ga,
+                         bool old_is_x, int64_t Nsig, const T* x, T* y) {
   gspx_ctx* ctx = g->ctx;
   const Options& opt = ctx->opt;
   const int64_t N = g->N;
@@ -2487,8 +2482,7 @@ static int newton_dev_t(gspx_graph* g, double lmax, int K, const double* nodes, 
   HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
   for (int64_t c0 = 0; c0 < Nsig; c0 += max_ld) {
     const unsigned ld = (unsigned)std::min<int64_t>(max_ld, Nsig - c0);
-    CHK(run_batch_newton<T>(g, K, nodes, dc, x + c0, (unsigned)Nsig, y + c0, (unsigned)Nsig, ld,
-                            ev_idx));
+    CHK(run_batch_program<T>(g, S, sc, be, ga, old_is_x, x + c0, (unsigned)Nsig, y + c0, (unsigned)Nsig, ld, ev_idx));
   }
   HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2504,8 +2498,80 @@ static int newton_dev_t(gspx_graph* g, double lmax, int K, const double* nodes, 
     t_steps += q;
   }
   ctx->timing[1] = t_steps;
-  ctx->timing[2] = (double)(ev_idx / 4) * K;
+  ctx->timing[2] = (double)(ev_idx / 4) * S;
   ctx->timing[3] = t_perm;
+  return GSPX_OK;
+}
+
+// the Newton form p(t) = sum_j d_j prod_{i<j} (t - r_i) by Horner, as a program: h <- (t - r_j) h + d_j x, j = K-1 .. 0
+template <typename T>
+static int newton_dev_t(gspx_graph* g, double lmax, int K, const double* nodes, const double* dc,
+                        int64_t Nsig, const T* x, T* y) {
+  std::vector<double> sc((size_t)K), be((size_t)K), ga((size_t)K);
+  for (int s = 0; s < K; ++s) {
+    const int j = K - 1 - s;
+    if (s == 0) {  // h_1 = d_K (t - r_{K-1}) x + d_{K-1} x
+      sc[0] = 0.5 * dc[K];
+      be[0] = 0.0;
+      ga[0] = dc[j] - dc[K] * nodes[j];
+    } else {
+      sc[(size_t)s] = 0.5;
+      be[(size_t)s] = -nodes[j];
+      ga[(size_t)s] = dc[j];
+    }
+  }
+  return program_dev_t<T>(g, lmax, K, sc.data(), be.data(), ga.data(), true, Nsig, x, y);
+}
+
+// A polynomial of the scaled operator t = (2 / lmax) L - I evaluated as a PROGRAM of S steps on device panels
+// (see run_batch_program): h_0 = x; h_{s+1} = scale_s (2 t) h_s + beta_s h_s + gamma_s o_s; y = h_S.  old_is_x != 0: o_s = x
+// (the Newton form); 0: o_s = h_{s-1}, gamma_0 ignored (the PRODUCT form: a real root r of the polynomial is one step
+// with scale sigma / 2, beta -sigma r, gamma 0 - two panel passes -, a conjugate pair a +- ib two steps, the second with
+// gamma sigma^2 b^2 - three passes).  pygsp_amd.filters.cheb_to_product builds such programs from Chebyshev coefficients.
+extern "C" int gspx_poly_program_dev(gspx_graph* g, double lmax, int S, const double* scale, const double* beta,
+                                     const double* gamma, int old_is_x, int64_t Nsig, const void* x_dev, void* y_dev,
+                                     double* kernel_ms) {
+  if (g) replay_reset(g->ctx);
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (S < 1) return set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape");
+  if (!scale || !beta || !gamma) return set_err(GSPX_ERR_INVALID, "null program");
+  if (Nsig < 0) return set_err(GSPX_ERR_INVALID, "negative number of signals");
+  if (!(lmax > 0.0) || !std::isfinite(lmax))
+    return set_err(GSPX_ERR_INVALID, "lmax must be positive and finite (got %g)", lmax);
+  if (Nsig > 0 && g->N > 0 && (!x_dev || !y_dev)) return set_err(GSPX_ERR_INVALID, "null signal pointer");
+  for (int i = 0; i < S; ++i)
+    if (!std::isfinite(scale[i]) || !std::isfinite(beta[i]) || !std::isfinite(gamma[i]))
+      return set_err(GSPX_ERR_INVALID, "non-finite program coefficient");
+  if (Nsig >= ((int64_t)1 << 31) / 16) return set_err(GSPX_ERR_INVALID, "too many signals");
+  HIPCHK(hipSetDevice(g->ctx->device));
+  int rc = g->dtype == GSPX_F32
+               ? program_dev_t<float>(g, lmax, S, scale, beta, gamma, old_is_x != 0, Nsig, (const float*)x_dev, (float*)y_dev)
+               : program_dev_t<double>(g, lmax, S, scale, beta, gamma, old_is_x != 0, Nsig, (const double*)x_dev,
+                                       (double*)y_dev);
+  if (rc == GSPX_OK && kernel_ms) *kernel_ms = g->ctx->timing[0];
+  return rc;
+}
+
+// ... and with host arrays (one copy in, the program, one copy out)
+extern "C" int gspx_poly_program(gspx_graph* g, double lmax, int S, const double* scale, const double* beta,
+                                 const double* gamma, int old_is_x, int64_t Nsig, const void* x_host, void* y_host,
+                                 double* kernel_ms) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (Nsig > 0 && g->N > 0 && (!x_host || !y_host)) return set_err(GSPX_ERR_INVALID, "null signal pointer");
+  gspx_ctx* ctx = g->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)g->N * (size_t)std::max<int64_t>(Nsig, 0) * elt_size(g->dtype);
+  if (n == 0) {
+    if (kernel_ms) *kernel_ms = 0;
+    return S < 1 ? set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape") : GSPX_OK;
+  }
+  CHK(ctx->io_x.ensure(n));
+  CHK(ctx->io_y.ensure(n));
+  HIPCHK(hipMemcpyAsync(ctx->io_x.p, x_host, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  CHK(gspx_poly_program_dev(g, lmax, S, scale, beta, gamma, old_is_x, Nsig, ctx->io_x.p, ctx->io_y.p, kernel_ms));
+  HIPCHK(hipMemcpyAsync(y_host, ctx->io_y.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return GSPX_OK;
 }
 

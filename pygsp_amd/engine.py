@@ -922,6 +922,30 @@ def _newton_methods():
             _capi.ptr(x), _capi.ptr(y), ctypes.byref(ms))
         return y, ms.value
 
+    def program_filter(self, program, x, lmax, old_is_x=False):
+        """A polynomial program (gspx_poly_program; filters.cheb_to_product builds the product form's): host arrays in /
+        out, x (N, Nsig) -> (N, Nsig).  program: (S, 3) rows of (scale, beta, gamma)."""
+        prog = np.ascontiguousarray(program, dtype=np.float64).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        if x.ndim != 2 or x.shape[0] != self.N:
+            raise ValueError("input must be (N, Nsig), got {}".format(x.shape))
+        y = np.empty_like(x)
+        ms = ctypes.c_double(0)
+        cols = [np.ascontiguousarray(prog[:, k]) for k in range(3)]
+        self.ctx.call(_capi.load().gspx_poly_program, self._h, float(lmax), int(prog.shape[0]), _capi.ptr(cols[0]),
+                      _capi.ptr(cols[1]), _capi.ptr(cols[2]), int(bool(old_is_x)), x.shape[1], _capi.ptr(x), _capi.ptr(y),
+                      ctypes.byref(ms))
+        return y, ms.value
+
+    def program_filter_dev(self, program, x_ptr, y_ptr, nsig, lmax, old_is_x=False):
+        prog = np.ascontiguousarray(program, dtype=np.float64).reshape(-1, 3)
+        cols = [np.ascontiguousarray(prog[:, k]) for k in range(3)]
+        ms = ctypes.c_double(0)
+        self.ctx.call(_capi.load().gspx_poly_program_dev, self._h, float(lmax), int(prog.shape[0]), _capi.ptr(cols[0]),
+                      _capi.ptr(cols[1]), _capi.ptr(cols[2]), int(bool(old_is_x)), int(nsig), ctypes.c_void_p(x_ptr),
+                      ctypes.c_void_p(y_ptr), ctypes.byref(ms))
+        return ms.value
+
     def newton_filter_dev(self, nodes, dcoef, x_ptr, y_ptr, nsig, lmax):
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
         dcoef = np.ascontiguousarray(dcoef, dtype=np.float64)
@@ -982,6 +1006,8 @@ def _newton_methods():
 
     DeviceGraph.newton_filter = newton_filter
     DeviceGraph.newton_filter_dev = newton_filter_dev
+    DeviceGraph.program_filter = program_filter
+    DeviceGraph.program_filter_dev = program_filter_dev
     DeviceGraph.download_internal = download_internal
     DeviceGraph.enable_gather_tiles = enable_gather_tiles
     DeviceGraph.disable_gather_tiles = disable_gather_tiles

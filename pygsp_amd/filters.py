@@ -71,10 +71,13 @@ def _quadrature_tables(m, points):
 #   'recurrence' - the reference's three-term Chebyshev recurrence (approximations.py:99-112); the default;
 #   'newton'     - the identical polynomial in Newton form on Leja-ordered Chebyshev nodes, by
 #                  Horner: a two-term recurrence, 3 instead of 3 2/3 panel passes per order;
-#   'auto'       - 'newton' for the calls where it is the faster evaluation AND newton_guard() clears the
-#                  polynomial for the compute dtype (one filter, analysis, one device, a panel beyond the
-#                  launch-bound sizes that replay as one hipGraph); the recurrence for everything else.
-EVALUATIONS = ("recurrence", "newton", "auto")
+#   'product'    - the identical polynomial as the product of its factors (t - r) over its roots, real roots one
+#                  step each (gather h, write h': 2 panel passes), conjugate pairs two steps (2 + 3 passes): 2.2 - 2.5
+#                  panel passes per order;
+#   'auto'       - 'product', else 'newton', for the calls where they are the faster evaluation AND product_guard() /
+#                  newton_guard() clears the polynomial for the compute dtype (one filter, analysis, one device, a
+#                  panel beyond the launch-bound sizes that replay as one hipGraph); the recurrence for everything else.
+EVALUATIONS = ("recurrence", "newton", "product", "auto")
 EVALUATION = "recurrence"
 AUTO_MIN_PANEL_BYTES = 32 << 20  # below: the recurrence replays as one hipGraph (gspx option graph_launch = 2)
 
@@ -82,7 +85,7 @@ AUTO_MIN_PANEL_BYTES = 32 << 20  # below: the recurrence replays as one hipGraph
 def set_evaluation(mode):
     global EVALUATION
     if mode not in EVALUATIONS:
-        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
+        raise ValueError("evaluation must be 'recurrence', 'newton', 'product' or 'auto'")
     EVALUATION = mode
 
 
@@ -247,14 +250,218 @@ def newton_guard(c, dtype=np.float64):
     return out
 
 
+_product_cache = {}
+
+
+def _leja_order_roots(points):
+    """Greedy Leja ordering of the factors' representatives (a real root, or the upper one of a conjugate pair - its
+    mirror counted with it): each next one maximises the product of distances to those chosen before."""
+    pts = np.asarray(points, dtype=np.complex128)
+    n = pts.size
+    order, left = [], list(range(n))
+    first = max(left, key=lambda i: abs(pts[i]))
+    order.append(first)
+    left.remove(first)
+    with np.errstate(divide="ignore"):
+        logp = {i: np.log(abs(pts[i] - pts[first])) + np.log(abs(pts[i] - np.conj(pts[first]))) for i in left}
+        while left:
+            i = max(left, key=lambda k: logp[k])
+            order.append(i)
+            left.remove(i)
+            for k in left:
+                logp[k] += np.log(abs(pts[k] - pts[i])) + np.log(abs(pts[k] - np.conj(pts[i])))
+    return order
+
+
+PRODUCT_TRIM = {np.dtype(np.float64): 1e-14, np.dtype(np.float32): 1e-9}
+
+
+def cheb_to_product(c, dtype=np.float64):
+    """Chebyshev coefficients c_0..c_K of p(t) = c_0/2 + sum_k c_k T_k(t) -> the PRODUCT-form program of the same
+    polynomial, an (S, 3) array of (scale, beta, gamma) rows for gspx_poly_program(old_is_x = 0):
+
+        p(t) = C prod_j sigma_j (t - r_j),      h_0 = x,  h_{s+1} = scale_s (2 t) h_s + beta_s h_s + gamma_s h_{s-1}
+
+    The roots are the eigenvalues of the colleague matrix (numpy.polynomial.chebyshev.chebroots, float64).  A real
+    root r is one step (sigma / 2, -sigma r, 0); a conjugate pair a +- ib two steps, (sigma / 2, -sigma a, 0) and
+    (sigma / 2, -sigma a, sigma^2 b^2): sigma^2 ((t - a)^2 + b^2).  sigma_j = 2 / |r_j + sqrt(r_j^2 - 1)| is the
+    logarithmic-capacity normalisation of the factor on [-1, 1] (the mean of log |sigma_j (t - r_j)| over the
+    Chebyshev measure is 0), so partial products neither grow nor vanish on average whatever the order; the constant
+    C = lead / prod sigma_j (formed in logarithms) rides on the first factor.  Factors are Leja-ordered.  Trailing
+    coefficients below PRODUCT_TRIM[dtype] of the largest are dropped first: a converged Chebyshev series ends in
+    rounding noise whose roots only add steps and error amplification (an order-200 Heat(50) is 41 factors, an
+    order-200 Heat(10) 21 - the polynomial moves by 1e-13 of its maximum, which product_guard() measures along with
+    everything else: its reference is the FULL polynomial)."""
+    from numpy.polynomial import chebyshev as npcheb
+    c = np.asarray(c, dtype=np.float64).ravel()
+    if c.size < 2:
+        raise TypeError("The coefficients have an invalid shape")
+    if not np.all(np.isfinite(c)):
+        raise ValueError("the Chebyshev coefficients must be finite")
+    trim = PRODUCT_TRIM.get(np.dtype(dtype), 1e-14)
+    key = c.tobytes() + np.dtype(dtype).str.encode()
+    hit = _product_cache.get(key)
+    if hit is not None:
+        return hit
+    cc = c.copy()
+    cc[0] /= 2
+    top = np.max(np.abs(cc))
+    K = cc.size - 1
+    while K > 1 and abs(cc[K]) <= trim * top:
+        K -= 1
+    cc = cc[:K + 1]
+    if cc[K] == 0.0:
+        raise ValueError("the polynomial is constant: no product form")
+    roots = npcheb.chebroots(cc)
+    lead_sign, lead_log = np.sign(cc[K]), np.log(abs(cc[K])) + (K - 1) * np.log(2.0)
+    reps, used = [], np.zeros(roots.size, dtype=bool)
+    for i, r in enumerate(roots):  # real roots and the upper member of every conjugate pair
+        if used[i]:
+            continue
+        used[i] = True
+        if abs(r.imag) <= 1e-11 * max(1.0, abs(r)):
+            reps.append(complex(r.real, 0.0))
+            continue
+        dist = np.where(used, np.inf, np.abs(roots - np.conj(r)))
+        j = int(np.argmin(dist))
+        if not np.isfinite(dist[j]) or dist[j] > 1e-6 * max(1.0, abs(r)):
+            raise ValueError("the roots of the polynomial do not pair up: no product form")
+        used[j] = True
+        reps.append(complex(0.5 * (r.real + roots[j].real), 0.5 * (abs(r.imag) + abs(roots[j].imag))))
+    reps = [reps[i] for i in _leja_order_roots(reps)]
+    rows, log_c = [], lead_log
+    for r in reps:
+        w = r + np.sqrt(r * r - 1)
+        if abs(w) < 1:
+            w = r - np.sqrt(r * r - 1)
+        sig = 2.0 / abs(w)
+        if r.imag == 0.0:
+            rows.append([0.5 * sig, -sig * r.real, 0.0])
+            log_c -= np.log(sig)
+        else:
+            rows.append([0.5 * sig, -sig * r.real, 0.0])
+            rows.append([0.5 * sig, -sig * r.real, sig * sig * r.imag * r.imag])
+            log_c -= 2 * np.log(sig)
+    const = lead_sign * np.exp(log_c)
+    rows[0][0] *= const
+    rows[0][1] *= const
+    if reps[0].imag != 0.0:  # the first factor is a pair: its second step adds sigma^2 b^2 h_0, which needs the constant too
+        rows[1][2] *= const
+    out = np.ascontiguousarray(rows, dtype=np.float64)
+    out.setflags(write=False)
+    if len(_product_cache) > 64:
+        _product_cache.clear()
+    _product_cache[key] = out
+    return out
+
+
+PRODUCT_GUARD = {
+    # compute dtype: (largest grid_err, largest eps * A * 8)
+    np.dtype(np.float64): (1e-10, 1e-8),
+    np.dtype(np.float32): (1e-4, 2.5e-4),
+}
+
+
+def product_stability(c, dtype=np.float64, program=None):
+    """The guard's measurements for the product form of the polynomial with Chebyshev coefficients `c` in `dtype`
+    (program: default cheb_to_product(c)): the scalar recurrence every eigencomponent goes through, run in the compute
+    dtype on a grid over [-1, 1], against the Chebyshev sum in extended precision (grid_err); the running error bound
+    A = sum_s max_t |h_s| max_t |R_s| / max |p|, R_s = what the remaining steps multiply an error made at step s by
+    (computed by running the remaining program on a unit impulse); finiteness of every coefficient and intermediate."""
+    c = np.asarray(c, dtype=np.float64).ravel()
+    dt = np.dtype(dtype)
+    prog = np.asarray(cheb_to_product(c, dt) if program is None else program, dtype=np.float64).reshape(-1, 3)
+    S = prog.shape[0]
+    K = c.size - 1
+    grid = np.unique(np.concatenate([np.cos(np.linspace(0.0, np.pi, 8 * K + 9)), [-1.0, 1.0]]))
+    tl, cl = grid.astype(np.longdouble), c.astype(np.longdouble)
+    t_old, t_cur = np.ones_like(tl), tl.copy()
+    p = cl[0] / 2 + cl[1] * t_cur
+    for k in range(2, K + 1):
+        t_old, t_cur = t_cur, 2 * tl * t_cur - t_old
+        p = p + cl[k] * t_cur
+    p_max = float(np.max(np.abs(p)))
+    scale = p_max if p_max > 0 else 1.0
+    with np.errstate(all="ignore"):
+        g, pr = grid.astype(dt), prog.astype(dt)
+        h_prev, h = np.zeros_like(g), np.ones_like(g)
+        h_max = []
+        for s in range(S):
+            gam = pr[s, 2] if s else dt.type(0)
+            h_prev, h = h, (pr[s, 0] * 2) * g * h + pr[s, 1] * h + gam * h_prev
+            h_max.append(float(np.max(np.abs(h))))
+        finite = bool(np.all(np.isfinite(pr)) and np.all(np.isfinite(h_max)))
+        grid_err = float(np.max(np.abs(h.astype(np.longdouble) - p))) / scale if finite else float("inf")
+        # what the rest of the program does to a unit error in h_{s+1} (h_s exact): run steps s+1 .. S-1 on (0, 1)
+        amp = 0.0
+        if finite:
+            e_prev, e = np.zeros_like(grid), np.ones_like(grid)  # after the LAST step an error stays as it is
+            rest = [1.0]
+            # backwards: the linear map of steps s+1.. is the forward recurrence started from (h_s, h_{s+1}) = (0, 1)
+            for s in range(S - 1, 0, -1):
+                a_prev, a_cur = np.zeros_like(grid), np.ones_like(grid)
+                for q in range(s, S):
+                    a_prev, a_cur = a_cur, (prog[q, 0] * 2) * grid * a_cur + prog[q, 1] * a_cur + prog[q, 2] * a_prev
+                rest.append(float(np.max(np.abs(a_cur))))
+                if S > 64 and (S - s) % 4:  # (long programs: every fourth suffix is enough for a bound of this kind)
+                    rest[-1] = max(rest[-1], rest[-2])
+            rest.reverse()  # rest[s]: amplification of an error made in h_{s+1}
+            amp = float(sum(a * b for a, b in zip(h_max, rest))) / scale
+    return {"S": int(S), "K": int(K), "dtype": dt.name, "grid_err": grid_err, "amplification": amp if finite else float("inf"),
+            "eps_amplification": float(np.finfo(dt).eps) * amp if finite else float("inf"), "finite": finite,
+            "h_max": max(h_max) if h_max else 0.0, "p_max": p_max,
+            "panel_passes_per_order": float(sum(2 if r[2] == 0 else 3 for r in prog)) / max(K, 1)}
+
+
+def product_guard(c, dtype=np.float64):
+    """(ok, measurements): may the polynomial with Chebyshev coefficients `c` be evaluated in product form in `dtype`?
+    False when the roots do not form a real polynomial's pairs, when the scalar program disagrees with the Chebyshev
+    sum on the grid beyond the dtype's threshold, when the running error bound exceeds it, or when an intermediate is
+    not representable (PRODUCT_GUARD)."""
+    c = np.asarray(c, dtype=np.float64).ravel()
+    dt = np.dtype(dtype)
+    key = ("product", c.tobytes(), dt.str)
+    hit = _guard_cache.get(key)
+    if hit is not None:
+        return hit
+    if dt not in PRODUCT_GUARD or c.size < 2 or not np.all(np.isfinite(c)):
+        out = (False, {"K": int(c.size - 1), "dtype": dt.name, "finite": False, "reason": "coefficients"})
+    else:
+        try:
+            m = product_stability(c, dt)
+        except (ValueError, np.linalg.LinAlgError) as e:
+            m = {"K": int(c.size - 1), "dtype": dt.name, "finite": False, "reason": "roots: " + str(e)}
+            out = (False, m)
+        else:
+            lim_grid, lim_amp = PRODUCT_GUARD[dt]
+            why = ("overflow" if not m["finite"] else "grid" if not m["grid_err"] <= lim_grid
+                   else "amplification" if not 8 * m["eps_amplification"] <= lim_amp else None)
+            m["reason"] = why
+            out = (why is None, m)
+    if len(_guard_cache) > 256:
+        _guard_cache.clear()
+    _guard_cache[key] = out
+    return out
+
+
 def choose_evaluation(evaluation, coeffs, dtype, n_vertices, n_signals, split=False):
-    """'recurrence' or 'newton' for one analysis call.  'newton' is the caller's explicit choice (a polynomial that
-    does not fit the compute dtype is an error then, not a silent fallback); 'auto' takes Newton only where it is
-    both faster and cleared by newton_guard()."""
+    """'recurrence', 'newton' or 'product' for one analysis call.  'newton' / 'product' are the caller's explicit choice
+    (a polynomial that does not fit the compute dtype is an error then, not a silent fallback); 'auto' takes the product
+    form, else the Newton form, only where they are faster and cleared by product_guard() / newton_guard()."""
     if evaluation not in EVALUATIONS:
-        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
+        raise ValueError("evaluation must be 'recurrence', 'newton', 'product' or 'auto'")
     if evaluation == "recurrence" or coeffs.shape[0] != 1:
         return "recurrence"
+    if evaluation == "product":
+        if split:
+            raise ValueError("evaluation='product' is a single-device evaluation; it cannot be combined with a device "
+                             "list (devices=[...] / plugin.install(devices=[...]))")
+        ok, m = product_guard(coeffs[0], dtype)
+        if not m.get("finite", False):
+            raise ValueError("evaluation='product': the product form of this order-{} polynomial is not representable "
+                             "in {} ({}) - use the recurrence (or evaluation='auto')".format(m["K"], m["dtype"],
+                                                                                             m.get("reason")))
+        return "product"
     if evaluation == "newton":
         if split:
             # (the column split runs the three-term recurrence on every GPU: the same call must not return
@@ -268,6 +475,8 @@ def choose_evaluation(evaluation, coeffs, dtype, n_vertices, n_signals, split=Fa
         return "newton"
     if split or n_vertices * n_signals * np.dtype(dtype).itemsize < AUTO_MIN_PANEL_BYTES:
         return "recurrence"
+    if coeffs.shape[1] > 2 and product_guard(coeffs[0], dtype)[0]:
+        return "product"
     return "newton" if newton_guard(coeffs[0], dtype)[0] else "recurrence"
 
 
@@ -299,7 +508,7 @@ def cheby_op(G, c, signal, **kwargs):
     devices = _device_list(G, kwargs.get("devices"))
     evaluation = kwargs.get("evaluation") or _configured_evaluation(G)
     if evaluation not in EVALUATIONS:
-        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
+        raise ValueError("evaluation must be 'recurrence', 'newton', 'product' or 'auto'")
     if devices is not None and x.shape[1] > 0:
         choose_evaluation(evaluation, coeffs, np.float64, G.N, x.shape[1], split=True)  # ('newton' + a split: an error)
         # signal-parallel: the graph replicated per GPU, the columns split, one RCCL gather
@@ -313,6 +522,8 @@ def cheby_op(G, c, signal, **kwargs):
             how = choose_evaluation(evaluation, coeffs, dev.dtype, G.N, x.shape[1])
         if how == "newton":
             y, ms = dev.newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
+        elif how == "product":
+            y, ms = dev.program_filter(cheb_to_product(coeffs[0], dev.dtype), x, G.lmax)
         else:
             y, ms = dev.cheby_filter(coeffs, x, G.lmax, _capi.ANALYSIS)
     _record_timing(G, ms, how)
@@ -499,6 +710,8 @@ def _filter_device_array(bank, s, cube_shape, coeffs, devices, evaluation=None):
         how = choose_evaluation(evaluation or _configured_evaluation(bank.G), coeffs, dev.dtype, N, nsig)
     if N * nsig and how == "newton":
         ms = dev.newton_filter_dev(*cheb_to_newton(coeffs[0]), x_ptr, out.ptr, nsig, bank.G.lmax)
+    elif N * nsig and how == "product":
+        ms = dev.program_filter_dev(cheb_to_product(coeffs[0], dev.dtype), x_ptr, out.ptr, nsig, bank.G.lmax)
     elif N * nsig:
         ms = dev.cheby_filter_dev(coeffs, x_ptr, out.ptr, nsig, bank.G.lmax,
                                   _capi.SYNTHESIS if synthesis else _capi.ANALYSIS)

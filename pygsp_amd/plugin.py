@@ -188,7 +188,7 @@ def install(pygsp_module=None, laplacian="device", dtype=np.float64, device=0, r
     polynomial for the compute dtype, the recurrence otherwise); None (default): pygsp_amd.filters.EVALUATION,
     which is 'recurrence' unless filters.set_evaluation() changed it."""
     if evaluation is not None and evaluation not in _filters.EVALUATIONS:
-        raise ValueError("evaluation must be 'recurrence', 'newton' or 'auto'")
+        raise ValueError("evaluation must be 'recurrence', 'newton', 'product' or 'auto'")
     if laplacian not in ("device", "host"):
         raise ValueError("laplacian must be 'device' or 'host'")
     if lmax not in ("device", "reference"):

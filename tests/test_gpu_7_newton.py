@@ -107,13 +107,16 @@ def test_auto_evaluation_at_headline_size(dtype):
     xd = engine.DeviceArray.from_host(dev.ctx, x, dtype)
     old = G.compute_dtype
     G.compute_dtype = dt
-    worst = {}
+    worst, picked = {}, {}
     try:
         for order in (30, 50, 100, 200):
             for i, (name, bank) in enumerate(zip(h["names"], h["banks"])):
                 c = filters.compute_cheby_coeff(bank, m=order)
-                expect = "newton" if filters.newton_guard(c, dt)[0] else "recurrence"
-                assert expect == ("recurrence" if (dt == np.float32 and order == 200) else "newton"), (name, order)
+                expect = ("product" if filters.product_guard(c, dt)[0] else
+                          "newton" if filters.newton_guard(c, dt)[0] else "recurrence")
+                if expect != "product":  # (what the Newton guard alone decides, as before the product form existed)
+                    assert expect == ("recurrence" if (dt == np.float32 and order == 200) else "newton"), (name, order)
+                picked[expect] = picked.get(expect, 0) + 1
                 y = bank.filter(xd, order=order, evaluation="auto")
                 assert isinstance(y, engine.DeviceArray) and G._gspx_last_evaluation == expect
                 got = np.asarray(y)[:, :2].astype(np.float64)
@@ -124,10 +127,16 @@ def test_auto_evaluation_at_headline_size(dtype):
         if dt == np.float32:
             with pytest.raises(ValueError, match="not representable"):
                 h["banks"][0].filter(xd, order=200, evaluation="newton")
-        # 'auto' == 'newton' bit for bit where the guard clears it, and the recurrence stays the default
+        # 'auto' == the form it names, bit for bit; every form on its own at a tenth of the bar; the recurrence stays
+        # the default
+        assert picked.get("product", 0) >= 8 and picked.get("newton", 0) >= 4, picked
+        c30 = filters.compute_cheby_coeff(h["banks"][0], m=30)
+        how = "product" if filters.product_guard(c30, dt)[0] else "newton"
         y_auto = np.asarray(h["banks"][0].filter(xd, order=30, evaluation="auto"))
-        y_newt = np.asarray(h["banks"][0].filter(xd, order=30, evaluation="newton"))
-        assert np.array_equal(y_auto, y_newt)
+        assert np.array_equal(y_auto, np.asarray(h["banks"][0].filter(xd, order=30, evaluation=how)))
+        for form in ("newton", "product"):
+            yf = np.asarray(h["banks"][0].filter(xd, order=30, evaluation=form))[:, :2].astype(np.float64)
+            assert rel_err(yf, h["ref"][30][0]) < tol, form
         h["banks"][0].filter(xd, order=30)
         assert G._gspx_last_evaluation == "recurrence"
     finally:
@@ -135,4 +144,51 @@ def test_auto_evaluation_at_headline_size(dtype):
         xd.free()
         if dt != old:
             G._dev.pop(dt).destroy()
-    print("worst Newton/auto error at 1M x 64, {}: {:.2e} (bar/10 = {:.0e})".format(dt.name, max(worst.values()), tol))
+    print("worst auto error at 1M x 64, {}: {:.2e} (bar/10 = {:.0e}); forms picked: {}".format(
+        dt.name, max(worst.values()), tol, picked))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nsig", [1, 3, 8, 16, 33, 64, 130])
+def test_product_form_matches_reference(ctx, dtype, nsig):
+    """gspx_poly_program in product form (filters.cheb_to_product) against the oracle on ragged graphs with a hub row
+    and isolated vertices, every panel width, with and without an internal order, the plain kernels and batching."""
+    n = 3001
+    W = random_graph(n, 9, seed=300 + nsig, hub=True, isolated=4)
+    L = orc.laplacian(W)
+    lmax = upper_lmax(W)
+    rng = np.random.default_rng(nsig)
+    x = rng.standard_normal((n, nsig))
+    perm = rng.permutation(n).astype(np.int32) if nsig % 2 else None
+    dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=perm, ctx=ctx)
+    tol = TOL[np.dtype(dtype)] * 100
+    for scale, order in ((7, 25), (40, 30), (5, 1), (5, 2), (3, 60)):
+        c = orc.compute_cheby_coeff(orc.heat_kernel(scale, lmax), lmax, order)
+        if not filters.product_guard(c, dtype)[0]:
+            continue
+        prog = filters.cheb_to_product(c, dtype)
+        y, ms = dev.program_filter(prog, x, lmax)
+        ref = orc.cheby_op(L, lmax, c, x.astype(dtype).astype(np.float64))
+        assert rel_err(y, ref) < tol, (scale, order)
+    for kern in (1, 5):
+        if nsig <= 4:
+            break
+        ctx.set_option("kernel", kern)
+        y, _ = dev.program_filter(prog, x, lmax)
+        assert rel_err(y, ref) < tol, kern
+    ctx.set_option("kernel", 0)
+    ctx.set_option("max_batch", 8)
+    y, _ = dev.program_filter(prog, x, lmax)
+    assert rel_err(y, ref) < tol
+    ctx.set_option("max_batch", 0)
+    # the Newton form is the same entry point with old_is_x: equal to gspx_newton_filter bit for bit
+    c = orc.compute_cheby_coeff(orc.heat_kernel(7, lmax), lmax, 25)
+    nodes, d = filters.cheb_to_newton(c)
+    K = nodes.size
+    rows = [[0.5 * d[K], 0.0, d[K - 1] - d[K] * nodes[K - 1]]] + [[0.5, -nodes[K - 1 - s], d[K - 1 - s]] for s in range(1, K)]
+    y_prog, _ = dev.program_filter(np.array(rows), x, lmax, old_is_x=True)
+    y_newt, _ = dev.newton_filter(nodes, d, x, lmax)
+    assert np.array_equal(y_prog, y_newt)
+    with pytest.raises(TypeError):
+        dev.program_filter(np.zeros((0, 3)), x, lmax)
+    dev.destroy()

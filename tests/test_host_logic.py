@@ -567,15 +567,20 @@ def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
     # choose_evaluation
     c1, c6 = np.atleast_2d(c), np.tile(c, (6, 1))
     big = (1000000, 64)
-    assert filters.choose_evaluation("auto", c1, np.float64, *big) == "newton"
+    assert filters.choose_evaluation("auto", c1, np.float64, *big) == "product"          # (order 60 Heat(50): both cleared)
+    monkeypatch.setattr(filters, "product_guard", lambda cc, dt=np.float64: (False, {"reason": "test"}))
+    assert filters.choose_evaluation("auto", c1, np.float64, *big) == "newton"             # product refused: Newton
+    monkeypatch.undo()
     assert filters.choose_evaluation("auto", c6, np.float64, *big) == "recurrence"          # a bank
     assert filters.choose_evaluation("auto", c1, np.float64, 100000, 1) == "recurrence"     # launch-bound: hipGraph replay
     assert filters.choose_evaluation("auto", c1, np.float64, *big, split=True) == "recurrence"
     assert filters.choose_evaluation("recurrence", c1, np.float64, *big) == "recurrence"
     assert filters.choose_evaluation("newton", c1, np.float64, 100, 1) == "newton"           # explicit: always
     c200 = np.atleast_2d(orc.compute_cheby_coeff(orc.heat_kernel(50, lmax), lmax, 200))
+    monkeypatch.setattr(filters, "product_guard", lambda cc, dt=np.float64: (False, {"reason": "test"}))
     assert filters.choose_evaluation("auto", c200, np.float32, *big) == "recurrence"       # guard: overflow
     assert filters.choose_evaluation("auto", c200, np.float64, *big) == "newton"
+    monkeypatch.undo()
     with pytest.raises(ValueError, match="not representable"):
         filters.choose_evaluation("newton", c200, np.float32, *big)
     with pytest.raises(ValueError, match="single-device"):
@@ -595,6 +600,14 @@ def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
             calls.append("recurrence")
             return orc.cheby_op(L, lmx, cc, x).reshape(cc.shape[0], G.N, -1), 0.0
 
+        def program_filter(self, prog, x, lmx, old_is_x=False):
+            calls.append("product")
+            t = (2.0 / lmx) * L - sparse.identity(G.N)
+            h_prev, h = np.zeros_like(x), x
+            for s_, (sc, be, ga) in enumerate(prog):
+                h_prev, h = h, (2 * sc) * t.dot(h) + be * h + (ga if s_ else 0.0) * h_prev
+            return h, 0.0
+
         def newton_filter(self, nd, dc, x, lmx):
             calls.append("newton")
             t = (2.0 / lmx) * L - sparse.identity(G.N)
@@ -609,16 +622,69 @@ def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
     assert calls == ["recurrence"] and rel_err(y, g["heat10_y5"]) < 1e-13
     monkeypatch.setattr(filters, "AUTO_MIN_PANEL_BYTES", 0)
     y = heat.filter(g["signals5"], order=30, evaluation="auto")
+    assert calls[-1] == "product" and rel_err(y, g["heat10_y5"]) < 1e-12 and G._gspx_last_evaluation == "product"
+    y = heat.filter(g["signals5"], order=30, evaluation="newton")
     assert calls[-1] == "newton" and rel_err(y, g["heat10_y5"]) < 1e-13 and G._gspx_last_evaluation == "newton"
     filters.MexicanHat(G, Nf=6).filter(g["signals5"], order=40, evaluation="auto")
     assert calls[-1] == "recurrence"
     try:
         filters.set_evaluation("auto")
         heat.filter(g["signal"], order=30)
-        assert calls[-1] == "newton"
+        assert calls[-1] == "product"
     finally:
         filters.set_evaluation("recurrence")
     heat.filter(g["signal"], order=30)
     assert calls[-1] == "recurrence"
     with pytest.raises(ValueError):
         filters.set_evaluation("horner")
+
+
+def test_product_form_and_its_guard():
+    """The product form (round 6): p(t) = C prod sigma_j (t - r_j) from the roots of the Chebyshev series - real roots
+    one step, conjugate pairs two - as a program of (scale, beta, gamma) rows.  The scalar program reproduces the
+    Chebyshev sum; converged series are trimmed to their effective degree; the guard clears what the device then
+    computes to 1e-13 and refuses what it computes badly (measured on the device: Mexican-hat low-pass at order 100
+    reads 5e-8 in fp64 and 25 in fp32)."""
+    from numpy.polynomial import chebyshev as npcheb
+    lmax = 22.1
+    kernels = {"heat50": orc.heat_kernel(50, lmax), "heat10": orc.heat_kernel(10, lmax)}
+    kernels.update({"mh%d" % i: k for i, k in enumerate(orc.mexican_hat_kernels(lmax, 6))})
+    grid = np.cos(np.linspace(0, np.pi, 401))
+    for name, kern in kernels.items():
+        for order in (2, 3, 30, 50, 100):
+            c = orc.compute_cheby_coeff(kern, lmax, order)
+            prog = filters.cheb_to_product(c, np.float64)
+            assert prog.shape[1] == 3 and 1 <= prog.shape[0] <= order and prog[0, 2] == 0.0
+            h_prev, h = np.zeros_like(grid), np.ones_like(grid)
+            for s, (sc, be, ga) in enumerate(prog):
+                h_prev, h = h, (2 * sc) * grid * h + be * h + (ga if s else 0.0) * h_prev
+            cc = c.copy()
+            cc[0] /= 2
+            p = npcheb.chebval(grid, cc)
+            assert np.max(np.abs(h - p)) < 2e-11 * np.max(np.abs(p)), (name, order)
+            ok, m = filters.product_guard(c, np.float64)
+            assert m["finite"] and m["grid_err"] < 2e-11 and 1.0 <= m["panel_passes_per_order"] * order / prog.shape[0] <= 3.0
+            assert ok == (8 * m["eps_amplification"] <= filters.PRODUCT_GUARD[np.dtype(np.float64)][1])
+    # the headline polynomial: 30 factors, 18 of them real roots (the interpolant oscillates about zero where the
+    # kernel is below its error), 2.2 panel passes per order; cleared in fp64
+    c = orc.compute_cheby_coeff(kernels["heat50"], lmax, 30)
+    ok, m = filters.product_guard(c, np.float64)
+    assert ok and m["S"] == 30 and abs(m["panel_passes_per_order"] - 2.2) < 0.05 and m["amplification"] < 1e3
+    # a converged series is trimmed: order 100 of Heat(10) is 22 factors in fp64 and fewer in fp32
+    c = orc.compute_cheby_coeff(kernels["heat10"], lmax, 100)
+    assert filters.cheb_to_product(c, np.float64).shape[0] < 30 > filters.cheb_to_product(c, np.float32).shape[0]
+    assert filters.product_guard(c, np.float64)[0] and filters.product_guard(c, np.float32)[0]
+    # refused: the Mexican-hat low-pass at order 100 (error amplification 9e11), in both dtypes
+    c = orc.compute_cheby_coeff(kernels["mh0"], lmax, 100)
+    for dt in (np.float64, np.float32):
+        ok, m = filters.product_guard(c, dt)
+        assert not ok and m["reason"] == "amplification" and m["amplification"] > 1e9
+    # explicit 'product' on a polynomial that does not fit: an error, not garbage; degenerate inputs
+    assert filters.choose_evaluation("product", np.atleast_2d(c), np.float64, 10, 1) == "product"  # finite: the caller's choice
+    with pytest.raises(ValueError, match="single-device"):
+        filters.choose_evaluation("product", np.atleast_2d(c), np.float64, 10, 1, split=True)
+    with pytest.raises(TypeError):
+        filters.cheb_to_product(np.array([1.0]))
+    with pytest.raises(ValueError):
+        filters.cheb_to_product(np.array([1.0, np.inf, 0.5]))
+    assert not filters.product_guard(np.array([2.0, 0.0, 0.0]), np.float64)[0]  # a constant: no product form
