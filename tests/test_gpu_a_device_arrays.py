@@ -338,8 +338,8 @@ def test_plugin_wrap_in_float32_and_with_a_device_list():
 
 def test_plugin_auto_evaluation_and_placement_tuning(monkeypatch):
     """The two opt-ins of round 6 through the seam of a pygsp-shaped package: install(evaluation='auto') runs a single
-    filter's analysis in Newton form when the panel is large and the guard clears the polynomial (the recurrence
-    otherwise: banks, synthesis, small panels), to rounding of the reference's result; plugin.tune_placement draws
+    filter's analysis in product (else Newton) form when the panel is large and the guard clears the polynomial (the
+    recurrence otherwise: banks, synthesis, small panels), to rounding of the reference's result; plugin.tune_placement draws
     candidate backings for the work panels with the bank's own coefficients and leaves results bit-identical."""
     from pygsp_amd import plugin
 
@@ -356,7 +356,13 @@ def test_plugin_auto_evaluation_and_placement_tuning(monkeypatch):
         plugin.install(fake, evaluation="auto")
         monkeypatch.setattr(filters, "AUTO_MIN_PANEL_BYTES", 1 << 20)  # (60k x 64 fp64 = 30 MB: "large" for this test)
         y_auto = heat.filter(x, order=30)
-        assert G._gspx_last_evaluation == "newton" and rel_err(y_auto[:, :2], ref) < 1e-11
+        c30 = orc.compute_cheby_coeff(orc.heat_kernel(20, lmax), lmax, 30)
+        expect = "product" if filters.product_guard(c30, np.float64)[0] else "newton"
+        assert G._gspx_last_evaluation == expect and rel_err(y_auto[:, :2], ref) < 1e-11
+        for form in ("newton", "product"):  # each form on its own through the seam
+            plugin.install(fake, evaluation=form)
+            assert rel_err(heat.filter(x, order=30)[:, :2], ref) < 1e-11 and G._gspx_last_evaluation == form
+        plugin.install(fake, evaluation="auto")
         bank.filter(x[:, :4], order=20)
         assert G._gspx_last_evaluation == "recurrence"  # a bank keeps the reference's recurrence
         plugin.install(fake)  # evaluation back to the default
