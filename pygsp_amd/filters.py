@@ -356,9 +356,12 @@ def cheb_to_product(c, dtype=np.float64):
 
 
 PRODUCT_GUARD = {
-    # compute dtype: (largest grid_err, largest eps * A * 8)
-    np.dtype(np.float64): (1e-10, 1e-8),
-    np.dtype(np.float32): (1e-4, 2.5e-4),
+    # compute dtype: (largest grid_err, largest eps * A * 8).  The second figure is a WORST-CASE bound of the result's
+    # relative error and is allowed up to the path's bar (1e-5 / 1e-3, BASELINE.json): the device stays two orders of
+    # magnitude below it wherever it was measured (profiles/r06_product_form.md: bound 4.5e-4 -> 6.8e-7, 1e-4 -> 5e-11),
+    # and tests/test_gpu_7_newton.py holds every form 'auto' picks to a tenth of the bar at 1M x 64.
+    np.dtype(np.float64): (1e-10, 1e-5),
+    np.dtype(np.float32): (1e-4, 1e-3),
 }
 
 
