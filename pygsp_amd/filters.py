@@ -80,6 +80,9 @@ def _quadrature_tables(m, points):
 EVALUATIONS = ("recurrence", "newton", "product", "auto")
 EVALUATION = "recurrence"
 AUTO_MIN_PANEL_BYTES = 32 << 20  # below: the recurrence replays as one hipGraph (gspx option graph_launch = 2)
+AUTO_MAX_HOST_PANEL_BYTES = 48 << 20  # host arrays beyond this are pipelined over PCIe in column batches by the
+                                      # recurrence's entry point (gspx_cheby_filter): the call is bound by the link, and the
+                                      # one-shot copies of the program entry points would cost more than their kernels save
 
 
 def set_evaluation(mode):
@@ -523,6 +526,8 @@ def cheby_op(G, c, signal, **kwargs):
         how = "recurrence"
         if evaluation != "recurrence":  # (the default never looks at the device graph's dtype or the guard)
             how = choose_evaluation(evaluation, coeffs, dev.dtype, G.N, x.shape[1])
+            if evaluation == "auto" and G.N * x.shape[1] * np.dtype(dev.dtype).itemsize >= AUTO_MAX_HOST_PANEL_BYTES:
+                how = "recurrence"  # host arrays of this size: the pipelined recurrence (DeviceArrays take the other forms)
         if how == "newton":
             y, ms = dev.newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
         elif how == "product":

@@ -623,6 +623,12 @@ def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
     monkeypatch.setattr(filters, "AUTO_MIN_PANEL_BYTES", 0)
     y = heat.filter(g["signals5"], order=30, evaluation="auto")
     assert calls[-1] == "product" and rel_err(y, g["heat10_y5"]) < 1e-12 and G._gspx_last_evaluation == "product"
+    monkeypatch.setattr(filters, "AUTO_MAX_HOST_PANEL_BYTES", 1)  # host arrays that the recurrence's entry point would
+    heat.filter(g["signals5"], order=30, evaluation="auto")        # pipeline over PCIe: 'auto' leaves them to it
+    assert calls[-1] == "recurrence" and G._gspx_last_evaluation == "recurrence"
+    heat.filter(g["signals5"], order=30, evaluation="product")     # (an explicit choice is honoured)
+    assert calls[-1] == "product"
+    monkeypatch.setattr(filters, "AUTO_MAX_HOST_PANEL_BYTES", 48 << 20)
     y = heat.filter(g["signals5"], order=30, evaluation="newton")
     assert calls[-1] == "newton" and rel_err(y, g["heat10_y5"]) < 1e-13 and G._gspx_last_evaluation == "newton"
     filters.MexicanHat(G, Nf=6).filter(g["signals5"], order=40, evaluation="auto")
