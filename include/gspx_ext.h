@@ -264,7 +264,9 @@ int gspx_ctx_tune_placement(gspx_graph* g, double lmax, int M, const double* coe
 /* Calibration: total GB/s of n_read (0-4) read streams and n_write (0-2) write streams of bytes_per_stream each, walked
  * together by workgroups_per_cu persistent workgroups per CU, 16 bytes per lane (nt: bit 0 non-temporal loads, bit 1
  * non-temporal stores, bit 2 write stream w overwrites read stream w in place, bit 3 the recurrence step's walk - every
- * workgroup takes 32 KB blocks of its XCD's eighth of every stream - instead of a grid-stride sweep) - what the memory system delivers to a read : write ratio with nothing else in the way. */
+ * workgroup takes 32 KB blocks of its XCD's eighth of every stream - instead of a grid-stride sweep, bit 4 the streams lie
+ * in the context's own T workspace instead of fresh allocations - GSPX_ERR_INVALID when it is smaller) - what the memory
+ * system delivers to a read : write ratio with nothing else in the way. */
 int gspx_bench_streams(gspx_ctx* ctx, int64_t bytes_per_stream, int n_read, int n_write, int nt, int workgroups_per_cu,
                        int iters, double* gbps);
 
