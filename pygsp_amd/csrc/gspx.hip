@@ -429,6 +429,14 @@ struct gspx_ctx {
   std::vector<unsigned char> seen_key;   // key of the last eager call (empty: none)
   std::vector<unsigned char> graph_key;  // key the instantiated graph was captured for
   hipGraphExec_t graph_exec = nullptr;
+  // a polynomial program for the batches of the pipelined host-pointer call instead of the recurrence (set by
+  // gspx_poly_program for the duration of its call)
+  const struct BatchProgram* batch_program = nullptr;
+};
+struct BatchProgram {
+  int S;
+  const double *sc, *be, *ga;
+  bool old_is_x;
 };
 
 // any other work on the context invalidates a recorded replay (it may have rewritten the weights,
@@ -2552,28 +2560,6 @@ extern "C" int gspx_poly_program_dev(gspx_graph* g, double lmax, int S, const do
   return rc;
 }
 
-// ... and with host arrays (one copy in, the program, one copy out)
-extern "C" int gspx_poly_program(gspx_graph* g, double lmax, int S, const double* scale, const double* beta,
-                                 const double* gamma, int old_is_x, int64_t Nsig, const void* x_host, void* y_host,
-                                 double* kernel_ms) {
-  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
-  if (Nsig > 0 && g->N > 0 && (!x_host || !y_host)) return set_err(GSPX_ERR_INVALID, "null signal pointer");
-  gspx_ctx* ctx = g->ctx;
-  HIPCHK(hipSetDevice(ctx->device));
-  const size_t n = (size_t)g->N * (size_t)std::max<int64_t>(Nsig, 0) * elt_size(g->dtype);
-  if (n == 0) {
-    if (kernel_ms) *kernel_ms = 0;
-    return S < 1 ? set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape") : GSPX_OK;
-  }
-  CHK(ctx->io_x.ensure(n));
-  CHK(ctx->io_y.ensure(n));
-  HIPCHK(hipMemcpyAsync(ctx->io_x.p, x_host, n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  CHK(gspx_poly_program_dev(g, lmax, S, scale, beta, gamma, old_is_x, Nsig, ctx->io_x.p, ctx->io_y.p, kernel_ms));
-  HIPCHK(hipMemcpyAsync(y_host, ctx->io_y.p, n, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return GSPX_OK;
-}
 
 extern "C" int gspx_newton_filter_dev(gspx_graph* g, double lmax, int K, const double* nodes,
                                       const double* dcoef, int64_t Nsig, const void* x_dev,
@@ -2699,6 +2685,56 @@ extern "C" int gspx_cheby_filter(gspx_graph* g, double lmax, int Nf, int M, cons
   CHK(gspx_cheby_filter_dev(g, lmax, Nf, M, coeffs, Nsig, ctx->io_x.p, ctx->io_y.p, mode,
                             kernel_ms));
   HIPCHK(hipMemcpyAsync(y_host, ctx->io_y.p, n_out * e, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return GSPX_OK;
+}
+
+// gspx_poly_program_dev with host arrays: pipelined in column batches like gspx_cheby_filter when the call is large,
+// else one copy in, the program, one copy out
+extern "C" int gspx_poly_program(gspx_graph* g, double lmax, int S, const double* scale, const double* beta,
+                                 const double* gamma, int old_is_x, int64_t Nsig, const void* x_host, void* y_host,
+                                 double* kernel_ms) {
+  if (!g) return set_err(GSPX_ERR_INVALID, "null graph");
+  if (Nsig > 0 && g->N > 0 && (!x_host || !y_host)) return set_err(GSPX_ERR_INVALID, "null signal pointer");
+  gspx_ctx* ctx = g->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)g->N * (size_t)std::max<int64_t>(Nsig, 0) * elt_size(g->dtype);
+  if (n == 0) {
+    if (kernel_ms) *kernel_ms = 0;
+    return S < 1 ? set_err(GSPX_ERR_COEFF, "The coefficients have an invalid shape") : GSPX_OK;
+  }
+  if (S >= 1 && scale && beta && gamma && lmax > 0.0 && std::isfinite(lmax)) {
+    // large calls: the same column batches pipelined over pinned staging as gspx_cheby_filter, the program on each batch
+    bool finite = true;
+    for (int i = 0; i < S; ++i) finite = finite && std::isfinite(scale[i]) && std::isfinite(beta[i]) && std::isfinite(gamma[i]);
+    std::vector<int64_t> widths;
+    int threads = 1;
+    host_pipeline_shape(ctx->opt, elt_size(g->dtype), g->N, Nsig, 2, &widths, &threads);
+    if (finite && widths.size() >= 2) {
+      if (!ctx->pipe) ctx->pipe = new HostPipe();
+      replay_reset(ctx);
+      const BatchProgram prog{S, scale, beta, gamma, old_is_x != 0};
+      const double dummy[2] = {1.0, 0.0};  // (the pipeline's own argument list: unused while batch_program is set)
+      ctx->batch_program = &prog;
+      const int rc = g->dtype == GSPX_F32
+                         ? filter_host_pipelined<float>(g, lmax, 1, 2, dummy, Nsig, (const float*)x_host, (float*)y_host,
+                                                        GSPX_ANALYSIS, widths, threads, kernel_ms)
+                         : filter_host_pipelined<double>(g, lmax, 1, 2, dummy, Nsig, (const double*)x_host,
+                                                         (double*)y_host, GSPX_ANALYSIS, widths, threads, kernel_ms);
+      ctx->batch_program = nullptr;
+      if (rc != GSPX_HOSTPIPE_UNAVAILABLE) return rc;
+    }
+  }
+  if (ctx->pipe) {  // this host call is not pipelined: no stage times, no timeline of an earlier call
+    ctx->pipe->timing[6] = 0;
+    ctx->pipe->timeline.clear();
+  }
+  CHK(ctx->io_x.ensure(n));
+  CHK(ctx->io_y.ensure(n));
+  HIPCHK(hipMemcpyAsync(ctx->io_x.p, x_host, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  CHK(gspx_poly_program_dev(g, lmax, S, scale, beta, gamma, old_is_x, Nsig, ctx->io_x.p, ctx->io_y.p, kernel_ms));
+  HIPCHK(hipMemcpyAsync(y_host, ctx->io_y.p, n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return GSPX_OK;
 }

@@ -231,7 +231,10 @@ static int filter_host_pipelined(gspx_graph* g, double lmax, int Nf, int M, cons
     if (!wait_for([&] { return issued >= b + 1 && shipped >= b - 1; })) break;
     if (hipfail(hipStreamWaitEvent(ctx->stream, hp.h2d_ev[s], 0), "hipStreamWaitEvent")) break;
     stamp(b, 2);
-    const int rc = filter_dev_t<T>(g, lmax, Nf, M, coeffs, width_of(b), (const T*)hp.dx[s].p, (T*)hp.dy[so].p, mode);
+    const BatchProgram* bp = ctx->batch_program;  // (gspx_poly_program: a polynomial program on every batch)
+    const int rc = bp ? program_dev_t<T>(g, lmax, bp->S, bp->sc, bp->be, bp->ga, bp->old_is_x, width_of(b),
+                                         (const T*)hp.dx[s].p, (T*)hp.dy[so].p)
+                      : filter_dev_t<T>(g, lmax, Nf, M, coeffs, width_of(b), (const T*)hp.dx[s].p, (T*)hp.dy[so].p, mode);
     if (rc != GSPX_OK) {
       fail(rc);
       break;

@@ -80,9 +80,6 @@ def _quadrature_tables(m, points):
 EVALUATIONS = ("recurrence", "newton", "product", "auto")
 EVALUATION = "recurrence"
 AUTO_MIN_PANEL_BYTES = 32 << 20  # below: the recurrence replays as one hipGraph (gspx option graph_launch = 2)
-AUTO_MAX_HOST_PANEL_BYTES = 48 << 20  # host arrays beyond this are pipelined over PCIe in column batches by the
-                                      # recurrence's entry point (gspx_cheby_filter): the call is bound by the link, and the
-                                      # one-shot copies of the program entry points would cost more than their kernels save
 
 
 def set_evaluation(mode):
@@ -251,6 +248,16 @@ def newton_guard(c, dtype=np.float64):
         _guard_cache.clear()
     _guard_cache[key] = out
     return out
+
+
+def newton_program(nodes, dcoef):
+    """The Newton form's Horner recurrence h <- (t - r_j) h + d_j x, j = K-1 .. 0, as (scale, beta, gamma) rows of a
+    polynomial program with o_s = x (gspx_poly_program(old_is_x = 1)); what gspx_newton_filter runs."""
+    nodes, d = np.asarray(nodes, dtype=np.float64), np.asarray(dcoef, dtype=np.float64)
+    K = nodes.size
+    rows = [[0.5 * d[K], 0.0, d[K - 1] - d[K] * nodes[K - 1]]]
+    rows += [[0.5, -nodes[K - 1 - s], d[K - 1 - s]] for s in range(1, K)]
+    return np.ascontiguousarray(rows, dtype=np.float64)
 
 
 _product_cache = {}
@@ -526,10 +533,8 @@ def cheby_op(G, c, signal, **kwargs):
         how = "recurrence"
         if evaluation != "recurrence":  # (the default never looks at the device graph's dtype or the guard)
             how = choose_evaluation(evaluation, coeffs, dev.dtype, G.N, x.shape[1])
-            if evaluation == "auto" and G.N * x.shape[1] * np.dtype(dev.dtype).itemsize >= AUTO_MAX_HOST_PANEL_BYTES:
-                how = "recurrence"  # host arrays of this size: the pipelined recurrence (DeviceArrays take the other forms)
-        if how == "newton":
-            y, ms = dev.newton_filter(*cheb_to_newton(coeffs[0]), x, G.lmax)
+        if how == "newton":  # (as a program: host arrays of any size go through the same pipelined entry point)
+            y, ms = dev.program_filter(newton_program(*cheb_to_newton(coeffs[0])), x, G.lmax, old_is_x=True)
         elif how == "product":
             y, ms = dev.program_filter(cheb_to_product(coeffs[0], dev.dtype), x, G.lmax)
         else:

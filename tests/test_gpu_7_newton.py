@@ -192,3 +192,32 @@ def test_product_form_matches_reference(ctx, dtype, nsig):
     with pytest.raises(TypeError):
         dev.program_filter(np.zeros((0, 3)), x, lmax)
     dev.destroy()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_programs_on_host_arrays_are_pipelined_like_the_recurrence(ctx, dtype):
+    """gspx_poly_program with host arrays large enough to pipeline (column batches over pinned staging, the program on
+    every batch): bit-identical to the one-shot form (host_pipeline = 0), for the product and the Newton program, and
+    right against the oracle; the stage times of the pipelined call are reported like the recurrence's."""
+    G = graphs.Sensor(200000, k=8, seed=11, compute_dtype=dtype, ctx=ctx)
+    G.estimate_lmax("bounds")
+    dev = G.device_graph(dtype)
+    x = np.random.default_rng(5).standard_normal((G.N, 64)).astype(dtype)  # 51 / 102 MB: pipelined
+    c = orc.compute_cheby_coeff(orc.heat_kernel(10, G.lmax), G.lmax, 40)
+    ref = orc.cheby_op(orc.laplacian(G.W), G.lmax, c, x[:, :2].astype(np.float64))
+    progs = {"product": (filters.cheb_to_product(c, dtype), False),
+             "newton": (filters.newton_program(*filters.cheb_to_newton(c)), True)}
+    for name, (prog, old_is_x) in progs.items():
+        ctx.set_option("host_pipeline", 2)
+        y_pipe, _ = dev.program_filter(prog, x, G.lmax, old_is_x=old_is_x)
+        stages = ctx.last_host_timing()
+        assert stages is not None and stages["batches"] >= 2, name
+        ctx.set_option("host_pipeline", 0)
+        y_one, _ = dev.program_filter(prog, x, G.lmax, old_is_x=old_is_x)
+        assert ctx.last_host_timing() is None
+        ctx.set_option("host_pipeline", 1)
+        assert np.array_equal(y_pipe, y_one), name
+        assert rel_err(y_pipe[:, :2], ref) < BAR[np.dtype(dtype)] / 10, name
+    # through the API: evaluation='auto' on numpy arrays
+    y = filters.Heat(G, 10).filter(x, order=40, evaluation="auto")
+    assert G._gspx_last_evaluation == "product" and rel_err(y[:, :2], ref) < BAR[np.dtype(dtype)] / 10

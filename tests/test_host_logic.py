@@ -601,11 +601,12 @@ def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
             return orc.cheby_op(L, lmx, cc, x).reshape(cc.shape[0], G.N, -1), 0.0
 
         def program_filter(self, prog, x, lmx, old_is_x=False):
-            calls.append("product")
+            calls.append("newton" if old_is_x else "product")
             t = (2.0 / lmx) * L - sparse.identity(G.N)
             h_prev, h = np.zeros_like(x), x
             for s_, (sc, be, ga) in enumerate(prog):
-                h_prev, h = h, (2 * sc) * t.dot(h) + be * h + (ga if s_ else 0.0) * h_prev
+                o = x if old_is_x else (h_prev if s_ else 0.0 * x)
+                h_prev, h = h, (2 * sc) * t.dot(h) + be * h + ga * o
             return h, 0.0
 
         def newton_filter(self, nd, dc, x, lmx):
@@ -623,12 +624,8 @@ def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
     monkeypatch.setattr(filters, "AUTO_MIN_PANEL_BYTES", 0)
     y = heat.filter(g["signals5"], order=30, evaluation="auto")
     assert calls[-1] == "product" and rel_err(y, g["heat10_y5"]) < 1e-12 and G._gspx_last_evaluation == "product"
-    monkeypatch.setattr(filters, "AUTO_MAX_HOST_PANEL_BYTES", 1)  # host arrays that the recurrence's entry point would
-    heat.filter(g["signals5"], order=30, evaluation="auto")        # pipeline over PCIe: 'auto' leaves them to it
-    assert calls[-1] == "recurrence" and G._gspx_last_evaluation == "recurrence"
-    heat.filter(g["signals5"], order=30, evaluation="product")     # (an explicit choice is honoured)
+    heat.filter(g["signals5"], order=30, evaluation="product")     # (an explicit choice)
     assert calls[-1] == "product"
-    monkeypatch.setattr(filters, "AUTO_MAX_HOST_PANEL_BYTES", 48 << 20)
     y = heat.filter(g["signals5"], order=30, evaluation="newton")
     assert calls[-1] == "newton" and rel_err(y, g["heat10_y5"]) < 1e-13 and G._gspx_last_evaluation == "newton"
     filters.MexicanHat(G, Nf=6).filter(g["signals5"], order=40, evaluation="auto")
