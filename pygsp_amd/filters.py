@@ -283,7 +283,21 @@ def _leja_order_roots(points):
     return order
 
 
-PRODUCT_TRIM = {np.dtype(np.float64): 1e-14, np.dtype(np.float32): 1e-9}
+PRODUCT_TRIM = {np.dtype(np.float64): 1e-13, np.dtype(np.float32): 1e-9}  # (the quadrature's noise floor is ~3e-14)
+
+
+def effective_coefficients(c, dtype=np.float64):
+    """`c` without its negligible tail: trailing coefficients below PRODUCT_TRIM[dtype] of the largest are dropped (at
+    least c_0, c_1 stay).  A converged Chebyshev series ends in rounding noise of the quadrature; every |T_k| <= 1 on the
+    spectrum, so the polynomial moves by at most the sum of what is dropped - 1e-13 of its maximum at order 200 in fp64.
+    What evaluation='auto' evaluates, in whichever form: an order-200 Heat(50) is 41 terms."""
+    c = np.asarray(c, dtype=np.float64).ravel()
+    trim = PRODUCT_TRIM.get(np.dtype(dtype), 1e-14)
+    top = max(abs(c[0]) / 2, np.max(np.abs(c[1:]))) if c.size > 1 else 0.0
+    K = c.size - 1
+    while K > 1 and abs(c[K]) <= trim * top:
+        K -= 1
+    return c[:K + 1]
 
 
 def cheb_to_product(c, dtype=np.float64):
@@ -490,7 +504,7 @@ def choose_evaluation(evaluation, coeffs, dtype, n_vertices, n_signals, split=Fa
         return "recurrence"
     if coeffs.shape[1] > 2 and product_guard(coeffs[0], dtype)[0]:
         return "product"
-    return "newton" if newton_guard(coeffs[0], dtype)[0] else "recurrence"
+    return "newton" if newton_guard(effective_coefficients(coeffs[0], dtype), dtype)[0] else "recurrence"
 
 
 def _as_coeff_matrix(c):
@@ -533,12 +547,15 @@ def cheby_op(G, c, signal, **kwargs):
         how = "recurrence"
         if evaluation != "recurrence":  # (the default never looks at the device graph's dtype or the guard)
             how = choose_evaluation(evaluation, coeffs, dev.dtype, G.N, x.shape[1])
+        c_used = coeffs
+        if evaluation == "auto" and how != "product" and coeffs.shape[0] == 1:  # ('auto' evaluates the series without
+            c_used = effective_coefficients(coeffs[0], dev.dtype)[np.newaxis, :]  # its negligible tail, in every form)
         if how == "newton":  # (as a program: host arrays of any size go through the same pipelined entry point)
-            y, ms = dev.program_filter(newton_program(*cheb_to_newton(coeffs[0])), x, G.lmax, old_is_x=True)
+            y, ms = dev.program_filter(newton_program(*cheb_to_newton(c_used[0])), x, G.lmax, old_is_x=True)
         elif how == "product":
             y, ms = dev.program_filter(cheb_to_product(coeffs[0], dev.dtype), x, G.lmax)
         else:
-            y, ms = dev.cheby_filter(coeffs, x, G.lmax, _capi.ANALYSIS)
+            y, ms = dev.cheby_filter(c_used, x, G.lmax, _capi.ANALYSIS)
     _record_timing(G, ms, how)
     stacked = np.asarray(y, dtype=np.float64).reshape(coeffs.shape[0] * G.N, x.shape[1])
     return stacked[:, 0] if vector_in else stacked
@@ -720,7 +737,10 @@ def _filter_device_array(bank, s, cube_shape, coeffs, devices, evaluation=None):
     out = engine.DeviceArray.empty(dev.ctx, (N, nsig, 1 if synthesis else bank.Nf), dev.dtype)
     ms, how = 0.0, "recurrence"
     if not synthesis:
-        how = choose_evaluation(evaluation or _configured_evaluation(bank.G), coeffs, dev.dtype, N, nsig)
+        asked = evaluation or _configured_evaluation(bank.G)
+        how = choose_evaluation(asked, coeffs, dev.dtype, N, nsig)
+        if asked == "auto" and how != "product" and coeffs.shape[0] == 1 and N * nsig * dev.dtype.itemsize >= AUTO_MIN_PANEL_BYTES:
+            coeffs = effective_coefficients(coeffs[0], dev.dtype)[np.newaxis, :]  # (see cheby_op)
     if N * nsig and how == "newton":
         ms = dev.newton_filter_dev(*cheb_to_newton(coeffs[0]), x_ptr, out.ptr, nsig, bank.G.lmax)
     elif N * nsig and how == "product":

@@ -113,9 +113,8 @@ def test_auto_evaluation_at_headline_size(dtype):
             for i, (name, bank) in enumerate(zip(h["names"], h["banks"])):
                 c = filters.compute_cheby_coeff(bank, m=order)
                 expect = ("product" if filters.product_guard(c, dt)[0] else
-                          "newton" if filters.newton_guard(c, dt)[0] else "recurrence")
-                if expect != "product":  # (what the Newton guard alone decides, as before the product form existed)
-                    assert expect == ("recurrence" if (dt == np.float32 and order == 200) else "newton"), (name, order)
+                          "newton" if filters.newton_guard(filters.effective_coefficients(c, dt), dt)[0] else "recurrence")
+                assert expect == filters.choose_evaluation("auto", np.atleast_2d(c), dt, G.N, 64)
                 picked[expect] = picked.get(expect, 0) + 1
                 y = bank.filter(xd, order=order, evaluation="auto")
                 assert isinstance(y, engine.DeviceArray) and G._gspx_last_evaluation == expect
@@ -129,7 +128,7 @@ def test_auto_evaluation_at_headline_size(dtype):
                 h["banks"][0].filter(xd, order=200, evaluation="newton")
         # 'auto' == the form it names, bit for bit; every form on its own at a tenth of the bar; the recurrence stays
         # the default
-        assert picked.get("product", 0) >= 8 and picked.get("newton", 0) >= 4, picked
+        assert picked.get("product", 0) >= 16 and picked.get("newton", 0) >= 2, picked
         c30 = filters.compute_cheby_coeff(h["banks"][0], m=30)
         how = "product" if filters.product_guard(c30, dt)[0] else "newton"
         y_auto = np.asarray(h["banks"][0].filter(xd, order=30, evaluation="auto"))

@@ -576,11 +576,15 @@ def test_newton_guard_and_auto_evaluation(golden_sensor123, monkeypatch):
     assert filters.choose_evaluation("auto", c1, np.float64, *big, split=True) == "recurrence"
     assert filters.choose_evaluation("recurrence", c1, np.float64, *big) == "recurrence"
     assert filters.choose_evaluation("newton", c1, np.float64, 100, 1) == "newton"           # explicit: always
-    c200 = np.atleast_2d(orc.compute_cheby_coeff(orc.heat_kernel(50, lmax), lmax, 200))
-    monkeypatch.setattr(filters, "product_guard", lambda cc, dt=np.float64: (False, {"reason": "test"}))
-    assert filters.choose_evaluation("auto", c200, np.float32, *big) == "recurrence"       # guard: overflow
+    # (a series that has NOT converged by its order - the Mexican-hat low-pass: all 200 terms count; Heat(50) at order
+    # 200 is 41 terms to 'auto', in every form: filters.effective_coefficients)
+    c200 = np.atleast_2d(orc.compute_cheby_coeff(orc.mexican_hat_kernels(lmax, 6)[0], lmax, 200))
+    assert filters.effective_coefficients(c200[0], np.float32).size == 201
+    heat200 = orc.compute_cheby_coeff(orc.heat_kernel(50, lmax), lmax, 200)
+    assert filters.effective_coefficients(heat200, np.float64).size < 50 > filters.effective_coefficients(heat200, np.float32).size
+    assert filters.effective_coefficients(np.array([1.0, 1e-30]), np.float64).size == 2  # (c_0, c_1 always stay)
+    assert filters.choose_evaluation("auto", c200, np.float32, *big) == "recurrence"       # product refused, Newton overflows
     assert filters.choose_evaluation("auto", c200, np.float64, *big) == "newton"
-    monkeypatch.undo()
     with pytest.raises(ValueError, match="not representable"):
         filters.choose_evaluation("newton", c200, np.float32, *big)
     with pytest.raises(ValueError, match="single-device"):
