@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import cheby_oracle as orc  # noqa: E402
-from pygsp_amd import engine, graphs  # noqa: E402
+from pygsp_amd import engine, filters, graphs  # noqa: E402
 
 FULL = dict(sizes=(40000, 200000, 700000), widths=(1, 2, 3, 4, 5, 6, 8, 12, 16, 20, 32, 36, 64, 72, 96, 128, 160),
             orders=(1, 2, 3, 5, 11, 30))
@@ -94,11 +94,66 @@ def soak_host_pipeline(calls=60, N=150000, log=print):
     return runs, bad
 
 
+def soak_programs(rounds=3, sizes=(40000, 200000), widths=(1, 3, 8, 16, 20, 64, 96), orders=(5, 30, 60), log=print):
+    """The polynomial programs of evaluation='auto' (round 6: Newton form with o_s = x, product form written in place)
+    on host arrays - one shot and pipelined - against oracle columns, and call against call bit for bit."""
+    ctx = engine.default_context(0)
+    rng = np.random.default_rng(2)
+    bad = runs = 0
+    try:
+        for N in sizes:
+            W, coords = graphs.sensor_weights(N, k=8, seed=N + 1)
+            L = orc.laplacian(W)
+            lmax = 2.0 * float(np.ravel(W.sum(0)).max())
+            for dtype in (np.float64, np.float32):
+                dev = engine.DeviceGraph.from_w(W, dtype=dtype, perm=engine.locality_order(W, coords), ctx=ctx)
+                dev.build_gather_tiles()
+                tol = 1e-10 if dtype == np.float64 else 1e-4
+                for order in orders:
+                    for scale in (10, 50):
+                        c = orc.compute_cheby_coeff(orc.heat_kernel(scale, lmax), lmax, order)
+                        forms = {}
+                        if filters.product_guard(c, dtype)[0]:
+                            forms["product"] = (filters.cheb_to_product(c, dtype), False)
+                        ce = filters.effective_coefficients(c, dtype)
+                        if filters.newton_guard(ce, dtype)[0]:
+                            forms["newton"] = (filters.newton_program(*filters.cheb_to_newton(ce)), True)
+                        for nsig in widths:
+                            x = rng.standard_normal((N, nsig)).astype(dtype)
+                            cols = [0, nsig // 2, nsig - 1]
+                            ref = orc.cheby_op(L, lmax, c, x[:, cols].astype(np.float64))
+                            for name, (prog, old_is_x) in forms.items():
+                                first = None
+                                for r in range(rounds):
+                                    ctx.set_option("host_pipeline", 2 if r % 2 else 0)
+                                    ctx.set_option("host_batch", int(rng.choice([8, 16, 24])) if r % 2 else 0)
+                                    y, _ms = dev.program_filter(prog, x, lmax, old_is_x)
+                                    err = float(np.max(np.abs(y[:, cols] - ref)) / np.max(np.abs(ref)))
+                                    runs += 1
+                                    if not err < tol:
+                                        bad += 1
+                                        log("PROGRAM BAD", name, N, np.dtype(dtype).name, nsig, order, scale, err)
+                                    if r % 2 == 0:  # (batches of other widths run other builds: equal to rounding only)
+                                        if first is None:
+                                            first = y
+                                        elif not np.array_equal(first, y):
+                                            bad += 1
+                                            log("PROGRAM NOT REPEATABLE", name, N, np.dtype(dtype).name, nsig, order)
+                dev.destroy()
+            log("programs N", N, "done; runs", runs, "bad", bad)
+    finally:
+        for k, v in (("host_pipeline", 1), ("host_batch", 0)):
+            ctx.set_option(k, v)
+    return runs, bad
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     log = lambda *a: print(*a, flush=True)  # noqa: E731
     runs, bad = soak_kernel(rounds, log=log)
     r2, b2 = soak_host_pipeline(200, log=log)
+    r3, b3 = soak_programs(rounds, log=log)
+    runs, bad = runs + r3, bad + b3
     import test_gpu_9_fuzz as fuzz
     for seed in range(4, 16):
         try:
