@@ -6,7 +6,6 @@ stand-in of tests/seam_plugin.py - there is no GPU in the build container."""
 import doctest
 import json
 import os
-import sys
 
 import numpy
 

@@ -3,12 +3,11 @@ size-independent properties (linearity, the constant-signal identity p(L) 1 = p(
 Through the C-ABI on a real MI355X (`-m gpu`)."""
 import numpy as np
 import pytest
-from scipy import sparse
 
-from conftest import csr_from, rel_err
+from conftest import rel_err
 from gpu_helpers import BAR, TOL, ctx, random_graph, upper_lmax  # noqa: F401 (ctx is a fixture)
 from oracle import cheby_oracle as orc
-from pygsp_amd import _capi, engine, filters, graphs
+from pygsp_amd import engine, filters, graphs
 
 pytestmark = pytest.mark.gpu
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 from scipy import sparse
 
-from conftest import csr_from, rel_err
+from conftest import rel_err
 from gpu_helpers import BAR, TOL, ctx, random_graph, upper_lmax  # noqa: F401 (ctx is a fixture)
 from oracle import cheby_oracle as orc
 from pygsp_amd import _capi, engine, filters, graphs

@@ -2,12 +2,11 @@
 cheby_rect / Jackson siblings (approximations.py:117-225) against reference goldens.  `-m gpu`."""
 import numpy as np
 import pytest
-from scipy import sparse
 
 from conftest import csr_from, rel_err
 from gpu_helpers import BAR, TOL, ctx, random_graph, upper_lmax  # noqa: F401 (ctx is a fixture)
 from oracle import cheby_oracle as orc
-from pygsp_amd import _capi, engine, filters, graphs
+from pygsp_amd import filters, graphs
 
 pytestmark = pytest.mark.gpu
 

@@ -3,12 +3,11 @@ counterpart - the reference's result is the bar): small graphs over widths and d
 headline size over orders 30-200 and the Heat / Mexican-hat kernels behind the host-side guard.  `-m gpu`."""
 import numpy as np
 import pytest
-from scipy import sparse
 
 from conftest import csr_from, rel_err
 from gpu_helpers import BAR, TOL, ctx, random_graph, upper_lmax  # noqa: F401 (ctx is a fixture)
 from oracle import cheby_oracle as orc
-from pygsp_amd import _capi, engine, filters, graphs
+from pygsp_amd import engine, filters, graphs
 
 pytestmark = pytest.mark.gpu
 

@@ -9,7 +9,6 @@ import os
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
