@@ -36,7 +36,8 @@ def test_config1_sensor100k_single_signal(dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_headline_size_properties(ctx, dtype):
     """North-star size: 1M-vertex k=8 sensor graph (~10M stored entries), 64 signals, order 30.
-    Oracle on 2 sampled columns; linearity and the constant-signal identity on all 64."""
+    Oracle on ALL 64 columns in float64 (the reference's arithmetic; 48 s of scipy on one core) and on 8 of them in
+    float32; linearity and the constant-signal identity on all 64 in both."""
     N, nsig, order = 1000000, 64, 30
     W, coords = graphs.sensor_weights(N, k=8, seed=42)
     G = graphs.Graph(W, coords=coords, compute_dtype=dtype)
@@ -58,9 +59,9 @@ def test_headline_size_properties(ctx, dtype):
     # constant-signal identity
     gain = _constant_signal_gain(c)
     assert np.max(np.abs(y[:, 5] - 3.0 * gain)) < tol * abs(3.0 * gain)
-    # oracle on two columns
+    # the oracle: every column in float64, every ninth in float32
     L = orc.laplacian(W)
-    cols = [0, 63]
+    cols = list(range(nsig)) if dtype == np.float64 else list(range(0, nsig, 9))
     ref = orc.cheby_op(L, lmax, c, x[:, cols].astype(np.float64))
     assert rel_err(y[:, cols], ref) < tol * 1e-1
     # linearity: f(2 x_a - x_b) = 2 f(x_a) - f(x_b), columnwise
