@@ -25,7 +25,8 @@ def main():
         if h is not None:
             names[h] = c.get("name")
     wide = {k["kernel_id"] for k in tool["kernel_symbols"]
-            if "k_step_tile<double, 2, 16, false, false" in (k.get("formatted_kernel_name") or k.get("demangled_kernel_name") or k.get("kernel_name") or "")}
+            if "k_step_tile<double" in (k.get("formatted_kernel_name") or k.get("demangled_kernel_name") or k.get("kernel_name") or "")}
+    # (every recurrence launch of a call, like tools/zone_tlb_summary.py: 30 per call, 90 per candidate)
     recs = tool["callback_records"].get("counter_collection") or tool["buffer_records"].get("counter_collection")
     disp = []
     for r in recs:
