@@ -147,6 +147,42 @@ def test_auto_evaluation_at_headline_size(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_auto_evaluation_on_degenerate_polynomials(dtype):
+    """evaluation='auto' where the polynomial is not a filter's: the zero polynomial, a constant, degree one, the
+    shortest coefficient vector the reference accepts, an alternating series (no decay: nothing to trim), a short heat
+    series, random coefficients of order 200 - whatever form is picked, the result is the recurrence's to a tenth of
+    the bar and finite."""
+    h = headline_case()
+    G = h["G"]
+    dt = np.dtype(dtype)
+    x = h["x"][:, :16]
+    rng = np.random.default_rng(11)
+    cases = {
+        "zero": np.zeros(31), "constant": np.r_[2.0, np.zeros(30)], "degree one": np.r_[2.0, 1.0, np.zeros(29)],
+        "two coefficients": np.array([1.0, 0.5]), "alternating": (-1.0) ** np.arange(31),
+        "heat order 5": orc.compute_cheby_coeff(orc.heat_kernel(10, G.lmax), G.lmax, 5),
+        "random order 200": rng.standard_normal(201),
+    }
+    old = G.compute_dtype
+    G.compute_dtype = dt
+    try:
+        for name, c in cases.items():
+            y_rec = filters.cheby_op(G, c, x.astype(dtype), evaluation="recurrence")
+            y_auto = filters.cheby_op(G, c, x.astype(dtype), evaluation="auto")
+            how = G._gspx_last_evaluation
+            assert how == filters.choose_evaluation("auto", np.atleast_2d(c), dt, G.N, 16), name
+            assert np.all(np.isfinite(y_auto)), (name, how)
+            den = max(float(np.max(np.abs(y_rec))), 1e-300)
+            assert float(np.max(np.abs(y_auto - y_rec))) / den < BAR[dt] / 10, (name, how)
+            if name in ("zero", "constant"):
+                assert np.array_equal(y_auto, y_rec), (name, how)  # 0 and c_0 / 2 * x: exact in every form
+    finally:
+        G.compute_dtype = old
+        if dt != old:
+            G._dev.pop(dt).destroy()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("nsig", [1, 3, 8, 16, 33, 64, 130])
 def test_product_form_matches_reference(ctx, dtype, nsig):
     """gspx_poly_program in product form (filters.cheb_to_product) against the oracle on ragged graphs with a hub row
