@@ -826,11 +826,14 @@ class Filter:
                              "Nf = {}, got {}.".format(self.Nf, shape))
         return self.filter(s, method, order, devices=devices)
 
-    def tune_placement(self, n_signals, order=30, candidates=6, stride_mb=0):
+    def tune_placement(self, n_signals, order=30, candidates=32, stride_mb=8000):
         """One-off set-up for a serving loop of single-filter analysis calls of `n_signals` columns at `order`: draw
         `candidates` physical backings for the context's streamed workspaces, run that call (on scratch panels) on each
         and keep the fastest (engine.DeviceGraph.tune_placement; on MI355X the same call runs 0.54-0.60 of 8 TB/s
-        depending on which pages back its work panels - profiles/r06_placement.md).  Results of later calls are
+        depending on which pages back its work panels - profiles/r06_placement.md).  The defaults - 32 candidates with
+        8 GB held between two draws - sample the whole card, which is what finds a fast zone on every card measured
+        (5-13 s, what bench.py does in its set-up); stride_mb=0 with a handful of candidates takes half a second and
+        only helps where fast and slow pages are mixed at the start of the memory.  Results of later calls are
         bit-identical whichever backing is kept.  Returns the report {"launch_ms": [...], "kept": index}."""
         return tune_placement(self, n_signals, order, candidates, stride_mb=stride_mb)
 
@@ -852,7 +855,7 @@ class Filter:
         return frame_panels(self, order)
 
 
-def tune_placement(bank, n_signals, order=30, candidates=6, coefficients=None, stride_mb=0):
+def tune_placement(bank, n_signals, order=30, candidates=32, coefficients=None, stride_mb=8000):
     """Filter.tune_placement for any object with the reference's Filter attributes (the mirror class or, through
     pygsp_amd.plugin.tune_placement, the real pygsp.filters.Filter): one filter only."""
     from . import engine

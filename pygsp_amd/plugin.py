@@ -122,7 +122,7 @@ def to_device(G, s):
     return engine.DeviceArray.from_host(dev.ctx, arr, dev.dtype)
 
 
-def tune_placement(bank, n_signals, order=30, candidates=6, stride_mb=0):
+def tune_placement(bank, n_signals, order=30, candidates=32, stride_mb=8000):
     """Placement tuning (filters.tune_placement) for a real ``pygsp.filters.Filter`` of one kernel after install():
     its own compute_cheby_coeff, the graph's device Laplacian on the configured context."""
     return _filters.tune_placement(bank, n_signals, order, candidates, _reference_coefficients, stride_mb)
